@@ -1,0 +1,235 @@
+/*
+ * mppi_hip.h -- C ABI of libmppi_hip.so, the MI355X (gfx950) MPPI rollout engine.
+ *
+ * The reference (mit-acl/mppi_numba) has no FFI: its device boundary is the
+ * set of numba calls made by mppi_numba/mppi.py, terrain.py and config.py
+ * (cuda.device_array / cuda.to_device / copy_to_host / kernel[grid, block](...)).
+ * Each entry point below replaces one such group of calls; the reference
+ * file:line it stands in for is given next to it (paths relative to
+ * /root/reference/mppi_numba).  The Python host code binds this header with
+ * ctypes (mppi_numba_amd/_lib.py); INTEGRATION.md shows the binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 (MPPI_OK) or a negative mppi_status; the text of
+ *     the last failure on the calling thread is mppi_last_error();
+ *   - handles are opaque and not thread-safe; one host thread drives a handle,
+ *     as in the reference (single Python thread, default stream);
+ *   - host arrays are owned by the caller, device memory by the library;
+ *   - every call is synchronous from the caller's point of view unless its
+ *     name ends in _async;
+ *   - host-side array layouts are the reference's: noise (N,T,2) f32, u (T,2)
+ *     f32, costs/weights (N) f32, sampled grids (G,R,C) int8, maps (Rp,Cp) int8,
+ *     pmf (B,Rp,Cp) int8, state rollouts (V,T+1,3) f32, all C-contiguous.
+ *     Device-side layouts are private to the library.
+ */
+#ifndef MPPI_HIP_H
+#define MPPI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPPI_HIP_ABI_VERSION 1
+
+typedef enum mppi_status {
+  MPPI_OK = 0,
+  MPPI_ERR_INVALID = -1,   /* bad argument / shape mismatch                   */
+  MPPI_ERR_HIP = -2,       /* a HIP runtime call failed                        */
+  MPPI_ERR_STATE = -3,     /* call sequence error (maps or params not set ...) */
+  MPPI_ERR_NO_DEVICE = -4, /* no usable gfx950 device                          */
+  MPPI_ERR_COMM = -5       /* RCCL failure                                     */
+} mppi_status;
+
+/* which of the reference's solve_* variants the planner runs (mppi.py:193-211) */
+typedef enum mppi_mode {
+  MPPI_MODE_DET = 0,       /* use_det_dynamics                 mppi.py:308-375 */
+  MPPI_MODE_SPEED_MAP = 1, /* use_nom_dynamics_with_speed_map  mppi.py:237-305 */
+  MPPI_MODE_TDM = 2,       /* use_tdm (CVaR over M samples)    mppi.py:376-531 */
+  MPPI_MODE_BAREBONE = 3   /* barebone_mppi_numba.ipynb: no maps, disc obstacles */
+} mppi_mode;
+
+typedef enum mppi_rng_kind {
+  MPPI_RNG_PHILOX = 0,    /* rocRAND Philox4x32-10, counter keyed by the GLOBAL
+                             (rollout, step) index: results do not depend on the
+                             number of GPUs                                     */
+  MPPI_RNG_XOROSHIRO = 1  /* bit-compatible with numba.cuda.random
+                             (xoroshiro128+, stream per thread) for seed -> u
+                             known-answer tests against the reference           */
+} mppi_rng_kind;
+
+typedef enum mppi_math_kind {
+  MPPI_MATH_EXACT = 0, /* float64 trig/sqrt where the reference's CPU path has
+                          float64: costs bit-identical to it (default)          */
+  MPPI_MATH_FAST = 1   /* float32 sincosf/sqrtf: ~1 ulp cost differences        */
+} mppi_math_kind;
+
+const char* mppi_last_error(void);
+int mppi_abi_version(void);
+
+/* ---- device query: replaces the import-time query of config.py:9-12 ------- */
+typedef struct mppi_device_props {
+  int max_threads_per_block;
+  int max_block_dim_x;
+  int max_grid_dim_x;
+  int wavefront_size;
+  int compute_units;
+  int lds_bytes_per_cu;
+  char gcn_arch[64];
+  char name[128];
+} mppi_device_props;
+
+int mppi_device_count(int* count);
+int mppi_device_props_get(int device, mppi_device_props* out);
+
+/* ---- traction distribution map (TDM_Numba) -------------------------------- */
+typedef struct mppi_tdm mppi_tdm;
+
+typedef struct mppi_tdm_cfg {
+  int device;
+  int num_grids;        /* M for use_tdm, 1 for the deterministic modes
+                           (terrain.py:171-177)                                 */
+  int max_rows;         /* cfg.max_map_dim: allocation of sample_grid_batch     */
+  int max_cols;
+  int thread_dim_x;     /* cfg.tdm_sample_thread_dim (only shapes the xoroshiro
+                           compatible stream->cell mapping, terrain.py:645-668) */
+  int thread_dim_y;
+  int rng;              /* mppi_rng_kind */
+  int _reserved;
+  uint64_t seed;
+} mppi_tdm_cfg;
+
+/* terrain.py:164-180 init_device_vars_before_sampling */
+int mppi_tdm_create(const mppi_tdm_cfg* cfg, mppi_tdm** out);
+int mppi_tdm_destroy(mppi_tdm* tdm);
+
+/* terrain.py:331-333,370-371,405-406,495,506: upload of the padded PMF grid,
+ * masks and (speed-map mode) padded risk traction map.  bin_to_int8[b] is
+ * np.int8(100.*(bin_values[b]-lo)/(hi-lo)) (terrain.py:689) evaluated by the
+ * host in the dtypes the reference would hold; traction_lo / traction_ratio are
+ * bin_values_bounds[0] and 0.01*(bounds[1]-bounds[0]) (mppi.py:674-675).
+ * risk may be NULL. */
+int mppi_tdm_set_maps(mppi_tdm* tdm, const int8_t* pmf, int bins, int rows, int cols,
+                      const int8_t* bin_to_int8, double traction_lo, double traction_ratio,
+                      const int8_t* obstacle, const int8_t* unknown, const int8_t* risk);
+
+/* terrain.py:610-622 sample_grids (kernel terrain.py:633-695) */
+int mppi_tdm_sample_grids(mppi_tdm* tdm, double alpha_dyn);
+
+/* test/visualisation access to sample_grid_batch_d, host layout
+ * (num_grids, max_rows, max_cols); set writes the [:, :rows, :cols] window */
+int mppi_tdm_set_sampled_grids(mppi_tdm* tdm, const int8_t* grids, int rows, int cols);
+int mppi_tdm_get_sampled_grids(mppi_tdm* tdm, int8_t* out);
+
+/* xoroshiro-compatible generator only: copy the (streams, 2) uint64 states */
+int mppi_tdm_rng_states(mppi_tdm* tdm, uint64_t* out, long capacity, long* count);
+
+/* ---- planner (MPPI_Numba) -------------------------------------------------- */
+typedef struct mppi_planner mppi_planner;
+
+typedef struct mppi_planner_cfg {
+  int device;
+  int mode;                   /* mppi_mode */
+  int num_control_rollouts;   /* N over ALL ranks                               */
+  int num_steps;              /* T = int(cfg.T / cfg.dt)                        */
+  int num_grid_samples;       /* M (1 unless MPPI_MODE_TDM)                     */
+  int num_vis_state_rollouts; /* V                                              */
+  int rng;                    /* mppi_rng_kind                                  */
+  int math;                   /* mppi_math_kind                                 */
+  int rank;                   /* this handle owns rollouts
+                                 [rank*N/world, (rank+1)*N/world)               */
+  int world_size;
+  uint64_t seed;
+} mppi_planner_cfg;
+
+/* mppi.py:214-234 move_mppi_task_vars_to_device: one struct instead of nine
+ * to_device calls.  Fields the reference casts to np.float32 are float. */
+typedef struct mppi_params {
+  float x0[3];
+  float xgoal[2];
+  float vrange[2];
+  float wrange[2];
+  float u_std[2];
+  float dt;
+  float goal_tolerance;
+  float v_post_rollout;
+  float lambda_weight;
+  float cvar_alpha;
+  float obs_cost;
+  float unknown_cost;
+  float res;          /* lin_tdm.res                                  */
+  float xlo;          /* float32(lin_tdm.padded_xlimits[0])           */
+  float ylo;          /* float32(lin_tdm.padded_ylimits[0])           */
+  double dist_weight; /* passed to the kernels as a Python number     */
+  double alpha_dyn;   /* params['alpha_dyn'] (use_tdm), else 1.0      */
+  int num_opt;
+  int _reserved;
+} mppi_params;
+
+/* mppi.py:108-127 init_device_vars_before_solving */
+int mppi_planner_create(const mppi_planner_cfg* cfg, mppi_planner** out);
+int mppi_planner_destroy(mppi_planner* p);
+
+int mppi_planner_set_params(mppi_planner* p, const mppi_params* params);
+
+/* barebone notebook: params['obstacle_positions'] (K,2), ['obstacle_radius'] (K) */
+int mppi_planner_set_disc_obstacles(mppi_planner* p, const float* positions, const float* radii,
+                                    int count);
+
+/* mppi.py:539-542 shift_optimal_control_sequence / mppi.py:305,375 copy_to_host */
+int mppi_planner_set_u(mppi_planner* p, const float* u);
+int mppi_planner_get_u(mppi_planner* p, float* u);
+int mppi_planner_get_u_prev(mppi_planner* p, float* u);
+/* device-side u[:-k] = u[k:] (tail kept), no host round trip */
+int mppi_planner_shift_u(mppi_planner* p, int num_shifts);
+
+/* mppi.py:186-531 solve(): samples both TDMs once, then num_opt x
+ * {sample noise, rollout, update}; writes the (T,2) control sequence.
+ * lin/ang are NULL in MPPI_MODE_BAREBONE. */
+int mppi_planner_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, float* u_out);
+
+/* the same without sampling the TDMs and without the final copy: `iterations`
+ * back-to-back {noise, rollout, update} on the planner's stream */
+int mppi_planner_iterate_async(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int iterations);
+int mppi_planner_synchronize(mppi_planner* p);
+
+/* stage-level entry points (the individual kernel launches of mppi.py:259-303),
+ * used by the parity tests to inject identical noise / grids / costs */
+int mppi_planner_sample_noise(mppi_planner* p);                              /* mppi.py:1354 */
+int mppi_planner_set_noise(mppi_planner* p, const float* noise);             /* (N_local,T,2) */
+int mppi_planner_get_noise(mppi_planner* p, float* noise);
+int mppi_planner_rollout(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang);     /* mppi.py:613-1111 */
+int mppi_planner_set_costs(mppi_planner* p, const float* costs);             /* (N_local) */
+int mppi_planner_get_costs(mppi_planner* p, float* costs);
+int mppi_planner_get_sample_costs(mppi_planner* p, float* costs);            /* (N_local,M), TDM mode */
+int mppi_planner_update(mppi_planner* p);                                    /* mppi.py:1113-1191 */
+int mppi_planner_get_weights(mppi_planner* p, float* weights);               /* normalised, (N_local) */
+
+/* mppi.py:545-608 get_state_rollout -> (V, T+1, 3) */
+int mppi_planner_get_state_rollout(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, float* out);
+
+/* xoroshiro-compatible generator only: copy the (N_local*T, 2) uint64 states */
+int mppi_planner_rng_states(mppi_planner* p, uint64_t* out, long capacity, long* count);
+
+/* hipEvent timing of the last solve/iterate call, averaged per iteration (ms):
+ * [0] noise  [1] rollout  [2] update (weights + weighted sum + apply)  [3] collective */
+int mppi_planner_stage_times(mppi_planner* p, float ms[4]);
+/* GPU time (ms, hipEvents on the planner's stream) of the last iterate/solve call */
+int mppi_planner_last_elapsed_ms(mppi_planner* p, float* ms);
+
+/* ---- multi-GPU: N sharded over ranks, one RCCL all-gather of (2T+2) floats
+ *      per iteration (not in the reference) ------------------------------------ */
+#define MPPI_COMM_ID_BYTES 128
+int mppi_comm_unique_id(char id[MPPI_COMM_ID_BYTES]);
+int mppi_planner_comm_init(mppi_planner* p, const char id[MPPI_COMM_ID_BYTES]);
+/* host-staged alternative to RCCL (also what the gloo tests exercise):
+ * packet = {beta, den, num[T][2]} of the local shard */
+int mppi_planner_update_local(mppi_planner* p, float* packet);
+int mppi_planner_update_apply(mppi_planner* p, const float* packets, int count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPPI_HIP_H */
