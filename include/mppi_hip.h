@@ -213,8 +213,10 @@ int mppi_planner_get_state_rollout(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang
 /* xoroshiro-compatible generator only: copy the (N_local*T, 2) uint64 states */
 int mppi_planner_rng_states(mppi_planner* p, uint64_t* out, long capacity, long* count);
 
-/* hipEvent timing of the last solve/iterate call, averaged per iteration (ms):
+/* hipEvent timing (planner's stream) of the stages of the LAST iteration of the
+ * last solve/iterate call, in ms; recorded only while profiling is enabled:
  * [0] noise  [1] rollout  [2] update (weights + weighted sum + apply)  [3] collective */
+int mppi_planner_set_profiling(mppi_planner* p, int enabled);
 int mppi_planner_stage_times(mppi_planner* p, float ms[4]);
 /* GPU time (ms, hipEvents on the planner's stream) of the last iterate/solve call */
 int mppi_planner_last_elapsed_ms(mppi_planner* p, float* ms);
@@ -224,10 +226,12 @@ int mppi_planner_last_elapsed_ms(mppi_planner* p, float* ms);
 #define MPPI_COMM_ID_BYTES 128
 int mppi_comm_unique_id(char id[MPPI_COMM_ID_BYTES]);
 int mppi_planner_comm_init(mppi_planner* p, const char id[MPPI_COMM_ID_BYTES]);
-/* host-staged alternative to RCCL (also what the gloo tests exercise):
- * packet = {beta, den, num[T][2]} of the local shard */
-int mppi_planner_update_local(mppi_planner* p, float* packet);
-int mppi_planner_update_apply(mppi_planner* p, const float* packets, int count);
+/* host-staged alternative to RCCL (the exchange itself is then done by the
+ * caller, e.g. over gloo): packet = {beta, den, num[T][2]} of the local shard,
+ * 2T+2 doubles; update_apply takes the packets of all ranks in rank order */
+int mppi_planner_packet_len(mppi_planner* p, int* doubles);
+int mppi_planner_update_local(mppi_planner* p, double* packet);
+int mppi_planner_update_apply(mppi_planner* p, const double* packets, int count);
 
 #ifdef __cplusplus
 }

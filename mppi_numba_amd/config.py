@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Config for MPPI_Numba / TDM_Numba on MI355X.
+
+Mirrors /root/reference/mppi_numba/config.py (module globals config.py:9-14,
+class Config config.py:16-100): same constructor keywords, same attributes,
+same validation, clamping and messages, so `copy.deepcopy`, attribute
+mutation and pickling of Config objects keep working.
+
+Difference: the reference queries the GPU at import time (config.py:9).  Here
+the query goes through the C ABI (mppi_device_props_get) and only happens if
+a device is present; on a box without a GPU the gfx950 architectural limits
+are used, so that importing this module and building a Config never needs a
+GPU.  The values only steer clamps and messages, never arithmetic.
+"""
+
+# gfx950 (MI355X) launch limits; refreshed from the device when one is present
+_GFX950_LIMITS = dict(max_threads_per_block=1024, max_block_dim_x=1024,
+                      max_grid_dim_x=2 ** 31 - 1)
+
+
+def _query_limits():
+    limits = dict(_GFX950_LIMITS)
+    try:
+        from . import _lib
+        if _lib.device_count() > 0:
+            pr = _lib.device_props(0)
+            limits = dict(max_threads_per_block=pr.max_threads_per_block,
+                          max_block_dim_x=pr.max_block_dim_x,
+                          max_grid_dim_x=pr.max_grid_dim_x)
+    except (ImportError, OSError):
+        pass  # Config-only use without the built library
+    return limits
+
+
+_limits = _query_limits()
+max_threads_per_block = _limits["max_threads_per_block"]
+max_square_block_dim = (int(_limits["max_block_dim_x"] ** 0.5), int(_limits["max_block_dim_x"] ** 0.5))
+max_blocks = _limits["max_grid_dim_x"]
+max_rec_blocks = rec_max_control_rollouts = 15000
+rec_min_control_rollouts = 100
+
+
+class Config:
+
+    """ Configurations that are typically fixed throughout execution. """
+
+    def __init__(self,
+                 T=10,  # Horizon (s)
+                 dt=0.1,  # Length of each step (s)
+                 num_grid_samples=1024,  # Number of grid samples when sampling dynamics
+                 num_control_rollouts=1024,  # Number of control sequences
+                 max_speed_padding=5.0,  # Maximum assumed speed for padding the perimeter of grid
+                 tdm_sample_thread_dim=(16, 16),  # Only shapes the xoroshiro-compatible sampler
+                 num_vis_state_rollouts=20,  # Number of visualization rollouts
+                 max_map_dim=(250, 250),  # Largest padded map (cells); anything bigger is cropped
+                 seed=1,
+                 use_tdm=False,
+                 use_det_dynamics=False,
+                 use_nom_dynamics_with_speed_map=False,
+                 use_costmap=False,
+                 # --- extensions (not in the reference) ---
+                 enforce_recommended_limits=True,  # False lifts the [100, 15000] rollout clamp
+                 rng="philox",  # "philox" (rocRAND) | "xoroshiro" (numba-compatible streams)
+                 math="exact",  # "exact" (reference CPU-path roundings) | "fast" (float32 trig)
+                 device=0,
+                 ):
+
+        self.seed = seed
+        self.use_tdm = use_tdm
+        self.use_det_dynamics = use_det_dynamics
+        self.use_nom_dynamics_with_speed_map = use_nom_dynamics_with_speed_map
+        self.use_costmap = use_costmap
+        modes_on = sum([use_tdm, use_det_dynamics, use_nom_dynamics_with_speed_map, use_costmap])
+
+        assert T > 0
+        assert dt > 0
+        assert T > dt
+        assert modes_on == 1, "MPPI Config Error: Only one of the use_tdm, use_det_dynamics, use_nom_dynamics_with_speed_map, use_costmap can be true."
+        assert not self.use_costmap, "Interface with costmap2d is not yet implemented."
+
+        self.T = T
+        self.dt = dt
+        self.num_steps = int(T / dt)
+        assert self.num_steps > 0
+
+        self.max_threads_per_block = max_threads_per_block
+        self.enforce_recommended_limits = enforce_recommended_limits
+        assert rng in ("philox", "xoroshiro")
+        assert math in ("exact", "fast")
+        self.rng = rng
+        self.math = math
+        self.device = device
+
+        if num_grid_samples > max_threads_per_block:
+            print("WARNING: slow-down expected since each thread needs to handle multiple grid samples due to num_grid_samples({})>max_threads_per_block({})".format(
+                num_grid_samples, max_threads_per_block))
+
+        self.num_grid_samples = num_grid_samples
+        if self.num_grid_samples > max_rec_blocks and enforce_recommended_limits:
+            self.num_grid_samples = max_rec_blocks
+            print("MPPI Config: Limit num_grid_samples by recommended max block number (<={}). But this can be overwritten if needed.".format(max_rec_blocks))
+        elif self.num_grid_samples < 1:
+            self.num_grid_samples = 1
+            print("MPPI Config: Set num_grid_samples from {} -> 1. Need at least 1 map to work with".format(num_grid_samples))
+
+        self.num_control_rollouts = num_control_rollouts
+        if enforce_recommended_limits:
+            if self.num_control_rollouts > rec_max_control_rollouts:
+                self.num_control_rollouts = rec_max_control_rollouts
+                print("MPPI Config: Clip num_control_rollouts to be recommended max number of {}. (Max={})".format(
+                    rec_max_control_rollouts, max_blocks))
+            elif self.num_control_rollouts < rec_min_control_rollouts:
+                self.num_control_rollouts = rec_min_control_rollouts
+                print("MPPI Config: Clip num_control_rollouts to be recommended min number of {}. (Recommended max={})".format(
+                    rec_min_control_rollouts, rec_max_control_rollouts))
+        assert self.num_control_rollouts >= 1
+
+        self.max_speed_padding = max_speed_padding
+
+        self.tdm_sample_thread_dim = tuple(tdm_sample_thread_dim)
+        assert len(self.tdm_sample_thread_dim) == 2
+        assert self.tdm_sample_thread_dim[0] > 0
+        assert self.tdm_sample_thread_dim[1] > 0
+        requested = self.tdm_sample_thread_dim[0] * self.tdm_sample_thread_dim[1]
+        if requested >= max_threads_per_block:
+            self.tdm_sample_thread_dim = max_square_block_dim
+            print("MPPI Config: Requested {} threads per block (more than max {}) for sampling tdm. Change tdm_sample_thread_dim to {}".format(
+                requested, max_threads_per_block, max_square_block_dim))
+
+        # For visualizing state rollouts
+        self.num_vis_state_rollouts = min([num_vis_state_rollouts,
+                                           self.num_control_rollouts,
+                                           self.num_grid_samples])
+        self.num_vis_state_rollouts = max([1, self.num_vis_state_rollouts])
+
+        self.max_map_dim = max_map_dim

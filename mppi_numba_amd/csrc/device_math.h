@@ -1,0 +1,101 @@
+// device_math.h -- arithmetic building blocks of the rollout kernels (gfx950).
+//
+// The reference's CPU path (numba CUDA simulator) evaluates every kernel body
+// on numpy scalars: float32 (op) float32 stays float32, anything that meets a
+// Python float / int literal or `**2` is float64, and every store into a
+// float32 array rounds once.  MPPI_MATH_EXACT keeps exactly those rounding
+// points (float64 where the reference has float64) so that trajectories and
+// costs come out bit-identical; the float64 work sits off the critical
+// dependency chain of the integrator (it overlaps the map gather), see
+// DESIGN.md.  This file is compiled with -ffp-contract=off: an fma is only
+// used where written.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mppi {
+
+// xi = int32((x - xlo) // res)  (mppi.py:971-972).  numpy's float32 floor
+// division returns the floor of the EXACT quotient (it goes through fmod), so
+// floorf(a / b) is not enough when a / b rounds up to an integer.  q0 is within
+// one of the answer; the fused remainder has the sign of the exact remainder.
+__device__ __forceinline__ int floordiv_to_int(float a, float b, float inv_b) {
+  float q = floorf(a * inv_b);
+  float r = fmaf(-q, b, a);
+  q = (r < 0.0f) ? q - 1.0f : q;
+  q = (r >= b) ? q + 1.0f : q;
+  return (int)q;
+}
+
+// float64 sin/cos of an angle that is exactly a float32 value.
+// Cody-Waite reduction by pi/2 (33-bit head so that k*head is exact for
+// |k| < 2^20) followed by the classic degree-13 / degree-14 minimax kernels on
+// [-pi/4, pi/4] (coefficients as published in fdlibm's k_sin.c / k_cos.c).
+// Absolute error < 2e-16: after the float32 rounding of x + dt*v*tr*cos(th)
+// this is indistinguishable from libm's cos() except with probability ~1e-9
+// per step.  Large arguments take the library path.
+__device__ __forceinline__ void sincos_f64(double x, double& s_out, double& c_out) {
+  if (__builtin_expect(fabs(x) > 100000.0, 0)) {
+    double s, c;
+    sincos(x, &s, &c);
+    s_out = s;
+    c_out = c;
+    return;
+  }
+  const double two_over_pi = 6.36619772367581382433e-01;
+  const double pio2_hi = 1.57079632673412561417e+00;
+  const double pio2_lo = 6.07710050650619224932e-11;
+  double fn = rint(x * two_over_pi);
+  double y = fma(-fn, pio2_lo, fma(-fn, pio2_hi, x));
+  int n = (int)fn;
+  double z = y * y;
+  // sin kernel
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  double sy = fma(y * z, ps, y);
+  // cos kernel
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  double cy = fma(z * z, pc, fma(z, -0.5, 1.0));
+  double s = (n & 1) ? cy : sy;
+  double c = (n & 1) ? sy : cy;
+  s = (n & 2) ? -s : s;
+  c = ((n + 1) & 2) ? -c : c;
+  s_out = s;
+  c_out = c;
+}
+
+__device__ __forceinline__ float clip_f32(float v, float lo, float hi) {
+  // max(lo, min(hi, v)) as the reference writes it
+  return fmaxf(lo, fminf(hi, v));
+}
+
+// order-preserving float <-> uint mapping (for min reductions on integers)
+__device__ __forceinline__ uint32_t float_to_ordered(float f) {
+  uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_float(uint32_t k) {
+  uint32_t b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(b);
+}
+
+// 64-lane butterfly reductions (wave64; all lanes end with the result)
+__device__ __forceinline__ float wave_min_f32(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+}  // namespace mppi

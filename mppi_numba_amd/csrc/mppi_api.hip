@@ -1,0 +1,1091 @@
+// mppi_api.hip -- host side of libmppi_hip.so: handles, memory, launches, RCCL.
+// C ABI declared in include/mppi_hip.h.  Built for gfx950 only:
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC
+#include "../../include/mppi_hip.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rng_kernels.h"
+#include "rollout_kernels.h"
+#include "update_kernels.h"
+
+using namespace mppi;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return fail(MPPI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                  __LINE__);                                                                  \
+  } while (0)
+
+#define REQUIRE(cond, code, ...)             \
+  do {                                       \
+    if (!(cond)) return fail(code, __VA_ARGS__); \
+  } while (0)
+
+#define TRY(expr)           \
+  do {                      \
+    int _rc = (expr);       \
+    if (_rc != MPPI_OK) return _rc; \
+  } while (0)
+
+extern "C" const char* mppi_last_error(void) { return g_last_error.c_str(); }
+extern "C" int mppi_abi_version(void) { return MPPI_HIP_ABI_VERSION; }
+
+template <typename T>
+static int dev_alloc(T** p, size_t count) {
+  *p = nullptr;
+  if (count == 0) count = 1;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+  return MPPI_OK;
+}
+template <typename T>
+static void dev_free(T*& p) {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+static inline int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// ---------------------------------------------------------------------------
+// device query (config.py:9-12)
+// ---------------------------------------------------------------------------
+extern "C" int mppi_device_count(int* count) {
+  REQUIRE(count, MPPI_ERR_INVALID, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(MPPI_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return MPPI_OK;
+}
+
+extern "C" int mppi_device_props_get(int device, mppi_device_props* out) {
+  REQUIRE(out, MPPI_ERR_INVALID, "out is NULL");
+  int n = 0;
+  TRY(mppi_device_count(&n));
+  REQUIRE(device >= 0 && device < n, MPPI_ERR_NO_DEVICE, "device %d not present (%d devices)", device, n);
+  hipDeviceProp_t pr;
+  HIP_TRY(hipGetDeviceProperties(&pr, device));
+  memset(out, 0, sizeof(*out));
+  out->max_threads_per_block = pr.maxThreadsPerBlock;
+  out->max_block_dim_x = pr.maxThreadsDim[0];
+  out->max_grid_dim_x = pr.maxGridSize[0];
+  out->wavefront_size = pr.warpSize;
+  out->compute_units = pr.multiProcessorCount;
+  out->lds_bytes_per_cu = (int)pr.maxSharedMemoryPerMultiProcessor;
+  snprintf(out->gcn_arch, sizeof(out->gcn_arch), "%s", pr.gcnArchName);
+  snprintf(out->name, sizeof(out->name), "%s", pr.name);
+  return MPPI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// TDM
+// ---------------------------------------------------------------------------
+struct mppi_tdm {
+  mppi_tdm_cfg cfg;
+  hipStream_t stream = nullptr;
+  int8_t* grid = nullptr;  // [G][max_rows][max_cols] int8 (reference layout)
+  int8_t* pmf = nullptr;   // [B][rows][cols]
+  size_t pmf_capacity = 0;
+  int8_t* table = nullptr;  // [B] bin -> int8 traction
+  int table_capacity = 0;
+  int8_t* obs = nullptr;  // [rows][cols]
+  int8_t* unk = nullptr;
+  int8_t* risk = nullptr;
+  size_t map_capacity = 0;
+  uint64_t* states = nullptr;  // xoroshiro-compatible generator only
+  long n_states = 0;
+  int bins = 0, rows = 0, cols = 0;
+  bool has_risk = false, maps_set = false, one_hot = false;
+  double lo = 0.0, ratio = 0.0;
+  uint64_t epoch = 0;         // Philox call counter
+  uint64_t maps_version = 0;  // bumped by set_maps
+  uint64_t grid_version = 0;  // bumped whenever `grid` changes
+  uint64_t sampled_maps_version = ~0ULL;
+  double sampled_alpha = -1.0;
+};
+
+extern "C" int mppi_tdm_destroy(mppi_tdm* t) {
+  if (!t) return MPPI_OK;
+  (void)hipSetDevice(t->cfg.device);
+  dev_free(t->grid);
+  dev_free(t->pmf);
+  dev_free(t->table);
+  dev_free(t->obs);
+  dev_free(t->unk);
+  dev_free(t->risk);
+  dev_free(t->states);
+  if (t->stream) (void)hipStreamDestroy(t->stream);
+  delete t;
+  return MPPI_OK;
+}
+
+extern "C" int mppi_tdm_create(const mppi_tdm_cfg* cfg, mppi_tdm** out) {
+  REQUIRE(cfg && out, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(cfg->num_grids >= 1 && cfg->max_rows >= 1 && cfg->max_cols >= 1, MPPI_ERR_INVALID,
+          "bad TDM dimensions (grids=%d rows=%d cols=%d)", cfg->num_grids, cfg->max_rows, cfg->max_cols);
+  REQUIRE(cfg->thread_dim_x >= 1 && cfg->thread_dim_y >= 1, MPPI_ERR_INVALID, "bad thread_dim");
+  REQUIRE(cfg->rng == MPPI_RNG_PHILOX || cfg->rng == MPPI_RNG_XOROSHIRO, MPPI_ERR_INVALID, "bad rng kind");
+  mppi_device_props pr;
+  TRY(mppi_device_props_get(cfg->device, &pr));
+  HIP_TRY(hipSetDevice(cfg->device));
+  mppi_tdm* t = new mppi_tdm();
+  t->cfg = *cfg;
+  int rc = MPPI_OK;
+  do {
+    if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess) {
+      rc = fail(MPPI_ERR_HIP, "hipStreamCreate failed");
+      break;
+    }
+    size_t cells = (size_t)cfg->num_grids * cfg->max_rows * cfg->max_cols;
+    if ((rc = dev_alloc(&t->grid, cells)) != MPPI_OK) break;
+    // the reference leaves the batch uninitialised (terrain.py:168); zero is friendlier
+    if (hipMemsetAsync(t->grid, 0, cells, t->stream) != hipSuccess) {
+      rc = fail(MPPI_ERR_HIP, "memset failed");
+      break;
+    }
+    if (cfg->rng == MPPI_RNG_XOROSHIRO) {
+      t->n_states = (long)cfg->num_grids * cfg->thread_dim_x * cfg->thread_dim_y;
+      std::vector<uint64_t> host(2 * (size_t)t->n_states);
+      xoroshiro_init_host(host.data(), t->n_states, cfg->seed);
+      if ((rc = dev_alloc(&t->states, host.size())) != MPPI_OK) break;
+      if (hipMemcpy(t->states, host.data(), host.size() * sizeof(uint64_t), hipMemcpyHostToDevice) !=
+          hipSuccess) {
+        rc = fail(MPPI_ERR_HIP, "state upload failed");
+        break;
+      }
+    }
+    if (hipStreamSynchronize(t->stream) != hipSuccess) {
+      rc = fail(MPPI_ERR_HIP, "sync failed");
+      break;
+    }
+  } while (0);
+  if (rc != MPPI_OK) {
+    std::string keep = g_last_error;
+    mppi_tdm_destroy(t);
+    g_last_error = keep;
+    return rc;
+  }
+  *out = t;
+  return MPPI_OK;
+}
+
+extern "C" int mppi_tdm_set_maps(mppi_tdm* t, const int8_t* pmf, int bins, int rows, int cols,
+                                 const int8_t* bin_to_int8, double traction_lo, double traction_ratio,
+                                 const int8_t* obstacle, const int8_t* unknown, const int8_t* risk) {
+  REQUIRE(t && pmf && bin_to_int8 && obstacle && unknown, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(bins >= 1 && rows >= 1 && cols >= 1, MPPI_ERR_INVALID, "bad map dims");
+  REQUIRE(rows <= t->cfg.max_rows && cols <= t->cfg.max_cols, MPPI_ERR_INVALID,
+          "padded map %dx%d exceeds max_map_dim %dx%d", rows, cols, t->cfg.max_rows, t->cfg.max_cols);
+  HIP_TRY(hipSetDevice(t->cfg.device));
+  size_t plane = (size_t)rows * cols, vol = plane * bins;
+  if (vol > t->pmf_capacity) {
+    dev_free(t->pmf);
+    TRY(dev_alloc(&t->pmf, vol));
+    t->pmf_capacity = vol;
+  }
+  if (bins > t->table_capacity) {
+    dev_free(t->table);
+    TRY(dev_alloc(&t->table, (size_t)bins));
+    t->table_capacity = bins;
+  }
+  if (plane > t->map_capacity) {
+    dev_free(t->obs);
+    dev_free(t->unk);
+    dev_free(t->risk);
+    TRY(dev_alloc(&t->obs, plane));
+    TRY(dev_alloc(&t->unk, plane));
+    TRY(dev_alloc(&t->risk, plane));
+    t->map_capacity = plane;
+  }
+  HIP_TRY(hipMemcpyAsync(t->pmf, pmf, vol, hipMemcpyHostToDevice, t->stream));
+  HIP_TRY(hipMemcpyAsync(t->table, bin_to_int8, (size_t)bins, hipMemcpyHostToDevice, t->stream));
+  HIP_TRY(hipMemcpyAsync(t->obs, obstacle, plane, hipMemcpyHostToDevice, t->stream));
+  HIP_TRY(hipMemcpyAsync(t->unk, unknown, plane, hipMemcpyHostToDevice, t->stream));
+  if (risk) HIP_TRY(hipMemcpyAsync(t->risk, risk, plane, hipMemcpyHostToDevice, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  // a PMF with all mass in one bin per cell samples to the same grid every time
+  bool one_hot = true;
+  for (size_t c = 0; c < plane && one_hot; ++c) {
+    int hundred = 0, other = 0;
+    for (int b = 0; b < bins; ++b) {
+      int8_t v = pmf[(size_t)b * plane + c];
+      if (v == 100) ++hundred;
+      else if (v != 0) ++other;
+    }
+    one_hot = (hundred == 1 && other == 0);
+  }
+  t->one_hot = one_hot;
+  t->bins = bins;
+  t->rows = rows;
+  t->cols = cols;
+  t->has_risk = risk != nullptr;
+  t->lo = traction_lo;
+  t->ratio = traction_ratio;
+  t->maps_set = true;
+  ++t->maps_version;
+  return MPPI_OK;
+}
+
+// enqueue the sampling kernel on `stream` (no synchronisation)
+static int tdm_sample_on(mppi_tdm* t, double alpha_dyn, hipStream_t stream) {
+  REQUIRE(t->maps_set, MPPI_ERR_STATE, "TDM maps not set");
+  if (t->one_hot && t->sampled_maps_version == t->maps_version && alpha_dyn > 0.0) return MPPI_OK;
+  const int G = t->cfg.num_grids;
+  if (t->cfg.rng == MPPI_RNG_PHILOX) {
+    long total = (long)G * t->rows * ((t->cols + 3) / 4);
+    hipLaunchKernelGGL(k_sample_grids_philox, dim3(ceil_div(total, 256)), dim3(256), 0, stream, t->pmf, t->bins,
+                       t->rows, t->cols, t->table, alpha_dyn, t->cfg.seed, t->epoch, G, t->grid,
+                       t->cfg.max_rows, t->cfg.max_cols);
+    ++t->epoch;
+  } else {
+    int threads = G * t->cfg.thread_dim_x * t->cfg.thread_dim_y;
+    hipLaunchKernelGGL(k_sample_grids_xoroshiro, dim3(ceil_div(threads, 64)), dim3(64), 0, stream, t->pmf,
+                       t->bins, t->rows, t->cols, t->table, alpha_dyn, t->states, G, t->cfg.thread_dim_x,
+                       t->cfg.thread_dim_y, t->grid, t->cfg.max_rows, t->cfg.max_cols);
+  }
+  HIP_TRY(hipGetLastError());
+  t->sampled_maps_version = t->maps_version;
+  t->sampled_alpha = alpha_dyn;
+  ++t->grid_version;
+  return MPPI_OK;
+}
+
+extern "C" int mppi_tdm_sample_grids(mppi_tdm* t, double alpha_dyn) {
+  REQUIRE(t, MPPI_ERR_INVALID, "NULL tdm");
+  HIP_TRY(hipSetDevice(t->cfg.device));
+  TRY(tdm_sample_on(t, alpha_dyn, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  return MPPI_OK;
+}
+
+extern "C" int mppi_tdm_set_sampled_grids(mppi_tdm* t, const int8_t* grids, int rows, int cols) {
+  REQUIRE(t && grids, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(rows >= 1 && cols >= 1 && rows <= t->cfg.max_rows && cols <= t->cfg.max_cols, MPPI_ERR_INVALID,
+          "window %dx%d does not fit max_map_dim", rows, cols);
+  HIP_TRY(hipSetDevice(t->cfg.device));
+  for (int g = 0; g < t->cfg.num_grids; ++g)
+    HIP_TRY(hipMemcpy2DAsync(t->grid + (size_t)g * t->cfg.max_rows * t->cfg.max_cols, (size_t)t->cfg.max_cols,
+                             grids + (size_t)g * rows * cols, (size_t)cols, (size_t)cols, (size_t)rows,
+                             hipMemcpyHostToDevice, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  ++t->grid_version;
+  t->sampled_maps_version = ~0ULL;  // injected grids are not a cached sample
+  return MPPI_OK;
+}
+
+extern "C" int mppi_tdm_get_sampled_grids(mppi_tdm* t, int8_t* out) {
+  REQUIRE(t && out, MPPI_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(t->cfg.device));
+  size_t bytes = (size_t)t->cfg.num_grids * t->cfg.max_rows * t->cfg.max_cols;
+  HIP_TRY(hipMemcpyAsync(out, t->grid, bytes, hipMemcpyDeviceToHost, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  return MPPI_OK;
+}
+
+extern "C" int mppi_tdm_rng_states(mppi_tdm* t, uint64_t* out, long capacity, long* count) {
+  REQUIRE(t && count, MPPI_ERR_INVALID, "NULL argument");
+  *count = t->n_states;
+  if (!out || t->n_states == 0) return MPPI_OK;
+  REQUIRE(capacity >= t->n_states, MPPI_ERR_INVALID, "capacity %ld < %ld states", capacity, t->n_states);
+  HIP_TRY(hipSetDevice(t->cfg.device));
+  HIP_TRY(hipMemcpy(out, t->states, 2 * sizeof(uint64_t) * (size_t)t->n_states, hipMemcpyDeviceToHost));
+  return MPPI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// RCCL, loaded on first use so that single-GPU users never touch it
+// ---------------------------------------------------------------------------
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int rccl_load() {
+  if (g_rccl.handle) return MPPI_OK;
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void* h = nullptr;
+  for (const char* n : names)
+    if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  REQUIRE(h, MPPI_ERR_COMM, "cannot load librccl.so: %s", dlerror());
+  g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+  g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+  g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+  g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+  REQUIRE(g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllGather &&
+              g_rccl.GetErrorString,
+          MPPI_ERR_COMM, "librccl.so lacks expected symbols");
+  g_rccl.handle = h;
+  return MPPI_OK;
+}
+
+#define RCCL_TRY(expr)                                                                  \
+  do {                                                                                  \
+    ncclResult_t _r = (expr);                                                           \
+    if (_r != ncclSuccess)                                                              \
+      return fail(MPPI_ERR_COMM, "%s failed: %s", #expr, g_rccl.GetErrorString(_r));   \
+  } while (0)
+
+extern "C" int mppi_comm_unique_id(char id[MPPI_COMM_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) <= MPPI_COMM_ID_BYTES, "ncclUniqueId larger than expected");
+  REQUIRE(id, MPPI_ERR_INVALID, "NULL id");
+  TRY(rccl_load());
+  ncclUniqueId uid;
+  RCCL_TRY(g_rccl.GetUniqueId(&uid));
+  memset(id, 0, MPPI_COMM_ID_BYTES);
+  memcpy(id, &uid, sizeof(uid));
+  return MPPI_OK;
+}
+
+// ---------------------------------------------------------------------------
+// planner
+// ---------------------------------------------------------------------------
+struct mppi_planner {
+  mppi_planner_cfg cfg;
+  hipStream_t stream = nullptr;
+  int n_local = 0, n_offset = 0;
+  // device buffers
+  float2* noise = nullptr;    // [T][n_local]
+  float2* staging = nullptr;  // (n_local,T) host-layout staging for set/get_noise
+  float2* u = nullptr;        // [T]
+  float2* u_prev = nullptr;   // [T]
+  float* costs = nullptr;     // [n_local]
+  float* weights = nullptr;   // [n_local], unnormalised exp(-(c-beta_g)/lambda)
+  float* weights_out = nullptr;
+  float* block_min = nullptr;  // [n_local]
+  int n_block_min = 0;
+  double* den_part = nullptr;  // [ceil(n_local/256)]
+  double2* partial = nullptr;  // [n_chunks][T]
+  int n_chunks = 1, chunk = 0;
+  double* packets = nullptr;  // [world][2+2T]; own packet at [rank]
+  double* weight_scale = nullptr;
+  uint32_t* cells = nullptr;
+  size_t cells_capacity = 0;
+  int8_t* risk_ref = nullptr;
+  float* sample_costs = nullptr;  // [n_local][M], allocated on first request
+  bool want_sample_costs = false;
+  uint64_t* states = nullptr;  // xoroshiro-compatible generator only
+  long n_states = 0;
+  float2* obs_pos = nullptr;
+  float* obs_r = nullptr;
+  int n_obstacles = 0;
+  float* state_rollout = nullptr;  // [V][T+1][3]
+  // host state
+  mppi_params params;
+  bool params_set = false;
+  uint64_t noise_epoch = 0;
+  const mppi_tdm* packed_lin = nullptr;
+  const mppi_tdm* packed_ang = nullptr;
+  uint64_t packed_lin_grid = ~0ULL, packed_ang_grid = ~0ULL, packed_lin_maps = ~0ULL;
+  // timing
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipEvent_t ev_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool profile_stages = false;
+  float stage_ms[4] = {0, 0, 0, 0};
+  float last_elapsed_ms = 0.f;
+  bool elapsed_pending = false;
+  int last_iterations = 0;
+  // comm
+  ncclComm_t comm = nullptr;
+};
+
+extern "C" int mppi_planner_destroy(mppi_planner* p) {
+  if (!p) return MPPI_OK;
+  (void)hipSetDevice(p->cfg.device);
+  if (p->stream) (void)hipStreamSynchronize(p->stream);
+  if (p->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(p->comm);
+  dev_free(p->noise);
+  dev_free(p->staging);
+  dev_free(p->u);
+  dev_free(p->u_prev);
+  dev_free(p->costs);
+  dev_free(p->weights);
+  dev_free(p->weights_out);
+  dev_free(p->block_min);
+  dev_free(p->den_part);
+  dev_free(p->partial);
+  dev_free(p->packets);
+  dev_free(p->weight_scale);
+  dev_free(p->cells);
+  dev_free(p->sample_costs);
+  dev_free(p->states);
+  dev_free(p->obs_pos);
+  dev_free(p->obs_r);
+  dev_free(p->state_rollout);
+  if (p->ev_begin) (void)hipEventDestroy(p->ev_begin);
+  if (p->ev_end) (void)hipEventDestroy(p->ev_end);
+  for (auto& e : p->ev_stage)
+    if (e) (void)hipEventDestroy(e);
+  if (p->stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+  return MPPI_OK;
+}
+
+static int planner_alloc(mppi_planner* p) {
+  const mppi_planner_cfg& c = p->cfg;
+  const size_t N = (size_t)p->n_local, T = (size_t)c.num_steps;
+  HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&p->ev_begin));
+  HIP_TRY(hipEventCreate(&p->ev_end));
+  for (auto& e : p->ev_stage) HIP_TRY(hipEventCreate(&e));
+  TRY(dev_alloc(&p->noise, N * T));
+  TRY(dev_alloc(&p->staging, N * T));
+  TRY(dev_alloc(&p->u, T));
+  TRY(dev_alloc(&p->u_prev, T));
+  TRY(dev_alloc(&p->costs, N));
+  TRY(dev_alloc(&p->weights, N));
+  TRY(dev_alloc(&p->weights_out, N));
+  TRY(dev_alloc(&p->block_min, N));
+  TRY(dev_alloc(&p->den_part, (size_t)ceil_div((long)N, kUpdateThreads)));
+  // weighted-sum grid: (T, n_chunks) workgroups, a few thousand in total
+  int want = ceil_div(2048, (long)T);
+  int max_chunks = ceil_div((long)N, 1024);
+  int nch = want < 1 ? 1 : (want > max_chunks ? max_chunks : want);
+  p->chunk = ceil_div(ceil_div((long)N, nch), kUpdateThreads) * kUpdateThreads;
+  p->n_chunks = ceil_div((long)N, p->chunk);
+  TRY(dev_alloc(&p->partial, (size_t)p->n_chunks * T));
+  TRY(dev_alloc(&p->packets, (size_t)c.world_size * packet_len((int)T)));
+  TRY(dev_alloc(&p->weight_scale, (size_t)1));
+  TRY(dev_alloc(&p->state_rollout, (size_t)c.num_vis_state_rollouts * (T + 1) * 3));
+  HIP_TRY(hipMemsetAsync(p->u, 0, T * sizeof(float2), p->stream));  // u_seq0 = zeros (mppi.py:93)
+  HIP_TRY(hipMemsetAsync(p->u_prev, 0, T * sizeof(float2), p->stream));
+  HIP_TRY(hipMemsetAsync(p->noise, 0, N * T * sizeof(float2), p->stream));
+  HIP_TRY(hipMemsetAsync(p->costs, 0, N * sizeof(float), p->stream));
+  HIP_TRY(hipMemsetAsync(p->weights, 0, N * sizeof(float), p->stream));
+  double one = 1.0;
+  HIP_TRY(hipMemcpyAsync(p->weight_scale, &one, sizeof(double), hipMemcpyHostToDevice, p->stream));
+  if (c.rng == MPPI_RNG_XOROSHIRO) {
+    // numba creates N*T states on the host, 2^64-jump apart (mppi.py:118); a
+    // shard keeps the slice of the global stream array that it owns
+    long total = (long)c.num_control_rollouts * c.num_steps;
+    std::vector<uint64_t> host(2 * (size_t)total);
+    xoroshiro_init_host(host.data(), total, c.seed);
+    p->n_states = (long)N * (long)T;
+    TRY(dev_alloc(&p->states, 2 * (size_t)p->n_states));
+    HIP_TRY(hipMemcpy(p->states, host.data() + 2 * (size_t)p->n_offset * T,
+                      2 * sizeof(uint64_t) * (size_t)p->n_states, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_create(const mppi_planner_cfg* cfg, mppi_planner** out) {
+  REQUIRE(cfg && out, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(cfg->mode >= MPPI_MODE_DET && cfg->mode <= MPPI_MODE_BAREBONE, MPPI_ERR_INVALID, "bad mode %d",
+          cfg->mode);
+  REQUIRE(cfg->num_control_rollouts >= 1 && cfg->num_steps >= 1, MPPI_ERR_INVALID, "bad N=%d or T=%d",
+          cfg->num_control_rollouts, cfg->num_steps);
+  REQUIRE(cfg->num_grid_samples >= 1 && cfg->num_vis_state_rollouts >= 1, MPPI_ERR_INVALID, "bad M or V");
+  REQUIRE(cfg->mode == MPPI_MODE_TDM || cfg->num_grid_samples == 1, MPPI_ERR_INVALID,
+          "num_grid_samples must be 1 unless MPPI_MODE_TDM");
+  REQUIRE(cfg->world_size >= 1 && cfg->rank >= 0 && cfg->rank < cfg->world_size, MPPI_ERR_INVALID,
+          "bad rank %d / world %d", cfg->rank, cfg->world_size);
+  REQUIRE(cfg->num_control_rollouts % cfg->world_size == 0, MPPI_ERR_INVALID,
+          "num_control_rollouts (%d) must be a multiple of world_size (%d)", cfg->num_control_rollouts,
+          cfg->world_size);
+  REQUIRE(cfg->rng == MPPI_RNG_PHILOX || cfg->rng == MPPI_RNG_XOROSHIRO, MPPI_ERR_INVALID, "bad rng kind");
+  REQUIRE(cfg->math == MPPI_MATH_EXACT || cfg->math == MPPI_MATH_FAST, MPPI_ERR_INVALID, "bad math kind");
+  mppi_device_props pr;
+  TRY(mppi_device_props_get(cfg->device, &pr));
+  REQUIRE(strncmp(pr.gcn_arch, "gfx950", 6) == 0, MPPI_ERR_NO_DEVICE,
+          "device %d is %s; this library is built for gfx950 (MI355X) only", cfg->device, pr.gcn_arch);
+  HIP_TRY(hipSetDevice(cfg->device));
+  const int n_local = cfg->num_control_rollouts / cfg->world_size;
+  REQUIRE(cfg->num_vis_state_rollouts <= n_local || cfg->mode == MPPI_MODE_TDM, MPPI_ERR_INVALID,
+          "num_vis_state_rollouts exceeds local rollouts");
+  REQUIRE(cfg->mode != MPPI_MODE_TDM || cfg->num_vis_state_rollouts <= cfg->num_grid_samples, MPPI_ERR_INVALID,
+          "num_vis_state_rollouts exceeds num_grid_samples");
+  mppi_planner* p = new mppi_planner();
+  p->cfg = *cfg;
+  p->n_local = n_local;
+  p->n_offset = cfg->rank * p->n_local;
+  memset(&p->params, 0, sizeof(p->params));
+  int rc = planner_alloc(p);
+  if (rc != MPPI_OK) {
+    std::string keep = g_last_error;
+    mppi_planner_destroy(p);
+    g_last_error = keep;
+    return rc;
+  }
+  *out = p;
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_set_params(mppi_planner* p, const mppi_params* params) {
+  REQUIRE(p && params, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(params->lambda_weight > 0.0f, MPPI_ERR_INVALID, "lambda_weight must be > 0");
+  REQUIRE(params->num_opt >= 0, MPPI_ERR_INVALID, "num_opt must be >= 0");
+  REQUIRE(p->cfg.mode == MPPI_MODE_BAREBONE || params->res > 0.0f, MPPI_ERR_INVALID, "res must be > 0");
+  REQUIRE(params->u_std[0] > 0.0f && params->u_std[1] > 0.0f, MPPI_ERR_INVALID, "u_std must be > 0");
+  p->params = *params;
+  p->params_set = true;
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_set_disc_obstacles(mppi_planner* p, const float* positions, const float* radii,
+                                               int count) {
+  REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
+  REQUIRE(count >= 0 && (count == 0 || (positions && radii)), MPPI_ERR_INVALID, "bad obstacle arrays");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  dev_free(p->obs_pos);
+  dev_free(p->obs_r);
+  p->n_obstacles = count;
+  if (count > 0) {
+    TRY(dev_alloc(&p->obs_pos, (size_t)count));
+    TRY(dev_alloc(&p->obs_r, (size_t)count));
+    HIP_TRY(hipMemcpy(p->obs_pos, positions, sizeof(float2) * (size_t)count, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(p->obs_r, radii, sizeof(float) * (size_t)count, hipMemcpyHostToDevice));
+  }
+  return MPPI_OK;
+}
+
+static int copy_in(mppi_planner* p, void* dst, const void* src, size_t bytes) {
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return MPPI_OK;
+}
+static int copy_out(mppi_planner* p, void* dst, const void* src, size_t bytes) {
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_set_u(mppi_planner* p, const float* u) {
+  REQUIRE(p && u, MPPI_ERR_INVALID, "NULL argument");
+  return copy_in(p, p->u, u, sizeof(float2) * (size_t)p->cfg.num_steps);
+}
+extern "C" int mppi_planner_get_u(mppi_planner* p, float* u) {
+  REQUIRE(p && u, MPPI_ERR_INVALID, "NULL argument");
+  return copy_out(p, u, p->u, sizeof(float2) * (size_t)p->cfg.num_steps);
+}
+extern "C" int mppi_planner_get_u_prev(mppi_planner* p, float* u) {
+  REQUIRE(p && u, MPPI_ERR_INVALID, "NULL argument");
+  return copy_out(p, u, p->u_prev, sizeof(float2) * (size_t)p->cfg.num_steps);
+}
+
+extern "C" int mppi_planner_shift_u(mppi_planner* p, int k) {
+  REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
+  if (k <= 0 || k >= p->cfg.num_steps) return MPPI_OK;  // u[:-k] = u[k:] is empty then
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  hipLaunchKernelGGL(k_shift_u, dim3(1), dim3(256), sizeof(float2) * (size_t)p->cfg.num_steps, p->stream, p->u,
+                     p->cfg.num_steps, k);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return MPPI_OK;
+}
+
+// ---- helpers -------------------------------------------------------------------
+static int check_tdms(const mppi_planner* p, const mppi_tdm* lin, const mppi_tdm* ang) {
+  if (p->cfg.mode == MPPI_MODE_BAREBONE) return MPPI_OK;
+  REQUIRE(lin && ang, MPPI_ERR_INVALID, "lin/ang TDM required in this mode");
+  REQUIRE(lin->maps_set && ang->maps_set, MPPI_ERR_STATE, "TDM maps not set");
+  REQUIRE(lin->cfg.device == p->cfg.device && ang->cfg.device == p->cfg.device, MPPI_ERR_INVALID,
+          "planner and TDMs live on different devices");
+  REQUIRE(lin->rows == ang->rows && lin->cols == ang->cols, MPPI_ERR_INVALID,
+          "lin and ang TDMs differ in padded size (%dx%d vs %dx%d)", lin->rows, lin->cols, ang->rows,
+          ang->cols);
+  REQUIRE(lin->cfg.num_grids == p->cfg.num_grid_samples && ang->cfg.num_grids == p->cfg.num_grid_samples,
+          MPPI_ERR_INVALID, "TDM num_grids (%d, %d) != planner num_grid_samples (%d)", lin->cfg.num_grids,
+          ang->cfg.num_grids, p->cfg.num_grid_samples);
+  REQUIRE(lin->cfg.max_rows == ang->cfg.max_rows && lin->cfg.max_cols == ang->cfg.max_cols, MPPI_ERR_INVALID,
+          "lin and ang TDMs differ in max_map_dim");
+  REQUIRE(p->cfg.mode != MPPI_MODE_SPEED_MAP || lin->has_risk, MPPI_ERR_STATE,
+          "speed-map mode needs lin TDM's risk traction map");
+  return MPPI_OK;
+}
+
+static DevParams make_dev_params(const mppi_planner* p, const mppi_tdm* lin, const mppi_tdm* ang) {
+  const mppi_params& a = p->params;
+  DevParams d;
+  memset(&d, 0, sizeof(d));
+  d.x0 = a.x0[0]; d.y0 = a.x0[1]; d.th0 = a.x0[2];
+  d.xg = a.xgoal[0]; d.yg = a.xgoal[1];
+  d.v_lo = a.vrange[0]; d.v_hi = a.vrange[1];
+  d.w_lo = a.wrange[0]; d.w_hi = a.wrange[1];
+  d.dt = a.dt;
+  d.gt2 = a.goal_tolerance * a.goal_tolerance;  // float32 product (mppi.py:960)
+  d.lambda = a.lambda_weight;
+  d.obs_cost = a.obs_cost;
+  d.unk_cost = a.unknown_cost;
+  d.res = a.res > 0.f ? a.res : 1.f;
+  d.inv_res = 1.0f / d.res;
+  d.xlo = a.xlo; d.ylo = a.ylo;
+  d.cvar_alpha = a.cvar_alpha;
+  d.numel = (int)std::ceil((double)p->cfg.num_grid_samples * (double)a.cvar_alpha);
+  if (d.numel < 1) d.numel = 1;
+  if (d.numel > p->cfg.num_grid_samples) d.numel = p->cfg.num_grid_samples;
+  d.dist_weight = a.dist_weight;
+  d.v_post_den = (double)a.v_post_rollout + 1e-6;
+  if (lin) { d.lin_lo = lin->lo; d.lin_ratio = lin->ratio; d.rows = lin->rows; d.cols = lin->cols; }
+  if (ang) { d.ang_lo = ang->lo; d.ang_ratio = ang->ratio; }
+  d.s0sq = (double)a.u_std[0] * (double)a.u_std[0];
+  d.s1sq = (double)a.u_std[1] * (double)a.u_std[1];
+  d.n_local = p->n_local;
+  d.n_steps = p->cfg.num_steps;
+  d.n_grids = p->cfg.num_grid_samples;
+  d.n_obstacles = p->n_obstacles;
+  return d;
+}
+
+// (re)build the packed cell words when the sampled grids or the masks changed
+static int ensure_packed(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang) {
+  if (p->cfg.mode == MPPI_MODE_BAREBONE) return MPPI_OK;
+  if (p->packed_lin == lin && p->packed_ang == ang && p->packed_lin_grid == lin->grid_version &&
+      p->packed_ang_grid == ang->grid_version && p->packed_lin_maps == lin->maps_version)
+    return MPPI_OK;
+  const int M = p->cfg.num_grid_samples;
+  size_t need = (size_t)lin->rows * lin->cols * M;
+  if (need > p->cells_capacity) {
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    dev_free(p->cells);
+    TRY(dev_alloc(&p->cells, need));
+    p->cells_capacity = need;
+  }
+  if (M == 1) {
+    hipLaunchKernelGGL(k_pack_cells_single, dim3(ceil_div((long)lin->rows * lin->cols, 256)), dim3(256), 0,
+                       p->stream, lin->grid, ang->grid, lin->cfg.max_cols, lin->obs, lin->unk, lin->rows,
+                       lin->cols, p->cells);
+  } else {
+    dim3 grid((unsigned)(lin->rows * ceil_div(lin->cols, 64)), (unsigned)ceil_div(M, 64));
+    hipLaunchKernelGGL(k_pack_cells_multi, grid, dim3(256), 0, p->stream, lin->grid, ang->grid,
+                       lin->cfg.max_rows, lin->cfg.max_cols, lin->obs, lin->unk, lin->rows, lin->cols, M,
+                       p->cells);
+  }
+  HIP_TRY(hipGetLastError());
+  p->risk_ref = lin->risk;
+  p->packed_lin = lin;
+  p->packed_ang = ang;
+  p->packed_lin_grid = lin->grid_version;
+  p->packed_ang_grid = ang->grid_version;
+  p->packed_lin_maps = lin->maps_version;
+  return MPPI_OK;
+}
+
+static int launch_noise(mppi_planner* p) {
+  const int N = p->n_local, T = p->cfg.num_steps;
+  long total = (long)N * T;
+  if (p->cfg.rng == MPPI_RNG_PHILOX) {
+    hipLaunchKernelGGL(k_noise_philox, dim3(ceil_div(total, 256)), dim3(256), 0, p->stream, p->noise, N,
+                       p->n_offset, T, p->cfg.seed, p->noise_epoch, p->params.u_std[0], p->params.u_std[1]);
+    ++p->noise_epoch;
+  } else {
+    hipLaunchKernelGGL(k_noise_xoroshiro, dim3(ceil_div(total, 256)), dim3(256), 0, p->stream, p->noise,
+                       p->states, N, T, p->params.u_std[0], p->params.u_std[1]);
+  }
+  HIP_TRY(hipGetLastError());
+  return MPPI_OK;
+}
+
+template <bool EXACT>
+static int launch_rollout_t(mppi_planner* p, const DevParams& d) {
+  const int N = p->n_local, T = p->cfg.num_steps, M = p->cfg.num_grid_samples;
+  size_t lds = sizeof(double2) * (size_t)T;
+  switch (p->cfg.mode) {
+    case MPPI_MODE_DET:
+      p->n_block_min = ceil_div(N, 64);
+      hipLaunchKernelGGL((k_rollout_map<MAP_DET, EXACT>), dim3(p->n_block_min), dim3(64), lds, p->stream, d,
+                         p->cells, (const int8_t*)nullptr, p->noise, p->u, p->costs, p->block_min);
+      break;
+    case MPPI_MODE_SPEED_MAP:
+      p->n_block_min = ceil_div(N, 64);
+      hipLaunchKernelGGL((k_rollout_map<MAP_SPEED, EXACT>), dim3(p->n_block_min), dim3(64), lds, p->stream, d,
+                         p->cells, (const int8_t*)p->risk_ref, p->noise, p->u, p->costs, p->block_min);
+      break;
+    case MPPI_MODE_TDM: {
+      int mp2 = next_pow2(M);
+      int threads = ceil_div(M, 64) * 64;
+      if (threads > 1024) threads = 1024;
+      lds += sizeof(float) * (size_t)mp2;
+      REQUIRE(lds <= 160 * 1024, MPPI_ERR_INVALID, "T=%d, M=%d need %zu bytes of LDS (> 160 KiB)", T, M, lds);
+      if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_tdm<EXACT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (p->want_sample_costs && !p->sample_costs) TRY(dev_alloc(&p->sample_costs, (size_t)N * M));
+      p->n_block_min = N;
+      hipLaunchKernelGGL((k_rollout_tdm<EXACT>), dim3(N), dim3(threads), lds, p->stream, d, p->cells, p->noise,
+                         p->u, p->costs, p->block_min, p->want_sample_costs ? p->sample_costs : nullptr, mp2);
+      break;
+    }
+    case MPPI_MODE_BAREBONE:
+      p->n_block_min = ceil_div(N, 64);
+      hipLaunchKernelGGL((k_rollout_barebone<EXACT>), dim3(p->n_block_min), dim3(64), lds, p->stream, d,
+                         p->obs_pos, p->obs_r, p->noise, p->u, p->costs, p->block_min);
+      break;
+    default:
+      return fail(MPPI_ERR_INVALID, "bad mode");
+  }
+  HIP_TRY(hipGetLastError());
+  return MPPI_OK;
+}
+
+static int launch_rollout(mppi_planner* p, const DevParams& d) {
+  REQUIRE((size_t)p->cfg.num_steps * sizeof(double2) <= 64 * 1024, MPPI_ERR_INVALID, "num_steps %d too large",
+          p->cfg.num_steps);
+  return p->cfg.math == MPPI_MATH_EXACT ? launch_rollout_t<true>(p, d) : launch_rollout_t<false>(p, d);
+}
+
+// weights + weighted sums + (single GPU) apply; with several GPUs the packet is
+// left in packets[rank] for the exchange
+static int launch_update_local(mppi_planner* p, bool apply_here) {
+  const int N = p->n_local, T = p->cfg.num_steps;
+  const mppi_params& a = p->params;
+  double* my_packet = p->packets + (size_t)p->cfg.rank * packet_len(T);
+  int n_den = ceil_div(N, kUpdateThreads);
+  hipLaunchKernelGGL(k_weights, dim3(n_den), dim3(kUpdateThreads), 0, p->stream, p->costs, N, p->block_min,
+                     p->n_block_min, a.lambda_weight, p->weights, p->den_part, my_packet);
+  hipLaunchKernelGGL(k_wsum, dim3(T, p->n_chunks), dim3(kUpdateThreads), 0, p->stream, p->weights, p->noise, N,
+                     p->chunk, p->partial);
+  if (apply_here)
+    hipLaunchKernelGGL(k_finish<true>, dim3(1), dim3(kUpdateThreads), 0, p->stream, p->partial, p->n_chunks,
+                       p->den_part, n_den, T, my_packet, p->u, p->u_prev, a.vrange[0], a.vrange[1], a.wrange[0],
+                       a.wrange[1], p->weight_scale);
+  else
+    hipLaunchKernelGGL(k_finish<false>, dim3(1), dim3(kUpdateThreads), 0, p->stream, p->partial, p->n_chunks,
+                       p->den_part, n_den, T, my_packet, p->u, p->u_prev, a.vrange[0], a.vrange[1], a.wrange[0],
+                       a.wrange[1], p->weight_scale);
+  HIP_TRY(hipGetLastError());
+  return MPPI_OK;
+}
+
+static int launch_apply(mppi_planner* p) {
+  const mppi_params& a = p->params;
+  hipLaunchKernelGGL(k_apply, dim3(1), dim3(kUpdateThreads), 0, p->stream, p->packets, p->cfg.world_size,
+                     p->cfg.rank, p->cfg.num_steps, a.lambda_weight, p->u, p->u_prev, a.vrange[0], a.vrange[1],
+                     a.wrange[0], a.wrange[1], p->weight_scale);
+  HIP_TRY(hipGetLastError());
+  return MPPI_OK;
+}
+
+static int launch_update(mppi_planner* p, bool prof) {
+  if (p->cfg.world_size == 1) {
+    TRY(launch_update_local(p, true));
+    if (prof) {
+      HIP_TRY(hipEventRecord(p->ev_stage[3], p->stream));
+      HIP_TRY(hipEventRecord(p->ev_stage[4], p->stream));
+    }
+    return MPPI_OK;
+  }
+  REQUIRE(p->comm, MPPI_ERR_STATE,
+          "world_size %d but no communicator: call mppi_planner_comm_init (or use update_local/update_apply)",
+          p->cfg.world_size);
+  TRY(launch_update_local(p, false));
+  const int len = packet_len(p->cfg.num_steps);
+  if (prof) HIP_TRY(hipEventRecord(p->ev_stage[3], p->stream));
+  // one all-gather of (2T+2) doubles per iteration, in place
+  RCCL_TRY(g_rccl.AllGather(p->packets + (size_t)p->cfg.rank * len, p->packets, (size_t)len, ncclDouble, p->comm,
+                            p->stream));
+  if (prof) HIP_TRY(hipEventRecord(p->ev_stage[4], p->stream));
+  return launch_apply(p);
+}
+
+static int rebuild_block_min(mppi_planner* p) {
+  p->n_block_min = ceil_div(p->n_local, kUpdateThreads);
+  hipLaunchKernelGGL(k_block_min_from_costs, dim3(p->n_block_min), dim3(kUpdateThreads), 0, p->stream, p->costs,
+                     p->n_local, p->block_min);
+  HIP_TRY(hipGetLastError());
+  return MPPI_OK;
+}
+
+static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int iterations) {
+  REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
+  TRY(check_tdms(p, lin, ang));
+  TRY(ensure_packed(p, lin, ang));
+  DevParams d = make_dev_params(p, lin, ang);
+  HIP_TRY(hipEventRecord(p->ev_begin, p->stream));
+  for (int k = 0; k < iterations; ++k) {
+    bool prof = p->profile_stages && k == iterations - 1;
+    if (prof) HIP_TRY(hipEventRecord(p->ev_stage[0], p->stream));
+    TRY(launch_noise(p));
+    if (prof) HIP_TRY(hipEventRecord(p->ev_stage[1], p->stream));
+    TRY(launch_rollout(p, d));
+    if (prof) HIP_TRY(hipEventRecord(p->ev_stage[2], p->stream));
+    TRY(launch_update(p, prof));
+  }
+  HIP_TRY(hipEventRecord(p->ev_end, p->stream));
+  p->elapsed_pending = true;
+  p->last_iterations = iterations;
+  return MPPI_OK;
+}
+
+static int finish_timing(mppi_planner* p) {
+  if (!p->elapsed_pending) return MPPI_OK;
+  HIP_TRY(hipEventSynchronize(p->ev_end));
+  HIP_TRY(hipEventElapsedTime(&p->last_elapsed_ms, p->ev_begin, p->ev_end));
+  if (p->profile_stages && p->last_iterations > 0) {
+    // ev_stage: 0 noise | 1 rollout | 2 update-local | 3 collective | 4 apply .. ev_end
+    float noise, roll, upd, coll, tail;
+    HIP_TRY(hipEventElapsedTime(&noise, p->ev_stage[0], p->ev_stage[1]));
+    HIP_TRY(hipEventElapsedTime(&roll, p->ev_stage[1], p->ev_stage[2]));
+    HIP_TRY(hipEventElapsedTime(&upd, p->ev_stage[2], p->ev_stage[3]));
+    HIP_TRY(hipEventElapsedTime(&coll, p->ev_stage[3], p->ev_stage[4]));
+    HIP_TRY(hipEventElapsedTime(&tail, p->ev_stage[4], p->ev_end));
+    p->stage_ms[0] = noise;
+    p->stage_ms[1] = roll;
+    p->stage_ms[2] = upd + tail;
+    p->stage_ms[3] = coll;
+  }
+  p->elapsed_pending = false;
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_iterate_async(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int iterations) {
+  REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
+  REQUIRE(iterations >= 0, MPPI_ERR_INVALID, "iterations < 0");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  return run_iterations(p, lin, ang, iterations);
+}
+
+extern "C" int mppi_planner_synchronize(mppi_planner* p) {
+  REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return finish_timing(p);
+}
+
+extern "C" int mppi_planner_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, float* u_out) {
+  REQUIRE(p && u_out, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  TRY(check_tdms(p, lin, ang));
+  if (p->cfg.mode != MPPI_MODE_BAREBONE) {
+    // grids are sampled once per solve(), not per optimisation iteration
+    // (mppi.py:247-248, 321-322, 391-394); the deterministic modes pass alpha_dyn = 1
+    double alpha = (p->cfg.mode == MPPI_MODE_TDM) ? p->params.alpha_dyn : 1.0;
+    TRY(tdm_sample_on(lin, alpha, p->stream));
+    TRY(tdm_sample_on(ang, alpha, p->stream));
+  }
+  TRY(run_iterations(p, lin, ang, p->params.num_opt));
+  HIP_TRY(hipMemcpyAsync(u_out, p->u, sizeof(float2) * (size_t)p->cfg.num_steps, hipMemcpyDeviceToHost,
+                         p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return finish_timing(p);
+}
+
+// ---- stage-level entry points -------------------------------------------------
+extern "C" int mppi_planner_sample_noise(mppi_planner* p) {
+  REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
+  REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  TRY(launch_noise(p));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_set_noise(mppi_planner* p, const float* noise) {
+  REQUIRE(p && noise, MPPI_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  size_t count = (size_t)p->n_local * p->cfg.num_steps;
+  HIP_TRY(hipMemcpyAsync(p->staging, noise, count * sizeof(float2), hipMemcpyHostToDevice, p->stream));
+  hipLaunchKernelGGL(k_noise_to_device_layout, dim3(ceil_div((long)count, 256)), dim3(256), 0, p->stream,
+                     p->staging, p->n_local, p->cfg.num_steps, p->noise);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_get_noise(mppi_planner* p, float* noise) {
+  REQUIRE(p && noise, MPPI_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  size_t count = (size_t)p->n_local * p->cfg.num_steps;
+  hipLaunchKernelGGL(k_noise_to_host_layout, dim3(ceil_div((long)count, 256)), dim3(256), 0, p->stream, p->noise,
+                     p->n_local, p->cfg.num_steps, p->staging);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(noise, p->staging, count * sizeof(float2), hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_rollout(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang) {
+  REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
+  REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  TRY(check_tdms(p, lin, ang));
+  TRY(ensure_packed(p, lin, ang));
+  DevParams d = make_dev_params(p, lin, ang);
+  TRY(launch_rollout(p, d));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_set_costs(mppi_planner* p, const float* costs) {
+  REQUIRE(p && costs, MPPI_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  HIP_TRY(hipMemcpyAsync(p->costs, costs, sizeof(float) * (size_t)p->n_local, hipMemcpyHostToDevice, p->stream));
+  TRY(rebuild_block_min(p));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_get_costs(mppi_planner* p, float* costs) {
+  REQUIRE(p && costs, MPPI_ERR_INVALID, "NULL argument");
+  return copy_out(p, costs, p->costs, sizeof(float) * (size_t)p->n_local);
+}
+
+extern "C" int mppi_planner_get_sample_costs(mppi_planner* p, float* costs) {
+  REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
+  REQUIRE(p->cfg.mode == MPPI_MODE_TDM, MPPI_ERR_STATE, "per-sample costs exist in MPPI_MODE_TDM only");
+  if (!costs) {  // arm: the next rollout records them
+    p->want_sample_costs = true;
+    return MPPI_OK;
+  }
+  REQUIRE(p->sample_costs, MPPI_ERR_STATE, "call once with NULL before the rollout to arm recording");
+  return copy_out(p, costs, p->sample_costs, sizeof(float) * (size_t)p->n_local * p->cfg.num_grid_samples);
+}
+
+extern "C" int mppi_planner_update(mppi_planner* p) {
+  REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
+  REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  if (p->n_block_min == 0) TRY(rebuild_block_min(p));
+  TRY(launch_update(p, false));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_packet_len(mppi_planner* p, int* doubles) {
+  REQUIRE(p && doubles, MPPI_ERR_INVALID, "NULL argument");
+  *doubles = packet_len(p->cfg.num_steps);
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_update_local(mppi_planner* p, double* packet) {
+  REQUIRE(p && packet, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  if (p->n_block_min == 0) TRY(rebuild_block_min(p));
+  TRY(launch_update_local(p, false));
+  const int len = packet_len(p->cfg.num_steps);
+  HIP_TRY(hipMemcpyAsync(packet, p->packets + (size_t)p->cfg.rank * len, sizeof(double) * (size_t)len,
+                         hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_update_apply(mppi_planner* p, const double* packets, int count) {
+  REQUIRE(p && packets, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(count == p->cfg.world_size, MPPI_ERR_INVALID, "expected %d packets, got %d", p->cfg.world_size, count);
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  const int len = packet_len(p->cfg.num_steps);
+  HIP_TRY(hipMemcpyAsync(p->packets, packets, sizeof(double) * (size_t)len * (size_t)count,
+                         hipMemcpyHostToDevice, p->stream));
+  TRY(launch_apply(p));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_get_weights(mppi_planner* p, float* weights) {
+  REQUIRE(p && weights, MPPI_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  hipLaunchKernelGGL(k_scale_weights, dim3(ceil_div(p->n_local, 256)), dim3(256), 0, p->stream, p->weights,
+                     p->weight_scale, p->n_local, p->weights_out);
+  HIP_TRY(hipGetLastError());
+  return copy_out(p, weights, p->weights_out, sizeof(float) * (size_t)p->n_local);
+}
+
+extern "C" int mppi_planner_get_state_rollout(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, float* out) {
+  REQUIRE(p && out, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  TRY(check_tdms(p, lin, ang));
+  TRY(ensure_packed(p, lin, ang));  // uses the already sampled grids (mppi.py:572-573)
+  DevParams d = make_dev_params(p, lin, ang);
+  const int V = p->cfg.num_vis_state_rollouts;
+  dim3 grid(ceil_div(V, 64)), block(64);
+  switch (p->cfg.mode) {
+    case MPPI_MODE_TDM:
+      REQUIRE(V <= p->cfg.num_grid_samples, MPPI_ERR_INVALID, "V > M");
+      hipLaunchKernelGGL((k_state_rollout<true, false>), grid, block, 0, p->stream, d, p->cells, p->noise,
+                         p->u_prev, p->u, V, p->state_rollout);
+      break;
+    case MPPI_MODE_BAREBONE:
+      hipLaunchKernelGGL((k_state_rollout<false, true>), grid, block, 0, p->stream, d, p->cells, p->noise,
+                         p->u_prev, p->u, V, p->state_rollout);
+      break;
+    default:
+      hipLaunchKernelGGL((k_state_rollout<false, false>), grid, block, 0, p->stream, d, p->cells, p->noise,
+                         p->u_prev, p->u, V, p->state_rollout);
+  }
+  HIP_TRY(hipGetLastError());
+  return copy_out(p, out, p->state_rollout, sizeof(float) * (size_t)V * (p->cfg.num_steps + 1) * 3);
+}
+
+extern "C" int mppi_planner_rng_states(mppi_planner* p, uint64_t* out, long capacity, long* count) {
+  REQUIRE(p && count, MPPI_ERR_INVALID, "NULL argument");
+  *count = p->n_states;
+  if (!out || p->n_states == 0) return MPPI_OK;
+  REQUIRE(capacity >= p->n_states, MPPI_ERR_INVALID, "capacity %ld < %ld states", capacity, p->n_states);
+  return copy_out(p, out, p->states, 2 * sizeof(uint64_t) * (size_t)p->n_states);
+}
+
+extern "C" int mppi_planner_set_profiling(mppi_planner* p, int enabled) {
+  REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
+  p->profile_stages = enabled != 0;
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_stage_times(mppi_planner* p, float ms[4]) {
+  REQUIRE(p && ms, MPPI_ERR_INVALID, "NULL argument");
+  TRY(finish_timing(p));
+  memcpy(ms, p->stage_ms, sizeof(p->stage_ms));
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_last_elapsed_ms(mppi_planner* p, float* ms) {
+  REQUIRE(p && ms, MPPI_ERR_INVALID, "NULL argument");
+  TRY(finish_timing(p));
+  *ms = p->last_elapsed_ms;
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_comm_init(mppi_planner* p, const char id[MPPI_COMM_ID_BYTES]) {
+  REQUIRE(p && id, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(!p->comm, MPPI_ERR_STATE, "communicator already initialised");
+  TRY(rccl_load());
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  RCCL_TRY(g_rccl.CommInitRank(&p->comm, p->cfg.world_size, uid, p->cfg.rank));
+  return MPPI_OK;
+}

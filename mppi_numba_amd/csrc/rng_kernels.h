@@ -1,0 +1,233 @@
+// rng_kernels.h -- control-noise and traction-map sampling (gfx950).
+//
+// Replaces sample_noise_numba (mppi.py:1354-1370) and sample_grids_numba
+// (terrain.py:633-695).
+//
+// Default generator: rocRAND Philox4x32-10 (device API).  It is counter based:
+// the counter is the GLOBAL (rollout, step) index -- respectively the global
+// (sample, row, column group) index -- and the call epoch, so a sharded run
+// draws exactly the numbers a single-GPU run draws, and no generator state is
+// stored in HBM (numba keeps 16 bytes of xoroshiro state per thread and
+// round-trips it on every call).
+//
+// Compatibility generator: numba.cuda.random's xoroshiro128+ with its stream
+// per thread and its thread -> cell mapping, bit for bit, so that seed -> u can
+// be checked against the reference end to end.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocrand/rocrand_kernel.h>
+#include <stdint.h>
+
+namespace mppi {
+
+// ---------------- xoroshiro128+ (numba/cuda/random.py:45-139) ----------------
+__host__ __device__ inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+__host__ __device__ inline uint64_t xoroshiro_next(uint64_t& s0, uint64_t& s1) {
+  uint64_t result = s0 + s1;
+  uint64_t t = s1 ^ s0;
+  s0 = rotl64(s0, 55) ^ t ^ (t << 14);
+  s1 = rotl64(t, 36);
+  return result;
+}
+
+__host__ __device__ inline float xoroshiro_uniform_f32(uint64_t& s0, uint64_t& s1) {
+  // float32(uint64 >> 11) * 2^-53 in float64)
+  return (float)((double)(xoroshiro_next(s0, s1) >> 11) * (1.0 / 9007199254740992.0));
+}
+
+// Box-Muller as the reference's CPU path evaluates it (random.py:175-196 on
+// Python floats): float32 uniforms, float64 log / sqrt / cos, second normal of
+// the pair discarded.
+__device__ inline double xoroshiro_normal(uint64_t& s0, uint64_t& s1) {
+  const float two_pi_f32 = 6.28318530717958647692f;
+  float u1 = xoroshiro_uniform_f32(s0, s1);
+  float u2 = xoroshiro_uniform_f32(s0, s1);
+  return sqrt(-2.0 * log((double)u1)) * cos((double)(two_pi_f32 * u2));
+}
+
+// host: SplitMix64 seeding of stream 0, stream k = stream k-1 jumped by 2^64
+// (random.py:46-68, 102-125, 225-240)
+inline void xoroshiro_init_host(uint64_t* states, long n, uint64_t seed) {
+  if (n < 1) return;
+  static const uint64_t kJump[2] = {0xbeac0467eba5facbULL, 0xd86b048b86aa9922ULL};
+  uint64_t z = seed + 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z = z ^ (z >> 31);
+  uint64_t s0 = z, s1 = z;
+  states[0] = s0;
+  states[1] = s1;
+  for (long i = 1; i < n; ++i) {
+    uint64_t a = 0, b = 0;
+    for (int w = 0; w < 2; ++w)
+      for (int bit = 0; bit < 64; ++bit) {
+        if (kJump[w] & (1ULL << bit)) {
+          a ^= s0;
+          b ^= s1;
+        }
+        xoroshiro_next(s0, s1);
+      }
+    s0 = a;
+    s1 = b;
+    states[2 * i] = s0;
+    states[2 * i + 1] = s1;
+  }
+}
+
+// ---------------- control noise ----------------
+// noise[t][n] = u_std * N(0,1); Philox subsequence = global (n, t), offset = epoch
+__global__ __launch_bounds__(256) void k_noise_philox(float2* __restrict__ noise, int n_local, int n_offset,
+                                                      int n_steps, uint64_t seed, uint64_t epoch, float std0,
+                                                      float std1) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)n_local * n_steps) return;
+  int t = (int)(i / n_local), n = (int)(i % n_local);
+  uint64_t key = (uint64_t)(n_offset + n) * (uint64_t)n_steps + (uint64_t)t;
+  rocrand_state_philox4x32_10 st;
+  rocrand_init(seed, key, 4ULL * epoch, &st);
+  float2 z = rocrand_normal2(&st);
+  noise[i] = make_float2(std0 * z.x, std1 * z.y);
+}
+
+// reference-compatible: stream n*T+t, two normals per call (4 draws), state kept
+__global__ __launch_bounds__(256) void k_noise_xoroshiro(float2* __restrict__ noise, uint64_t* __restrict__ states,
+                                                         int n_local, int n_steps, float std0, float std1) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)n_local * n_steps) return;
+  int t = (int)(i / n_local), n = (int)(i % n_local);
+  size_t k = (size_t)n * n_steps + t;
+  uint64_t s0 = states[2 * k], s1 = states[2 * k + 1];
+  double z0 = xoroshiro_normal(s0, s1);
+  double z1 = xoroshiro_normal(s0, s1);
+  states[2 * k] = s0;
+  states[2 * k + 1] = s1;
+  noise[i] = make_float2((float)((double)std0 * z0), (float)((double)std1 * z1));
+}
+
+// ---------------- traction-map sampling ----------------
+// inverse-CDF draw from the int8 PMF (bins sum to 100), terrain.py:682-689
+__device__ __forceinline__ int8_t draw_bin(const int8_t* __restrict__ pmf, size_t cell, size_t plane, int bins,
+                                           const int8_t* __restrict__ table, int8_t target) {
+  int8_t cum = 0;
+  for (int b = 0; b < bins; ++b) {
+    cum = (int8_t)(cum + pmf[(size_t)b * plane + cell]);
+    if (target <= cum) return table[b];
+  }
+  return table[bins - 1];  // malformed PMF (sum < target): the reference leaves the cell unwritten
+}
+
+// Philox: one thread per (sample g, row r, 4 consecutive columns): one counter
+// block = 4 uniforms; 4-byte-contiguous stores.  out is [G][out_rows][out_stride].
+__global__ __launch_bounds__(256) void k_sample_grids_philox(const int8_t* __restrict__ pmf, int bins, int rows,
+                                                             int cols, const int8_t* __restrict__ table,
+                                                             double alpha_dyn, uint64_t seed, uint64_t epoch,
+                                                             int n_grids, int8_t* __restrict__ out, int out_rows,
+                                                             int out_stride) {
+  const int groups = (cols + 3) / 4;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t total = (size_t)n_grids * rows * groups;
+  if (i >= total) return;
+  int cg = (int)(i % groups);
+  int r = (int)((i / groups) % rows);
+  int g = (int)(i / ((size_t)groups * rows));
+  rocrand_state_philox4x32_10 st;
+  rocrand_init(seed, (uint64_t)i, 4ULL * epoch, &st);
+  float4 uu = rocrand_uniform4(&st);  // (0, 1]
+  float uv[4] = {uu.x, uu.y, uu.z, uu.w};
+  const size_t plane = (size_t)rows * cols;
+  int8_t* o = out + ((size_t)g * out_rows + r) * out_stride;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int c = cg * 4 + k;
+    if (c < cols) {
+      int8_t target = (int8_t)(int)ceil((double)uv[k] * 100.0 * alpha_dyn);
+      o[c] = draw_bin(pmf, (size_t)r * cols + c, plane, bins, table, target);
+    }
+  }
+}
+
+// reference-compatible: launch geometry [(1,G),(tx,ty)] flattened; thread (i,j)
+// of block g owns stream i*ty*G + g*ty + j and walks its tile row-major
+// (terrain.py:645-668)
+__global__ void k_sample_grids_xoroshiro(const int8_t* __restrict__ pmf, int bins, int rows, int cols,
+                                         const int8_t* __restrict__ table, double alpha_dyn,
+                                         uint64_t* __restrict__ states, int n_grids, int tx, int ty,
+                                         int8_t* __restrict__ out, int out_rows, int out_stride) {
+  int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= n_grids * tx * ty) return;
+  int j = id % ty, i = (id / ty) % tx, g = id / (tx * ty);
+  size_t stream = (size_t)i * ty * n_grids + (size_t)g * ty + j;
+  uint64_t s0 = states[2 * stream], s1 = states[2 * stream + 1];
+  int nr = (rows + tx - 1) / tx, nc = (cols + ty - 1) / ty;
+  int r0 = min(i * nr, rows), r1 = min(r0 + nr, rows);
+  int c0 = min(j * nc, cols), c1 = min(c0 + nc, cols);
+  const size_t plane = (size_t)rows * cols;
+  for (int r = r0; r < r1; ++r)
+    for (int c = c0; c < c1; ++c) {
+      float rnd = xoroshiro_uniform_f32(s0, s1);
+      int8_t target = (int8_t)(long)ceil((double)rnd * 100.0 * alpha_dyn);
+      int8_t cum = 0;
+      for (int b = 0; b < bins; ++b) {
+        cum = (int8_t)(cum + pmf[(size_t)b * plane + (size_t)r * cols + c]);
+        if (target <= cum) {
+          out[((size_t)g * out_rows + r) * out_stride + c] = table[b];
+          break;
+        }
+      }
+    }
+  states[2 * stream] = s0;
+  states[2 * stream + 1] = s1;
+}
+
+// ---------------- map packing ----------------
+// cells[r*cols+c] = lin | ang<<8 | obs<<16 | unk<<24 from sample 0 of each TDM
+__global__ void k_pack_cells_single(const int8_t* __restrict__ lin, const int8_t* __restrict__ ang, int grid_stride,
+                                    const int8_t* __restrict__ obs, const int8_t* __restrict__ unk, int rows,
+                                    int cols, uint32_t* __restrict__ cells) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  int r = i / cols, c = i % cols;
+  uint32_t l = (uint8_t)lin[(size_t)r * grid_stride + c], a = (uint8_t)ang[(size_t)r * grid_stride + c];
+  uint32_t o = (uint8_t)obs[i], k = (uint8_t)unk[i];
+  cells[i] = l | (a << 8) | (o << 16) | (k << 24);
+}
+
+// cellsM[(r*cols+c)*M + m]: transpose (M,R,C) -> (R,C,M) through an LDS tile
+// of 64 samples x 64 cells so that both the byte reads (along c) and the word
+// writes (along m) are contiguous.
+__global__ __launch_bounds__(256) void k_pack_cells_multi(const int8_t* __restrict__ lin,
+                                                          const int8_t* __restrict__ ang, int grid_rows,
+                                                          int grid_stride, const int8_t* __restrict__ obs,
+                                                          const int8_t* __restrict__ unk, int rows, int cols,
+                                                          int n_grids, uint32_t* __restrict__ cells) {
+  __shared__ uint16_t tile[64][65];
+  const int col_tiles = (cols + 63) / 64;
+  const int c0 = (blockIdx.x % col_tiles) * 64;
+  const int r = blockIdx.x / col_tiles;
+  const int m0 = blockIdx.y * 64;
+  const size_t plane = (size_t)grid_rows * grid_stride;
+  // read: thread (q, lane) with lane = cell within the tile, q steps over samples
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  for (int mm = q; mm < 64; mm += 4) {
+    int m = m0 + mm, c = c0 + lane;
+    uint16_t v = 0;
+    if (m < n_grids && c < cols) {
+      size_t off = plane * m + (size_t)r * grid_stride + c;
+      v = (uint16_t)((uint8_t)lin[off] | ((uint16_t)(uint8_t)ang[off] << 8));
+    }
+    tile[mm][lane] = v;
+  }
+  __syncthreads();
+  // write: lane = sample within the tile, q steps over cells
+  for (int cc = q; cc < 64; cc += 4) {
+    int c = c0 + cc, m = m0 + lane;
+    if (m < n_grids && c < cols) {
+      size_t ci = (size_t)r * cols + c;
+      uint32_t o = (uint8_t)obs[ci], k = (uint8_t)unk[ci];
+      cells[ci * n_grids + m] = (uint32_t)tile[lane][cc] | (o << 16) | (k << 24);
+    }
+  }
+}
+
+}  // namespace mppi

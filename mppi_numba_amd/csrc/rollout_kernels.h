@@ -1,0 +1,384 @@
+// rollout_kernels.h -- the integrator kernels (gfx950, wave64).
+//
+// Replaces (reference paths relative to /root/reference/mppi_numba):
+//   rollout_det_dyn_numba              mppi.py:916-1009   -> k_rollout_map<DET>
+//   rollout_det_dyn_w_speed_map_numba  mppi.py:1013-1111  -> k_rollout_map<SPEED>
+//   rollout_numba / rollout_oversized  mppi.py:613-913    -> k_rollout_tdm
+//   barebone rollout_numba             barebone_mppi_numba.ipynb cell 3
+//   get_state_rollout_* kernels        mppi.py:1194-1351  -> k_state_rollout_*
+//
+// Device data layout (private to the library):
+//   noise  [T][N] float2      step-major: lane n of a wave reads 8 contiguous
+//                             bytes next to its neighbours at every step, and
+//                             the weighted sum over n of the update streams it
+//   cells  [Rp*Cp] uint32     one word per map cell: lin | ang<<8 | obs<<16 |
+//                             unk<<24 (int8 each) -> ONE gather per step
+//   cellsM [Rp*Cp][M] uint32  the same per traction sample, sample index
+//                             fastest: the M lanes that evaluate one control
+//                             sequence sit in the same or neighbouring cells, so
+//                             a wave's gather touches a handful of 256-byte
+//                             runs instead of 64 cache lines (M,R,C layout)
+//   u [T] float2, costs [N] float
+//
+// One rollout (or one (rollout, sample) pair) per lane; the cost stays in a
+// register and is written once (the reference does three global RMWs per step).
+#pragma once
+#include "device_math.h"
+
+namespace mppi {
+
+enum MapKind { MAP_DET = 0, MAP_SPEED = 1 };
+
+struct DevParams {
+  float x0, y0, th0;
+  float xg, yg;
+  float v_lo, v_hi, w_lo, w_hi;
+  float dt, gt2, lambda;
+  float obs_cost, unk_cost;
+  float res, inv_res, xlo, ylo;
+  float cvar_alpha;
+  int numel;          // ceil(M * float32(alpha)) evaluated in float64 (mppi.py:743)
+  double dist_weight;
+  double v_post_den;  // float64(v_post_rollout) + 1e-6            (mppi.py:28)
+  double lin_lo, lin_ratio, ang_lo, ang_ratio;
+  double s0sq, s1sq;  // u_std**2 in float64                       (mppi.py:709)
+  int n_local;        // rollouts on this GPU
+  int n_steps;        // T
+  int n_grids;        // M
+  int rows, cols;     // padded map dims Rp, Cp
+  int n_obstacles;    // barebone only
+};
+
+// u[t]/std^2 (float64) for the control-cost term, staged in LDS once per block
+__device__ __forceinline__ void stage_control_ratios(const DevParams& P, const float2* __restrict__ u,
+                                                     double2* uos) {
+  for (int t = threadIdx.x; t < P.n_steps; t += blockDim.x) {
+    float2 ut = u[t];
+    uos[t] = make_double2((double)ut.x / P.s0sq, (double)ut.y / P.s1sq);
+  }
+  __syncthreads();
+}
+
+// lambda*((u0/s0^2)*e0 + (u1/s1^2)*e1)                           (mppi.py:708-710)
+__device__ __forceinline__ double control_cost(const DevParams& P, double2 r, float2 e) {
+  return (double)P.lambda * fma(r.x, (double)e.x, r.y * (double)e.y);
+}
+
+struct StepOut {
+  float x, y, th;
+  double d2;
+};
+
+// One Euler step with traction (mppi.py:977-992): float64 products, float32 stores.
+template <bool EXACT>
+__device__ __forceinline__ StepOut unicycle_step(const DevParams& P, float x, float y, float th, float v,
+                                                 float w, int lin, int ang) {
+  StepOut o;
+  if (EXACT) {
+    double s, c;
+    sincos_f64((double)th, s, c);
+    double q = (double)P.dt * (double)v;  // exact: two float32 factors
+    double vtr = fma(P.lin_ratio, (double)lin, P.lin_lo);
+    double wtr = fma(P.ang_ratio, (double)ang, P.ang_lo);
+    o.x = (float)fma(vtr, q * c, (double)x);
+    o.y = (float)fma(vtr, q * s, (double)y);
+    o.th = (float)fma(wtr, (double)P.dt * (double)w, (double)th);
+    double dx = (double)(P.xg - o.x), dy = (double)(P.yg - o.y);
+    o.d2 = fma(dx, dx, dy * dy);
+  } else {
+    float s, c;
+    sincosf(th, &s, &c);
+    float vtr = fmaf((float)P.lin_ratio, (float)lin, (float)P.lin_lo);
+    float wtr = fmaf((float)P.ang_ratio, (float)ang, (float)P.ang_lo);
+    float q = P.dt * v * vtr;
+    o.x = fmaf(q, c, x);
+    o.y = fmaf(q, s, y);
+    o.th = fmaf(P.dt * wtr, w, th);
+    float dx = P.xg - o.x, dy = P.yg - o.y;
+    o.d2 = (double)fmaf(dx, dx, dy * dy);
+  }
+  return o;
+}
+
+// cost += stage_cost(d2, step_time, dist_weight)  (mppi.py:20-22, 994): the sum is
+// float64, the store float32.
+template <bool EXACT>
+__device__ __forceinline__ float add_stage_cost(const DevParams& P, float cost, double d2, double step_time) {
+  if (EXACT) return (float)((double)cost + fma(P.dist_weight, sqrt(d2), step_time));
+  return cost + fmaf((float)P.dist_weight, sqrtf((float)d2), (float)step_time);
+}
+
+__device__ __forceinline__ int clamp_index(int i, int n) { return min(max(i, 0), n - 1); }
+
+// -------------------------------------------------------------------------
+// Deterministic-dynamics rollouts: one control sample per lane, 64-lane
+// workgroups so that small N still spreads over the CUs.
+// Cost order (mppi.py:994-1009): per step stage, obstacle, unknown; then the
+// terminal cost; then the control cost of all T steps.
+// -------------------------------------------------------------------------
+template <int KIND, bool EXACT>
+__global__ __launch_bounds__(64) void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
+                                                    const int8_t* __restrict__ risk,
+                                                    const float2* __restrict__ noise,
+                                                    const float2* __restrict__ u,
+                                                    float* __restrict__ costs,
+                                                    float* __restrict__ block_min) {
+  extern __shared__ double2 uos[];
+  stage_control_ratios(P, u, uos);
+  const int n = blockIdx.x * 64 + threadIdx.x;
+  const bool live = n < P.n_local;
+  const int nn = live ? n : P.n_local - 1;
+  const int N = P.n_local, T = P.n_steps;
+
+  float x = P.x0, y = P.y0, th = P.th0;
+  float cost = 0.0f;
+  double d2 = 1e9;
+  bool done = false, reached = false;
+  float2 e = (T > 0) ? noise[nn] : make_float2(0.f, 0.f);
+  for (int t = 0; t < T; ++t) {
+    float2 e_next = (t + 1 < T) ? noise[(size_t)(t + 1) * N + nn] : make_float2(0.f, 0.f);
+    float2 ut = u[t];
+    int xi = clamp_index(floordiv_to_int(x - P.xlo, P.res, P.inv_res), P.cols);
+    int yi = clamp_index(floordiv_to_int(y - P.ylo, P.res, P.inv_res), P.rows);
+    int ci = yi * P.cols + xi;
+    uint32_t cell = cells[ci];
+    int rk = (KIND == MAP_SPEED) ? (int)risk[ci] : 0;
+    float v = clip_f32(ut.x + e.x, P.v_lo, P.v_hi);
+    float w = clip_f32(ut.y + e.y, P.w_lo, P.w_hi);
+    StepOut o = unicycle_step<EXACT>(P, x, y, th, v, w, (int)(int8_t)(cell & 0xff),
+                                     (int)(int8_t)((cell >> 8) & 0xff));
+    double step_time = (double)P.dt;
+    if (KIND == MAP_SPEED) {
+      // dt / (effective_speed + 1e-6), effective speed from the risk map (mppi.py:1095-1096)
+      double eff = fma(P.lin_ratio, (double)rk, P.lin_lo);
+      step_time = (double)P.dt / (eff + 1e-6);
+    }
+    float c1 = add_stage_cost<EXACT>(P, cost, o.d2, step_time);
+    c1 = c1 + (float)(int8_t)((cell >> 16) & 0xff) * P.obs_cost;
+    c1 = c1 + (float)(int8_t)(cell >> 24) * P.unk_cost;
+    if (!done) {
+      x = o.x; y = o.y; th = o.th; d2 = o.d2; cost = c1;
+      if (o.d2 <= (double)P.gt2) { reached = true; done = true; }
+    }
+    e = e_next;
+    if (__all(done)) break;
+  }
+  // terminal cost (mppi.py:26-28, 1005)
+  double term = (reached ? 0.0 : 1.0) * sqrt(d2) / P.v_post_den;
+  cost = EXACT ? (float)((double)cost + term) : cost + (float)term;
+  // control cost over ALL steps, also after an early goal break (mppi.py:1007-1009)
+  for (int t = 0; t < T; ++t) {
+    double cc = control_cost(P, uos[t], noise[(size_t)t * N + nn]);
+    cost = EXACT ? (float)((double)cost + cc) : cost + (float)cc;
+  }
+  if (live) costs[n] = cost;
+  float m = wave_min_f32(live ? cost : __builtin_inff());
+  if (threadIdx.x == 0) block_min[blockIdx.x] = m;
+}
+
+// -------------------------------------------------------------------------
+// Stochastic rollouts (CVaR over M traction samples).  One workgroup per
+// control sample n; lane m (strided if M > blockDim) owns traction sample m.
+// Cost order (mppi.py:690-713): per step stage, obstacle, unknown; control cost
+// of all T steps; terminal cost.  Then per n: sort descending if alpha < 1 and
+// average the first ceil(M*alpha) with the reference's strided tree
+// (mppi.py:716-755).  rollout_oversized_numba (M > 1024) is this kernel with a
+// strided lane loop; its swap-without-compare 'sort' (mppi.py:881-895) is a
+// defect and is not reproduced.
+// LDS: [T] double2 control ratios | [Mp] float sample costs (Mp = next pow2).
+// -------------------------------------------------------------------------
+template <bool EXACT>
+__global__ void k_rollout_tdm(DevParams P, const uint32_t* __restrict__ cellsM,
+                              const float2* __restrict__ noise, const float2* __restrict__ u,
+                              float* __restrict__ costs, float* __restrict__ block_min,
+                              float* __restrict__ sample_costs, int m_pow2) {
+  extern __shared__ double2 uos[];
+  float* sc = reinterpret_cast<float*>(uos + P.n_steps);
+  stage_control_ratios(P, u, uos);
+  const int n = blockIdx.x;
+  const int N = P.n_local, T = P.n_steps, M = P.n_grids;
+
+  for (int m = threadIdx.x; m < m_pow2; m += blockDim.x) {
+    if (m >= M) {
+      sc[m] = -__builtin_inff();  // padding sorts to the tail
+      continue;
+    }
+    float x = P.x0, y = P.y0, th = P.th0;
+    float cost = 0.0f;
+    double d2 = 1e9;
+    bool reached = false;
+    for (int t = 0; t < T; ++t) {
+      float2 e = noise[(size_t)t * N + n];
+      float2 ut = u[t];
+      int xi = clamp_index(floordiv_to_int(x - P.xlo, P.res, P.inv_res), P.cols);
+      int yi = clamp_index(floordiv_to_int(y - P.ylo, P.res, P.inv_res), P.rows);
+      uint32_t cell = cellsM[(size_t)(yi * P.cols + xi) * M + m];
+      float v = clip_f32(ut.x + e.x, P.v_lo, P.v_hi);
+      float w = clip_f32(ut.y + e.y, P.w_lo, P.w_hi);
+      StepOut o = unicycle_step<EXACT>(P, x, y, th, v, w, (int)(int8_t)(cell & 0xff),
+                                       (int)(int8_t)((cell >> 8) & 0xff));
+      x = o.x; y = o.y; th = o.th; d2 = o.d2;
+      cost = add_stage_cost<EXACT>(P, cost, o.d2, (double)P.dt);
+      cost = cost + (float)(int8_t)((cell >> 16) & 0xff) * P.obs_cost;
+      cost = cost + (float)(int8_t)(cell >> 24) * P.unk_cost;
+      if (o.d2 <= (double)P.gt2) { reached = true; break; }
+    }
+    for (int t = 0; t < T; ++t) {
+      double cc = control_cost(P, uos[t], noise[(size_t)t * N + n]);
+      cost = EXACT ? (float)((double)cost + cc) : cost + (float)cc;
+    }
+    double term = (reached ? 0.0 : 1.0) * sqrt(d2) / P.v_post_den;
+    cost = EXACT ? (float)((double)cost + term) : cost + (float)term;
+    sc[m] = cost;
+    if (sample_costs) sample_costs[(size_t)n * M + m] = cost;
+  }
+  __syncthreads();
+
+  if (P.cvar_alpha < 1.0f) {
+    // bitonic sort, descending, over the padded power-of-two array
+    for (int k = 2; k <= m_pow2; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = threadIdx.x; i < m_pow2; i += blockDim.x) {
+          int p = i ^ j;
+          if (p > i) {
+            float a = sc[i], b = sc[p];
+            bool desc = ((i & k) == 0);
+            if (desc ? (a < b) : (a > b)) { sc[i] = b; sc[p] = a; }
+          }
+        }
+        __syncthreads();
+      }
+  }
+  // strided tree sum of the first numel entries, float32, as mppi.py:744-751
+  const int numel = P.numel;
+  for (int s = 1; s < numel; s <<= 1) {
+    for (int i = threadIdx.x; i < M; i += blockDim.x)
+      if ((i % (2 * s) == 0) && (i + s < numel)) sc[i] = sc[i] + sc[i + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    // shared[0]/numel: float32 / int -> float64 -> float32 store (mppi.py:755)
+    float c = (float)((double)sc[0] / (double)numel);
+    costs[n] = c;
+    block_min[n] = c;
+  }
+}
+
+// -------------------------------------------------------------------------
+// barebone notebook rollout: nominal unicycle, quadratic distance cost, disc
+// obstacles tested at the post-step position.
+// -------------------------------------------------------------------------
+template <bool EXACT>
+__global__ __launch_bounds__(64) void k_rollout_barebone(DevParams P, const float2* __restrict__ obs_pos,
+                                                         const float* __restrict__ obs_r,
+                                                         const float2* __restrict__ noise,
+                                                         const float2* __restrict__ u,
+                                                         float* __restrict__ costs,
+                                                         float* __restrict__ block_min) {
+  extern __shared__ double2 uos[];
+  stage_control_ratios(P, u, uos);
+  const int n = blockIdx.x * 64 + threadIdx.x;
+  const bool live = n < P.n_local;
+  const int nn = live ? n : P.n_local - 1;
+  const int N = P.n_local, T = P.n_steps;
+  float x = P.x0, y = P.y0, th = P.th0;
+  float cost = 0.0f;
+  double d2 = 1e9;
+  bool done = false, reached = false;
+  for (int t = 0; t < T; ++t) {
+    float2 e = noise[(size_t)t * N + nn];
+    float2 ut = u[t];
+    float v = clip_f32(ut.x + e.x, P.v_lo, P.v_hi);
+    float w = clip_f32(ut.y + e.y, P.w_lo, P.w_hi);
+    float nx, ny, nth;
+    double nd2;
+    float dtv = P.dt * v;  // float32 * float32 first (cell 3: dt_d*v_noisy*math.cos(...))
+    if (EXACT) {
+      double s, c;
+      sincos_f64((double)th, s, c);
+      nx = (float)fma((double)dtv, c, (double)x);
+      ny = (float)fma((double)dtv, s, (double)y);
+    } else {
+      float s, c;
+      sincosf(th, &s, &c);
+      nx = fmaf(dtv, c, x);
+      ny = fmaf(dtv, s, y);
+    }
+    nth = th + P.dt * w;
+    double dx = (double)(P.xg - nx), dy = (double)(P.yg - ny);
+    nd2 = fma(dx, dx, dy * dy);
+    float c1 = (float)((double)cost + P.dist_weight * nd2);
+    for (int k = 0; k < P.n_obstacles; ++k) {
+      float2 op = obs_pos[k];
+      double ex = (double)(nx - op.x), ey = (double)(ny - op.y);
+      double rr = (double)obs_r[k] * (double)obs_r[k];
+      double diff = fma(ex, ex, ey * ey) - rr;
+      double hit = (diff > 0.0) ? 0.0 : 1.0;
+      c1 = (float)((double)c1 + hit * (double)P.obs_cost);
+    }
+    if (!done) {
+      x = nx; y = ny; th = nth; d2 = nd2; cost = c1;
+      if (nd2 <= (double)P.gt2) { reached = true; done = true; }
+    }
+    if (__all(done)) break;
+  }
+  cost = (float)((double)cost + (reached ? 0.0 : 1.0) * d2);
+  for (int t = 0; t < T; ++t) {
+    double cc = control_cost(P, uos[t], noise[(size_t)t * N + nn]);
+    cost = (float)((double)cost + cc);
+  }
+  if (live) costs[n] = cost;
+  float m = wave_min_f32(live ? cost : __builtin_inff());
+  if (threadIdx.x == 0) block_min[blockIdx.x] = m;
+}
+
+// -------------------------------------------------------------------------
+// Visualisation rollouts -> states [V][T+1][3]
+// across control noise (mppi.py:1194-1295): row 0 = u_cur, no noise, no clip;
+// row b>0 = clip(u_prev + noise[b]); all on traction sample 0.
+// across environments (mppi.py:1298-1351): u_cur over samples 0..V-1.
+// MAPLESS: the barebone notebook's variant.
+// -------------------------------------------------------------------------
+template <bool ACROSS_ENVS, bool MAPLESS>
+__global__ void k_state_rollout(DevParams P, const uint32_t* __restrict__ cells,
+                                const float2* __restrict__ noise, const float2* __restrict__ u_prev,
+                                const float2* __restrict__ u_cur, int n_vis, float* __restrict__ out) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_vis) return;
+  const int T = P.n_steps, N = P.n_local;
+  const int M = ACROSS_ENVS ? P.n_grids : 1;
+  const int m = ACROSS_ENVS ? b : 0;
+  float* o = out + (size_t)b * (T + 1) * 3;
+  float x = P.x0, y = P.y0, th = P.th0;
+  o[0] = x; o[1] = y; o[2] = th;
+  for (int t = 0; t < T; ++t) {
+    float v, w;
+    if (ACROSS_ENVS || b == 0) {
+      v = u_cur[t].x;
+      w = u_cur[t].y;
+    } else {
+      float2 e = noise[(size_t)t * N + b];
+      v = clip_f32(u_prev[t].x + e.x, P.v_lo, P.v_hi);
+      w = clip_f32(u_prev[t].y + e.y, P.w_lo, P.w_hi);
+    }
+    if (MAPLESS) {
+      double s, c;
+      sincos_f64((double)th, s, c);
+      float dtv = P.dt * v;
+      float nx = (float)fma((double)dtv, c, (double)x);
+      float ny = (float)fma((double)dtv, s, (double)y);
+      th = th + P.dt * w;
+      x = nx; y = ny;
+    } else {
+      int xi = clamp_index(floordiv_to_int(x - P.xlo, P.res, P.inv_res), P.cols);
+      int yi = clamp_index(floordiv_to_int(y - P.ylo, P.res, P.inv_res), P.rows);
+      uint32_t cell = cells[(size_t)(yi * P.cols + xi) * M + m];
+      StepOut so = unicycle_step<true>(P, x, y, th, v, w, (int)(int8_t)(cell & 0xff),
+                                       (int)(int8_t)((cell >> 8) & 0xff));
+      x = so.x; y = so.y; th = so.th;
+    }
+    o[3 * (t + 1)] = x; o[3 * (t + 1) + 1] = y; o[3 * (t + 1) + 2] = th;
+  }
+}
+
+}  // namespace mppi
