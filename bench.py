@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Benchmark of the MPPI hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one MPPI iteration: sample control noise -> roll every control
+sample through the horizon with traction-grid lookups -> min-subtract +
+exp-weighted control update (+ one RCCL all-gather of 2T+2 doubles when N > 1).
+Inputs (maps, sampled grids, warm-started u) are resident in HBM before the
+timed region; the K steps run back to back on the planner's stream (u stays on
+the device between steps, exactly the data dependence of params['num_opt'] = K).
+
+Workloads (synthetic; BASELINE.json configs[1..3]):
+  c2  use_det_dynamics, N=8192 per GPU, T=100, 256x256 nominal traction grid
+  c3  use_tdm (CVaR), N=4096 x M=128, 16-bin PMF, 256x256
+  c4  use_det_dynamics, N=65536 per GPU, T=200, CVaR-bin traction
+Multi-GPU is weak scaling: every rank owns `N` control samples of a global
+problem of N*world samples (noise is keyed by the global sample index).
+
+Prints ONE JSON line (rank 0).  torch is imported only for the multi-process
+rendezvous (gloo): the product path is ctypes -> libmppi_hip.so.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def synthetic_world(workload, rng):
+    """Maps per SURVEY.md section 8d: 256x256 cells of 0.25 m, Bernoulli(0.02)
+    obstacle / unknown masks."""
+    rows = cols = 256
+    res = 0.25
+    obstacle = (rng.random((rows, cols)) < 0.02).astype(np.int8)
+    unknown = (rng.random((rows, cols)) < 0.02).astype(np.int8)
+    # keep the start and goal cells free
+    for m in (obstacle, unknown):
+        m[12:20, 12:20] = 0
+        m[236:244, 236:244] = 0
+    if workload == "c2":
+        bins = 2
+        pmf = np.zeros((bins, rows, cols), dtype=np.int8)
+        pmf[-1] = 100  # nominal traction (README.md:136-151 recipe)
+        bin_values = np.array([0.0, 1.0])
+        alpha = 1.0
+    else:
+        bins = 16
+        raw = rng.dirichlet(np.ones(bins), size=(rows, cols))
+        p = np.floor(raw * 100).astype(np.int64)
+        p[..., -1] += 100 - p.sum(axis=-1)
+        pmf = np.ascontiguousarray(np.moveaxis(p, -1, 0)).astype(np.int8)
+        bin_values = np.linspace(0.0, 1.0, bins)
+        alpha = 0.2
+    tdm_dict = dict(xlimits=(0.0, cols * res), ylimits=(0.0, rows * res), res=res,
+                    bin_values=bin_values, bin_values_bounds=(0.0, 1.0),
+                    det_dynamics_cvar_alpha=alpha)
+    return pmf, obstacle, unknown, tdm_dict
+
+
+def make_params(workload):
+    return dict(
+        x0=np.array([4.0, 4.0, np.pi / 4]), xgoal=np.array([60.0, 60.0]), dt=0.1,
+        goal_tolerance=0.5, v_post_rollout=0.01, lambda_weight=1.0,
+        cvar_alpha=0.2 if workload == "c3" else 1.0, alpha_dyn=1.0, num_opt=1,
+        u_std=np.array([2.0, 3.0]), vrange=np.array([0.0, 3.0]), wrange=np.array([-np.pi, np.pi]),
+        dist_weight=1.0, obs_penalty=1e5, unknown_penalty=1e2)
+
+
+WORKLOADS = {
+    "c2": dict(n=8192, t=100, m=1, mode=dict(use_det_dynamics=True),
+               label="Unicycle MPPI det-dyn, N=8192/GPU, T=100, 256x256 nominal traction grid"),
+    "c3": dict(n=4096, t=100, m=128, mode=dict(use_tdm=True),
+               label="CVaR MPPI, N=4096/GPU x M=128 traction samples, 16-bin PMF, 256x256"),
+    "c4": dict(n=65536, t=200, m=1, mode=dict(use_det_dynamics=True),
+               label="Unicycle MPPI det-dyn (CVaR-bin traction), N=65536/GPU, T=200, 256x256"),
+}
+
+
+def algorithmic_bytes(w, n, rp, cp):
+    """SURVEY.md section 8d.  Returns (bytes per iteration, bytes per rollout-kernel launch)."""
+    t, m = w["t"], w["m"]
+    if m == 1:
+        it = n * t * 28 + n * 16 + 32 * t + 4 * rp * cp
+        roll = n * t * (8 + 4) + n * 4 + 8 * t + 4 * rp * cp
+    else:
+        it = 4 * n * m * t + 24 * n * t + 16 * n + 2 * m * rp * cp
+        roll = 4 * n * m * t + 8 * n * t + 4 * n + 2 * m * rp * cp
+    return it, roll
+
+
+def cpu_baseline(w, world_params, lin, ang, planner, budget_s=12.0):
+    """The oracle (C restatement of the reference's CPU path) timed on this
+    host: noise + rollout + update per iteration, OpenMP over rollouts."""
+    from oracle import oracle as O
+    n, t, m = w["n"], w["t"], w["m"]
+    P = world_params
+    p = O.make_params(P, lin.res, lin.padded_xlimits, lin.padded_ylimits,
+                      lin.bin_values_bounds_d.copy_to_host(), ang.bin_values_bounds_d.copy_to_host())
+    rp, cp = lin.pmf_grid_d.shape[1:]
+    lin_g = lin.sample_grid_batch_d.copy_to_host()
+    ang_g = ang.sample_grid_batch_d.copy_to_host()
+    obs, unk = lin.obstacle_map_d.copy_to_host(), lin.unknown_map_d.copy_to_host()
+    u = planner.u_cur_d.copy_to_host()
+    # bounded sample: fewer rollouts for the CVaR workload (N*M*T is 64x the work)
+    n_cpu = n if m == 1 else max(64, n // 32)
+    states = O.xoroshiro_init(n_cpu * t, 1)
+    threads = O.num_threads()
+    iters, t0 = 0, time.perf_counter()
+    while True:
+        noise = O.sample_noise(states, P["u_std"], n_cpu, t)
+        if m == 1:
+            costs = O.rollout_det(p, lin_g, ang_g, obs, unk, noise, u)
+        else:
+            costs = O.rollout_tdm(p, lin_g, ang_g, obs, unk, noise, u)
+        O.update_useq(P["lambda_weight"], costs, noise, P["vrange"], P["wrange"], u)
+        iters += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or iters >= 200:
+            break
+    return dict(value=n_cpu * iters / el, unit="rollouts/s", cores=threads, kind="port",
+                sample="%d iterations of {xoroshiro noise, rollout, update} on %d of the %d "
+                       "control samples (T=%d, M=%d), oracle/liboracle.so with OpenMP over rollouts, "
+                       "%.1f s" % (iters, n_cpu, n, t, m, el))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--math", default="exact", choices=["exact", "fast"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "(--nproc-per-node %d)" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    dist = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import torch.distributed as dist  # rendezvous + barrier only (gloo, CPU)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    from mppi_numba_amd import _lib
+    from mppi_numba_amd.config import Config
+    from mppi_numba_amd.mppi import MPPI_Numba, comm_unique_id
+    from mppi_numba_amd.terrain import TDM_Numba
+
+    w = WORKLOADS[args.workload]
+    n_local, t_steps, m = w["n"], w["t"], w["m"]
+    n_global = n_local * world
+    device = local_rank % max(1, _lib.device_count())
+
+    import contextlib
+    import io
+    quiet = contextlib.redirect_stdout(io.StringIO())  # the mirror prints like the reference does
+    with quiet:
+        cfg = Config(T=t_steps * 0.1, dt=0.1, num_grid_samples=m, num_control_rollouts=n_global,
+                     max_speed_padding=5.0, num_vis_state_rollouts=1, max_map_dim=(260, 260), seed=1,
+                     enforce_recommended_limits=False, math=args.math, device=device, **w["mode"])
+        assert cfg.num_steps == t_steps, cfg.num_steps
+        world_rng = np.random.default_rng(0)
+        pmf, obstacle, unknown, tdm_dict = synthetic_world(args.workload, world_rng)
+        lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
+        lin.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
+        ang.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
+        planner = MPPI_Numba(cfg, rank=rank, world_size=world)
+        params = make_params(args.workload)
+        planner.setup(params, lin, ang)
+    rp, cp = lin.pmf_grid_d.shape[1:]
+
+    if world > 1:
+        ids = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        planner.comm_init(ids[0])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # warm start: one full solve (samples the grids) + 10 iterations
+    planner.solve()
+    planner.iterate_async(10)
+    planner.synchronize()
+
+    # ---- timed region ------------------------------------------------------------
+    planner.iterate_async(args.warmup)
+    planner.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    planner.iterate_async(args.steps)
+    planner.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    gpu_ms = planner.last_elapsed_ms()
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = n_global * args.steps / elapsed
+
+    # ---- per-kernel durations with HIP events on the planner's stream ---------------
+    planner.set_profiling(True)
+    stage = dict(noise=0.0, rollout=0.0, update=0.0, collective=0.0)
+    reps = 50
+    for _ in range(reps):
+        planner.iterate_async(1)
+        planner.synchronize()
+        for k, v in planner.stage_times_ms().items():
+            stage[k] += v / reps
+    planner.set_profiling(False)
+
+    if rank != 0:
+        barrier()
+        return
+
+    bytes_iter, bytes_roll = algorithmic_bytes(w, n_local, rp, cp)
+    roll_s = stage["rollout"] * 1e-3
+    achieved = bytes_roll / roll_s / 1e9
+    out = {
+        "metric": "rollouts/sec (MPPI iteration = noise + rollout + update)",
+        "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32 state / f64 intermediates (reference CPU-path roundings)"
+        if args.math == "exact" else "f32",
+        "data": "synthetic",
+        "config": {"workload": w["label"], "rollouts_per_gpu": n_local, "global_rollouts": n_global,
+                   "horizon_steps": t_steps, "traction_samples": m, "padded_grid": [int(rp), int(cp)],
+                   "rng": "rocRAND philox4x32-10", "math": args.math,
+                   "sharding": "control samples over ranks, 1 all-gather of (2T+2) f64 per step"},
+        "gpu_ms_per_step_events": gpu_ms / args.steps,
+        "kernel_ms": stage,
+        "roofline": {"bound": "hbm", "kernel": "k_rollout (dominant kernel)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": bytes_roll,
+                     "kernel_ms": stage["rollout"]},
+        "roofline_iteration": {"bound": "hbm", "achieved": bytes_iter / (ms_per_step * 1e-3) / 1e9,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": bytes_iter / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "algorithmic_bytes_per_step": bytes_iter},
+    }
+    if not args.no_cpu_baseline:
+        with quiet:
+            out["cpu_baseline"] = cpu_baseline(w, params, lin, ang, planner)
+    print(json.dumps(out))
+    barrier()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmppi_hip.so")
+# MPPI_HIP_LIB lets a developer point at an experimental build of the SAME library
+LIB_PATH = os.environ.get("MPPI_HIP_LIB") or os.path.join(_HERE, "libmppi_hip.so")
 
 MPPI_OK = 0
 MODE_DET, MODE_SPEED_MAP, MODE_TDM, MODE_BAREBONE = 0, 1, 2, 3

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -130,12 +131,15 @@ struct mppi_tdm {
   long n_states = 0;
   int bins = 0, rows = 0, cols = 0;
   bool has_risk = false, maps_set = false, one_hot = false;
+  bool compact_ok = false;  // masks are 0/1 and every traction byte is in [0,127]: 16-bit cells usable
   double lo = 0.0, ratio = 0.0;
   uint64_t epoch = 0;         // Philox call counter
   uint64_t maps_version = 0;  // bumped by set_maps
   uint64_t grid_version = 0;  // bumped whenever `grid` changes
   uint64_t sampled_maps_version = ~0ULL;
   double sampled_alpha = -1.0;
+  bool injected = false;  // grids came from mppi_tdm_set_sampled_grids
+  int8_t injected_max = 0, injected_min = 0;
 };
 
 extern "C" int mppi_tdm_destroy(mppi_tdm* t) {
@@ -248,6 +252,11 @@ extern "C" int mppi_tdm_set_maps(mppi_tdm* t, const int8_t* pmf, int bins, int r
     }
     one_hot = (hundred == 1 && other == 0);
   }
+  bool compact = true;
+  for (int b = 0; b < bins && compact; ++b) compact = bin_to_int8[b] >= 0;
+  for (size_t c = 0; c < plane && compact; ++c)
+    compact = (obstacle[c] == 0 || obstacle[c] == 1) && (unknown[c] == 0 || unknown[c] == 1);
+  t->compact_ok = compact;
   t->one_hot = one_hot;
   t->bins = bins;
   t->rows = rows;
@@ -281,6 +290,7 @@ static int tdm_sample_on(mppi_tdm* t, double alpha_dyn, hipStream_t stream) {
   t->sampled_maps_version = t->maps_version;
   t->sampled_alpha = alpha_dyn;
   ++t->grid_version;
+  t->injected = false;
   return MPPI_OK;
 }
 
@@ -302,8 +312,15 @@ extern "C" int mppi_tdm_set_sampled_grids(mppi_tdm* t, const int8_t* grids, int 
                              grids + (size_t)g * rows * cols, (size_t)cols, (size_t)cols, (size_t)rows,
                              hipMemcpyHostToDevice, t->stream));
   HIP_TRY(hipStreamSynchronize(t->stream));
+  t->injected_min = 127;
+  t->injected_max = -128;
+  for (size_t i = 0; i < (size_t)t->cfg.num_grids * rows * cols; ++i) {
+    if (grids[i] < t->injected_min) t->injected_min = grids[i];
+    if (grids[i] > t->injected_max) t->injected_max = grids[i];
+  }
   ++t->grid_version;
   t->sampled_maps_version = ~0ULL;  // injected grids are not a cached sample
+  t->injected = true;                // arbitrary bytes: the 16-bit cell format is not guaranteed
   return MPPI_OK;
 }
 
@@ -400,6 +417,12 @@ struct mppi_planner {
   double* weight_scale = nullptr;
   uint32_t* cells = nullptr;
   size_t cells_capacity = 0;
+  uint16_t* cells16 = nullptr;  // 16-bit cells, row pitch multiple of 8 (LDS window source)
+  size_t cells16_capacity = 0;
+  int pitch16 = 0;
+  bool cells16_valid = false;
+  int num_cus = 256;
+  int lds_per_cu = 160 * 1024;
   int8_t* risk_ref = nullptr;
   float* sample_costs = nullptr;  // [n_local][M], allocated on first request
   bool want_sample_costs = false;
@@ -446,6 +469,7 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   dev_free(p->packets);
   dev_free(p->weight_scale);
   dev_free(p->cells);
+  dev_free(p->cells16);
   dev_free(p->sample_costs);
   dev_free(p->states);
   dev_free(p->obs_pos);
@@ -530,6 +554,7 @@ extern "C" int mppi_planner_create(const mppi_planner_cfg* cfg, mppi_planner** o
           "device %d is %s; this library is built for gfx950 (MI355X) only", cfg->device, pr.gcn_arch);
   HIP_TRY(hipSetDevice(cfg->device));
   const int n_local = cfg->num_control_rollouts / cfg->world_size;
+  const int device_cus = pr.compute_units, device_lds = pr.lds_bytes_per_cu;
   REQUIRE(cfg->num_vis_state_rollouts <= n_local || cfg->mode == MPPI_MODE_TDM, MPPI_ERR_INVALID,
           "num_vis_state_rollouts exceeds local rollouts");
   REQUIRE(cfg->mode != MPPI_MODE_TDM || cfg->num_vis_state_rollouts <= cfg->num_grid_samples, MPPI_ERR_INVALID,
@@ -538,6 +563,8 @@ extern "C" int mppi_planner_create(const mppi_planner_cfg* cfg, mppi_planner** o
   p->cfg = *cfg;
   p->n_local = n_local;
   p->n_offset = cfg->rank * p->n_local;
+  p->num_cus = device_cus > 0 ? device_cus : 256;
+  p->lds_per_cu = device_lds >= 64 * 1024 ? device_lds : 64 * 1024;
   memset(&p->params, 0, sizeof(p->params));
   int rc = planner_alloc(p);
   if (rc != MPPI_OK) {
@@ -683,10 +710,28 @@ static int ensure_packed(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang) {
     TRY(dev_alloc(&p->cells, need));
     p->cells_capacity = need;
   }
+  p->cells16_valid = false;
   if (M == 1) {
     hipLaunchKernelGGL(k_pack_cells_single, dim3(ceil_div((long)lin->rows * lin->cols, 256)), dim3(256), 0,
                        p->stream, lin->grid, ang->grid, lin->cfg.max_cols, lin->obs, lin->unk, lin->rows,
                        lin->cols, p->cells);
+    auto grid_7bit = [](const mppi_tdm* t) {
+      return t->injected ? (t->injected_min >= 0) : t->compact_ok;
+    };
+    if (lin->compact_ok && grid_7bit(lin) && grid_7bit(ang)) {
+      p->pitch16 = ceil_div(lin->cols, 8) * 8;
+      size_t need16 = (size_t)lin->rows * p->pitch16;
+      if (need16 > p->cells16_capacity) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        dev_free(p->cells16);
+        TRY(dev_alloc(&p->cells16, need16));
+        p->cells16_capacity = need16;
+      }
+      hipLaunchKernelGGL(k_pack_cells16, dim3(ceil_div((long)need16, 256)), dim3(256), 0, p->stream, lin->grid,
+                         ang->grid, lin->cfg.max_cols, lin->obs, lin->unk, lin->rows, lin->cols, p->pitch16,
+                         p->cells16);
+      p->cells16_valid = true;
+    }
   } else {
     dim3 grid((unsigned)(lin->rows * ceil_div(lin->cols, 64)), (unsigned)ceil_div(M, 64));
     hipLaunchKernelGGL(k_pack_cells_multi, grid, dim3(256), 0, p->stream, lin->grid, ang->grid,
@@ -718,20 +763,73 @@ static int launch_noise(mppi_planner* p) {
   return MPPI_OK;
 }
 
-template <bool EXACT>
-static int launch_rollout_t(mppi_planner* p, const DevParams& d) {
+// Decide whether the deterministic rollout can keep its map in LDS: the 16-bit cell
+// window must cover every cell reachable from x0 within the horizon and fit next to
+// the staged controls.  Fills the window fields of `d`.
+static bool plan_lds_window(const mppi_planner* p, DevParams& d, size_t* lds_bytes) {
+  const int T = p->cfg.num_steps;
+  const size_t head = sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);
+  const size_t budget = (size_t)p->lds_per_cu - 1024;  // leave room for the runtime's own use
+  if (!p->cells16_valid || p->cfg.mode != MPPI_MODE_DET) return false;
+  const mppi_params& a = p->params;
+  d.pitch16 = p->pitch16;
+  size_t whole = (size_t)d.rows * p->pitch16 * sizeof(uint16_t);
+  if (head + whole <= budget) {
+    d.win_r0 = 0; d.win_c0 = 0; d.win_rows = d.rows; d.win_cols = p->pitch16;
+    *lds_bytes = head + whole;
+    return true;
+  }
+  double vmax = std::fmax(std::fabs((double)a.vrange[0]), std::fabs((double)a.vrange[1]));
+  double trmax = std::fmax(std::fabs(d.lin_lo), std::fabs(d.lin_lo + 127.0 * d.lin_ratio));
+  double reach_m = (double)T * (double)a.dt * vmax * trmax;
+  if (!std::isfinite(reach_m)) return false;
+  long reach = (long)std::ceil(reach_m / (double)a.res) + 2;
+  long xi0 = (long)std::floor(((double)a.x0[0] - (double)a.xlo) / (double)a.res);
+  long yi0 = (long)std::floor(((double)a.x0[1] - (double)a.ylo) / (double)a.res);
+  long r0 = std::max(0L, yi0 - reach), r1 = std::min((long)d.rows, yi0 + reach + 1);
+  long c0 = std::max(0L, xi0 - reach) / 8 * 8;
+  long c1 = std::min((long)p->pitch16, (std::min((long)d.cols, xi0 + reach + 1) + 7) / 8 * 8);
+  if (r1 <= r0 || c1 <= c0) return false;
+  size_t bytes = (size_t)(r1 - r0) * (size_t)(c1 - c0) * sizeof(uint16_t);
+  if (head + bytes > budget) return false;
+  d.win_r0 = (int)r0; d.win_c0 = (int)c0; d.win_rows = (int)(r1 - r0); d.win_cols = (int)(c1 - c0);
+  *lds_bytes = head + bytes;
+  return true;
+}
+
+template <bool EXACT, bool BOUNDED>
+static int launch_rollout_t(mppi_planner* p, DevParams d) {
   const int N = p->n_local, T = p->cfg.num_steps, M = p->cfg.num_grid_samples;
   size_t lds = sizeof(double2) * (size_t)T;
+  const size_t lds_map = sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);  // + staged u[t]
   switch (p->cfg.mode) {
-    case MPPI_MODE_DET:
-      p->n_block_min = ceil_div(N, 64);
-      hipLaunchKernelGGL((k_rollout_map<MAP_DET, EXACT>), dim3(p->n_block_min), dim3(64), lds, p->stream, d,
-                         p->cells, (const int8_t*)nullptr, p->noise, p->u, p->costs, p->block_min);
+    case MPPI_MODE_DET: {
+      p->n_block_min = ceil_div(N, 64);  // one minimum per wave
+      size_t lds_win = 0;
+      if (plan_lds_window(p, d, &lds_win)) {
+        // the window makes it one workgroup per CU: size the workgroup so that the grid
+        // is at most one wave of workgroups over the CUs
+        // (at least 4 waves: one per SIMD, and four times the lanes to copy the window)
+        int waves = ceil_div(ceil_div(N, 64), p->num_cus);
+        int block = 64 * (waves < 4 ? 4 : (waves > 16 ? 16 : waves));
+        auto kern = k_rollout_map<MAP_DET, EXACT, BOUNDED, true>;
+        if (lds_win > 64 * 1024)
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
+        hipLaunchKernelGGL(kern, dim3(ceil_div(N, block)), dim3(block), lds_win, p->stream, d, p->cells,
+                           p->cells16, (const int8_t*)nullptr, p->noise, p->u, p->costs, p->block_min);
+      } else {
+        hipLaunchKernelGGL((k_rollout_map<MAP_DET, EXACT, BOUNDED, false>), dim3(p->n_block_min), dim3(64),
+                           lds_map, p->stream, d, p->cells, (const uint16_t*)nullptr, (const int8_t*)nullptr,
+                           p->noise, p->u, p->costs, p->block_min);
+      }
       break;
+    }
     case MPPI_MODE_SPEED_MAP:
       p->n_block_min = ceil_div(N, 64);
-      hipLaunchKernelGGL((k_rollout_map<MAP_SPEED, EXACT>), dim3(p->n_block_min), dim3(64), lds, p->stream, d,
-                         p->cells, (const int8_t*)p->risk_ref, p->noise, p->u, p->costs, p->block_min);
+      hipLaunchKernelGGL((k_rollout_map<MAP_SPEED, EXACT, BOUNDED, false>), dim3(p->n_block_min), dim3(64),
+                         lds_map, p->stream, d, p->cells, (const uint16_t*)nullptr, (const int8_t*)p->risk_ref,
+                         p->noise, p->u, p->costs, p->block_min);
       break;
     case MPPI_MODE_TDM: {
       int mp2 = next_pow2(M);
@@ -763,7 +861,16 @@ static int launch_rollout_t(mppi_planner* p, const DevParams& d) {
 static int launch_rollout(mppi_planner* p, const DevParams& d) {
   REQUIRE((size_t)p->cfg.num_steps * sizeof(double2) <= 64 * 1024, MPPI_ERR_INVALID, "num_steps %d too large",
           p->cfg.num_steps);
-  return p->cfg.math == MPPI_MATH_EXACT ? launch_rollout_t<true>(p, d) : launch_rollout_t<false>(p, d);
+  // |theta| can never exceed |theta0| + T*dt*max|w|*max(traction): when that is far
+  // inside the range of the two-term pi/2 reduction, the kernels drop the libm branch
+  const mppi_params& a = p->params;
+  double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
+  double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + 127.0 * d.ang_ratio));
+  if (p->cfg.mode == MPPI_MODE_BAREBONE) trmax = 1.0;
+  double theta_bound = std::fabs((double)a.x0[2]) + (double)p->cfg.num_steps * (double)a.dt * wmax * trmax;
+  bool bounded = std::isfinite(theta_bound) && theta_bound < 5.0e4;
+  if (p->cfg.math != MPPI_MATH_EXACT) return launch_rollout_t<false, false>(p, d);
+  return bounded ? launch_rollout_t<true, true>(p, d) : launch_rollout_t<true, false>(p, d);
 }
 
 // weights + weighted sums + (single GPU) apply; with several GPUs the packet is

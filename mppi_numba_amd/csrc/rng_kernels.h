@@ -193,6 +193,23 @@ __global__ void k_pack_cells_single(const int8_t* __restrict__ lin, const int8_t
   cells[i] = l | (a << 8) | (o << 16) | (k << 24);
 }
 
+// 16-bit variant for the LDS-resident window: lin | ang<<7 | obs<<14 | unk<<15,
+// row pitch `pitch` (multiple of 8 cells so that rows start 16-byte aligned)
+__global__ void k_pack_cells16(const int8_t* __restrict__ lin, const int8_t* __restrict__ ang, int grid_stride,
+                               const int8_t* __restrict__ obs, const int8_t* __restrict__ unk, int rows,
+                               int cols, int pitch, uint16_t* __restrict__ cells16) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * pitch) return;
+  int r = i / pitch, c = i % pitch;
+  uint32_t v = 0;
+  if (c < cols) {
+    uint32_t l = (uint8_t)lin[(size_t)r * grid_stride + c] & 127u, a = (uint8_t)ang[(size_t)r * grid_stride + c] & 127u;
+    uint32_t o = (uint8_t)obs[(size_t)r * cols + c] & 1u, k = (uint8_t)unk[(size_t)r * cols + c] & 1u;
+    v = l | (a << 7) | (o << 14) | (k << 15);
+  }
+  cells16[i] = (uint16_t)v;
+}
+
 // cellsM[(r*cols+c)*M + m]: transpose (M,R,C) -> (R,C,M) through an LDS tile
 // of 64 samples x 64 cells so that both the byte reads (along c) and the word
 // writes (along m) are contiguous.

@@ -47,6 +47,10 @@ struct DevParams {
   int n_grids;        // M
   int rows, cols;     // padded map dims Rp, Cp
   int n_obstacles;    // barebone only
+  // LDS-resident window of the 16-bit cell map (deterministic modes)
+  int win_r0, win_c0;      // first row / column of the window (column multiple of 8)
+  int win_rows, win_cols;  // window size; win_cols is a multiple of 8
+  int pitch16;             // row pitch of the global 16-bit cell array (multiple of 8)
 };
 
 // u[t]/std^2 (float64) for the control-cost term, staged in LDS once per block
@@ -70,13 +74,13 @@ struct StepOut {
 };
 
 // One Euler step with traction (mppi.py:977-992): float64 products, float32 stores.
-template <bool EXACT>
+template <bool EXACT, bool BOUNDED = false>
 __device__ __forceinline__ StepOut unicycle_step(const DevParams& P, float x, float y, float th, float v,
                                                  float w, int lin, int ang) {
   StepOut o;
   if (EXACT) {
     double s, c;
-    sincos_f64((double)th, s, c);
+    sincos_f64<BOUNDED>((double)th, s, c);
     double q = (double)P.dt * (double)v;  // exact: two float32 factors
     double vtr = fma(P.lin_ratio, (double)lin, P.lin_lo);
     double wtr = fma(P.ang_ratio, (double)ang, P.ang_lo);
@@ -104,7 +108,7 @@ __device__ __forceinline__ StepOut unicycle_step(const DevParams& P, float x, fl
 // float64, the store float32.
 template <bool EXACT>
 __device__ __forceinline__ float add_stage_cost(const DevParams& P, float cost, double d2, double step_time) {
-  if (EXACT) return (float)((double)cost + fma(P.dist_weight, sqrt(d2), step_time));
+  if (EXACT) return (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(d2), step_time));
   return cost + fmaf((float)P.dist_weight, sqrtf((float)d2), (float)step_time);
 }
 
@@ -116,64 +120,157 @@ __device__ __forceinline__ int clamp_index(int i, int n) { return min(max(i, 0),
 // Cost order (mppi.py:994-1009): per step stage, obstacle, unknown; then the
 // terminal cost; then the control cost of all T steps.
 // -------------------------------------------------------------------------
-template <int KIND, bool EXACT>
-__global__ __launch_bounds__(64) void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
-                                                    const int8_t* __restrict__ risk,
-                                                    const float2* __restrict__ noise,
-                                                    const float2* __restrict__ u,
-                                                    float* __restrict__ costs,
-                                                    float* __restrict__ block_min) {
+// steps whose noise is fetched together: kNoiseBatch independent 8-byte loads per
+// lane are in flight while the previous batch is integrated, and the batch body is
+// straight-line code (no per-step branch), so that the compiler can hoist the LDS
+// reads of u[t] and interleave independent work of neighbouring steps.
+constexpr int kNoiseBatch = 8;
+
+struct RolloutState {
+  float x, y, th, cost;
+  double d2;
+  bool done, reached;
+};
+
+// 16-bit cell: lin (7 bits) | ang (7 bits) << 7 | obstacle << 14 | unknown << 15.
+// Usable when both masks are 0/1 and every traction byte is in [0, 127] (the
+// reference's own maps always are: tractions 0..100, indicator masks).
+template <int KIND, bool EXACT, bool BOUNDED, bool LDSMAP>
+__device__ __forceinline__ void map_step(const DevParams& P, const uint32_t* __restrict__ cells,
+                                         const int8_t* __restrict__ risk, const uint16_t* lds_map,
+                                         float2 ut, float2 e, RolloutState& st) {
+  int xi = clamp_index(floordiv_to_int(st.x - P.xlo, P.res, P.inv_res), P.cols);
+  int yi = clamp_index(floordiv_to_int(st.y - P.ylo, P.res, P.inv_res), P.rows);
+  int lin, ang, obs, unk, rk = 0;
+  if (LDSMAP) {
+    // the window covers every cell reachable within the horizon (host-checked);
+    // the clamp only guards memory safety
+    int wr = clamp_index(yi - P.win_r0, P.win_rows), wc = clamp_index(xi - P.win_c0, P.win_cols);
+    uint32_t c16 = lds_map[wr * P.win_cols + wc];
+    lin = (int)(c16 & 127u);
+    ang = (int)((c16 >> 7) & 127u);
+    obs = (int)((c16 >> 14) & 1u);
+    unk = (int)(c16 >> 15);
+  } else {
+    int ci = yi * P.cols + xi;
+    uint32_t cell = cells[ci];
+    if (KIND == MAP_SPEED) rk = (int)risk[ci];
+    lin = (int)(int8_t)(cell & 0xff);
+    ang = (int)(int8_t)((cell >> 8) & 0xff);
+    obs = (int)(int8_t)((cell >> 16) & 0xff);
+    unk = (int)(int8_t)(cell >> 24);
+  }
+  float v = clip_f32(ut.x + e.x, P.v_lo, P.v_hi);
+  float w = clip_f32(ut.y + e.y, P.w_lo, P.w_hi);
+  StepOut o = unicycle_step<EXACT, BOUNDED>(P, st.x, st.y, st.th, v, w, lin, ang);
+  double step_time = (double)P.dt;
+  if (KIND == MAP_SPEED) {
+    // dt / (effective_speed + 1e-6), effective speed from the risk map (mppi.py:1095-1096)
+    double eff = fma(P.lin_ratio, (double)rk, P.lin_lo);
+    step_time = (double)P.dt / (eff + 1e-6);
+  }
+  float c1 = add_stage_cost<EXACT>(P, st.cost, o.d2, step_time);
+  c1 = c1 + (float)obs * P.obs_cost;
+  c1 = c1 + (float)unk * P.unk_cost;
+  bool hit = o.d2 <= (double)P.gt2;
+  bool act = !st.done;
+  st.x = act ? o.x : st.x;
+  st.y = act ? o.y : st.y;
+  st.th = act ? o.th : st.th;
+  st.d2 = act ? o.d2 : st.d2;
+  st.cost = act ? c1 : st.cost;
+  st.reached = st.reached || (act && hit);
+  st.done = st.done || hit;
+}
+
+// LDS: [T] double2 control ratios | [T] float2 u | (LDSMAP) window of 16-bit cells
+template <int KIND, bool EXACT, bool BOUNDED, bool LDSMAP>
+__global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
+                              const uint16_t* __restrict__ cells16, const int8_t* __restrict__ risk,
+                              const float2* __restrict__ noise, const float2* __restrict__ u,
+                              float* __restrict__ costs, float* __restrict__ block_min) {
   extern __shared__ double2 uos[];
+  float2* us = reinterpret_cast<float2*>(uos + P.n_steps);  // u[t] staged next to the ratios
+  // 16-byte aligned start of the map window
+  uint16_t* lds_map = reinterpret_cast<uint16_t*>(uos + P.n_steps + (P.n_steps + 1) / 2);
+  if (LDSMAP) {
+    // coalesced 16-byte copies (window columns are multiples of 8 cells); eight
+    // independent loads per lane are issued before the first LDS write
+    const int vec_per_row = P.win_cols / 8;
+    const int total = P.win_rows * vec_per_row;
+    const uint4* src = reinterpret_cast<const uint4*>(cells16);
+    uint4* dst = reinterpret_cast<uint4*>(lds_map);
+    const size_t base = ((size_t)P.win_r0 * P.pitch16 + P.win_c0) / 8;
+    const int src_pitch = P.pitch16 / 8;
+    if (P.win_cols == P.pitch16) {
+      // full-width window: one contiguous run
+      for (int i0 = threadIdx.x; i0 < total; i0 += 8 * blockDim.x) {
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = src[base + min(i0 + k * (int)blockDim.x, total - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          int i = i0 + k * (int)blockDim.x;
+          if (i < total) dst[i] = v[k];
+        }
+      }
+    } else {
+      // one wave per row, lanes along the row
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+      for (int r = wave; r < P.win_rows; r += n_waves)
+        for (int c8 = lane; c8 < vec_per_row; c8 += 64)
+          dst[r * vec_per_row + c8] = src[base + (size_t)r * src_pitch + c8];
+    }
+  }
+  for (int t = threadIdx.x; t < P.n_steps; t += blockDim.x) us[t] = u[t];
   stage_control_ratios(P, u, uos);
-  const int n = blockIdx.x * 64 + threadIdx.x;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = n < P.n_local;
   const int nn = live ? n : P.n_local - 1;
   const int N = P.n_local, T = P.n_steps;
+  const float2* col = noise + nn;  // this lane's column of the [T][N] noise
 
-  float x = P.x0, y = P.y0, th = P.th0;
-  float cost = 0.0f;
-  double d2 = 1e9;
-  bool done = false, reached = false;
-  float2 e = (T > 0) ? noise[nn] : make_float2(0.f, 0.f);
-  for (int t = 0; t < T; ++t) {
-    float2 e_next = (t + 1 < T) ? noise[(size_t)(t + 1) * N + nn] : make_float2(0.f, 0.f);
-    float2 ut = u[t];
-    int xi = clamp_index(floordiv_to_int(x - P.xlo, P.res, P.inv_res), P.cols);
-    int yi = clamp_index(floordiv_to_int(y - P.ylo, P.res, P.inv_res), P.rows);
-    int ci = yi * P.cols + xi;
-    uint32_t cell = cells[ci];
-    int rk = (KIND == MAP_SPEED) ? (int)risk[ci] : 0;
-    float v = clip_f32(ut.x + e.x, P.v_lo, P.v_hi);
-    float w = clip_f32(ut.y + e.y, P.w_lo, P.w_hi);
-    StepOut o = unicycle_step<EXACT>(P, x, y, th, v, w, (int)(int8_t)(cell & 0xff),
-                                     (int)(int8_t)((cell >> 8) & 0xff));
-    double step_time = (double)P.dt;
-    if (KIND == MAP_SPEED) {
-      // dt / (effective_speed + 1e-6), effective speed from the risk map (mppi.py:1095-1096)
-      double eff = fma(P.lin_ratio, (double)rk, P.lin_lo);
-      step_time = (double)P.dt / (eff + 1e-6);
-    }
-    float c1 = add_stage_cost<EXACT>(P, cost, o.d2, step_time);
-    c1 = c1 + (float)(int8_t)((cell >> 16) & 0xff) * P.obs_cost;
-    c1 = c1 + (float)(int8_t)(cell >> 24) * P.unk_cost;
-    if (!done) {
-      x = o.x; y = o.y; th = o.th; d2 = o.d2; cost = c1;
-      if (o.d2 <= (double)P.gt2) { reached = true; done = true; }
-    }
-    e = e_next;
-    if (__all(done)) break;
+  RolloutState st = {P.x0, P.y0, P.th0, 0.0f, 1e9, false, false};
+  float2 e_cur[kNoiseBatch], e_nxt[kNoiseBatch];
+  // rows past the horizon are clamped to the last row: every load is unconditional
+#pragma unroll
+  for (int j = 0; j < kNoiseBatch; ++j) e_cur[j] = col[(size_t)min(j, T - 1) * N];
+  int t0 = 0;
+  for (; t0 + kNoiseBatch <= T; t0 += kNoiseBatch) {
+#pragma unroll
+    for (int j = 0; j < kNoiseBatch; ++j) e_nxt[j] = col[(size_t)min(t0 + kNoiseBatch + j, T - 1) * N];
+#pragma unroll
+    for (int j = 0; j < kNoiseBatch; ++j)
+      map_step<KIND, EXACT, BOUNDED, LDSMAP>(P, cells, risk, lds_map, us[t0 + j], e_cur[j], st);
+#pragma unroll
+    for (int j = 0; j < kNoiseBatch; ++j) e_cur[j] = e_nxt[j];
+    if (__all(st.done)) break;
   }
+  if (!__all(st.done))
+    for (int t = t0; t < T; ++t)
+      map_step<KIND, EXACT, BOUNDED, LDSMAP>(P, cells, risk, lds_map, us[t], e_cur[t - t0], st);
+
+  float cost = st.cost;
   // terminal cost (mppi.py:26-28, 1005)
-  double term = (reached ? 0.0 : 1.0) * sqrt(d2) / P.v_post_den;
+  double term = (st.reached ? 0.0 : 1.0) * sqrt(st.d2) / P.v_post_den;
   cost = EXACT ? (float)((double)cost + term) : cost + (float)term;
-  // control cost over ALL steps, also after an early goal break (mppi.py:1007-1009)
-  for (int t = 0; t < T; ++t) {
-    double cc = control_cost(P, uos[t], noise[(size_t)t * N + nn]);
-    cost = EXACT ? (float)((double)cost + cc) : cost + (float)cc;
+  // control cost over ALL steps, also after an early goal break (mppi.py:1007-1009);
+  // the float32-rounded accumulation is sequential, loads and products are batched
+  for (t0 = 0; t0 + kNoiseBatch <= T; t0 += kNoiseBatch) {
+    double cc[kNoiseBatch];
+#pragma unroll
+    for (int j = 0; j < kNoiseBatch; ++j) cc[j] = control_cost(P, uos[t0 + j], col[(size_t)(t0 + j) * N]);
+#pragma unroll
+    for (int j = 0; j < kNoiseBatch; ++j) cost = EXACT ? (float)((double)cost + cc[j]) : cost + (float)cc[j];
+  }
+  for (int t = t0; t < T; ++t) {
+    double c1 = control_cost(P, uos[t], col[(size_t)t * N]);
+    cost = EXACT ? (float)((double)cost + c1) : cost + (float)c1;
   }
   if (live) costs[n] = cost;
+  // one minimum per wave (the update kernel reduces them): slot = global wave index
   float m = wave_min_f32(live ? cost : __builtin_inff());
-  if (threadIdx.x == 0) block_min[blockIdx.x] = m;
+  if ((threadIdx.x & 63) == 0) block_min[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = m;
 }
 
 // -------------------------------------------------------------------------
@@ -295,7 +392,7 @@ __global__ __launch_bounds__(64) void k_rollout_barebone(DevParams P, const floa
     float dtv = P.dt * v;  // float32 * float32 first (cell 3: dt_d*v_noisy*math.cos(...))
     if (EXACT) {
       double s, c;
-      sincos_f64((double)th, s, c);
+      sincos_f64<false>((double)th, s, c);
       nx = (float)fma((double)dtv, c, (double)x);
       ny = (float)fma((double)dtv, s, (double)y);
     } else {
@@ -363,7 +460,7 @@ __global__ void k_state_rollout(DevParams P, const uint32_t* __restrict__ cells,
     }
     if (MAPLESS) {
       double s, c;
-      sincos_f64((double)th, s, c);
+      sincos_f64<false>((double)th, s, c);
       float dtv = P.dt * v;
       float nx = (float)fma((double)dtv, c, (double)x);
       float ny = (float)fma((double)dtv, s, (double)y);

@@ -1,0 +1,210 @@
+"""GPU parity at BASELINE.json's sizes against the C restatement (oracle/), plus
+size-independent properties: generator statistics, shard-count invariance,
+shift semantics, cost-shift invariance of the update."""
+import numpy as np
+import pytest
+
+import bench
+from helpers import ulp_diff_f32
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def build(workload, n=None, rank=0, world=1, rng="philox", math="exact", seed=1):
+    from mppi_numba_amd.config import Config
+    from mppi_numba_amd.mppi import MPPI_Numba
+    from mppi_numba_amd.terrain import TDM_Numba
+    w = dict(bench.WORKLOADS[workload])
+    if n is not None:
+        w["n"] = n
+    cfg = Config(T=w["t"] * 0.1, dt=0.1, num_grid_samples=w["m"], num_control_rollouts=w["n"] * world,
+                 max_speed_padding=5.0, num_vis_state_rollouts=1, max_map_dim=(260, 260), seed=seed,
+                 enforce_recommended_limits=False, rng=rng, math=math, **w["mode"])
+    pmf, obstacle, unknown, tdm_dict = bench.synthetic_world(workload, np.random.default_rng(0))
+    lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
+    lin.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
+    ang.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
+    planner = MPPI_Numba(cfg, rank=rank, world_size=world)
+    params = bench.make_params(workload)
+    planner.setup(params, lin, ang)
+    return w, cfg, lin, ang, planner, params
+
+
+def oracle_params(params, lin, ang):
+    return O.make_params(params, lin.res, lin.padded_xlimits, lin.padded_ylimits,
+                         lin.bin_values_bounds_d.copy_to_host(), ang.bin_values_bounds_d.copy_to_host())
+
+
+def oracle_costs(w, params, lin, ang, noise, u):
+    p = oracle_params(params, lin, ang)
+    args = (p, lin.sample_grid_batch_d.copy_to_host(), ang.sample_grid_batch_d.copy_to_host(),
+            lin.obstacle_map_d.copy_to_host(), lin.unknown_map_d.copy_to_host(), noise, u)
+    return O.rollout_tdm(*args) if w["m"] > 1 else O.rollout_det(*args)
+
+
+@pytest.mark.parametrize("workload,n", [("c2", None), ("c4", 16384), ("c3", 192)])
+def test_costs_and_update_vs_oracle_at_scale(workload, n):
+    """BASELINE configs[1] at full size (N=8192, T=100, 256x256), configs[3]'s
+    T=200 CVaR-bin variant at N=16384, configs[2]'s M=128 CVaR at reduced N."""
+    w, cfg, lin, ang, planner, params = build(workload, n)
+    planner.solve()            # samples grids, one iteration
+    planner.iterate_async(5)   # warm-start u away from zero
+    planner.synchronize()
+    planner.sample_noise()
+    noise = planner.noise_samples_d.copy_to_host()
+    u_in = planner.u_cur_d.copy_to_host()
+    planner.rollout()
+    got = planner.costs_d.copy_to_host()
+    want = oracle_costs(w, params, lin, ang, noise, u_in)
+    ulps = ulp_diff_f32(got, want)
+    assert (ulps == 0).mean() >= 0.999, "exact fraction %.5f, max ulp %d" % ((ulps == 0).mean(), ulps.max())
+    assert (np.abs(got - want) / np.abs(want)).max() < 1e-6
+    # update: deterministic float64 tree vs the reference's float32 order
+    planner.update()
+    w_ref, u_ref, _ = O.update_useq(params["lambda_weight"], want, noise, params["vrange"],
+                                    params["wrange"], u_in)
+    scale = np.array([3.0, np.pi])
+    assert (np.abs(planner.u_cur_d.copy_to_host() - u_ref) / scale).max() <= 1e-5
+    got_w = planner.weights_d.copy_to_host()
+    assert abs(got_w.sum() - 1.0) < 1e-5
+    assert np.abs(got_w - w_ref).max() <= 1e-5 * w_ref.max()
+
+
+def test_fast_math_close_to_exact():
+    w, cfg, lin, ang, planner, params = build("c2", 4096, math="fast")
+    planner.solve()
+    planner.sample_noise()
+    noise, u_in = planner.noise_samples_d.copy_to_host(), planner.u_cur_d.copy_to_host()
+    planner.rollout()
+    got = planner.costs_d.copy_to_host()
+    want = oracle_costs(w, params, lin, ang, noise, u_in)
+    rel = np.abs(got - want) / np.abs(want)
+    # float32 trajectories can cross a cell border one step apart: compare the bulk
+    assert np.quantile(rel, 0.99) < 1e-5
+
+
+def test_philox_noise_statistics_and_epochs():
+    w, cfg, lin, ang, planner, params = build("c2", 8192)
+    planner.sample_noise()
+    a = planner.noise_samples_d.copy_to_host().astype(np.float64)
+    planner.sample_noise()
+    b = planner.noise_samples_d.copy_to_host().astype(np.float64)
+    assert not np.array_equal(a, b)
+    n = a[..., 0].size
+    for c, std in enumerate(params["u_std"]):
+        z = a[..., c] / std
+        assert abs(z.mean()) < 5.0 / np.sqrt(n)
+        assert abs(z.std() - 1.0) < 5.0 / np.sqrt(2 * n)
+        assert abs((np.abs(z) < 1.0).mean() - 0.682689) < 5.0 * np.sqrt(0.2167 / n)
+        assert abs(np.mean(z ** 4) - 3.0) < 0.05
+    assert abs(np.corrcoef(a[..., 0].ravel(), a[..., 1].ravel())[0, 1]) < 5.0 / np.sqrt(n)
+    assert abs(np.corrcoef(a.ravel(), b.ravel())[0, 1]) < 5.0 / np.sqrt(2 * n)
+
+
+def test_philox_noise_is_independent_of_shard_count():
+    """Counter = global (rollout, step) index: shard r of 2 draws rows [r*N/2, ...) of the 1-GPU noise."""
+    _, _, _, _, full, _ = build("c2", 2048)
+    full.sample_noise()
+    want = full.noise_samples_d.copy_to_host()
+    for r in range(2):
+        _, _, _, _, part, _ = build("c2", 1024, rank=r, world=2)
+        part.sample_noise()
+        got = part.noise_samples_d.copy_to_host()
+        assert np.array_equal(got, want[r * 1024:(r + 1) * 1024])
+
+
+def test_sharded_update_equals_single_gpu():
+    """Two shards (packets exchanged on the host here; RCCL all-gather in production)
+    give the u of the unsharded run."""
+    w, _, lin, ang, full, params = build("c2", 2048)
+    full.solve()
+    full.iterate_async(3)
+    full.synchronize()
+    u_in = full.u_cur_d.copy_to_host()
+    full.sample_noise()
+    noise = full.noise_samples_d.copy_to_host()
+    full.rollout()
+    costs = full.costs_d.copy_to_host()
+    full.update()
+    want = full.u_cur_d.copy_to_host()
+    want_w = full.weights_d.copy_to_host()
+    parts, packets = [], []
+    for r in range(2):
+        _, _, _, _, part, _ = build("c2", 1024, rank=r, world=2)
+        part.set_u(u_in)
+        part.set_noise(noise[r * 1024:(r + 1) * 1024])
+        part.set_costs(costs[r * 1024:(r + 1) * 1024])
+        packets.append(part.update_local())
+        parts.append(part)
+    packets = np.stack(packets)
+    for r, part in enumerate(parts):
+        part.update_apply(packets)
+        got = part.u_cur_d.copy_to_host()
+        assert np.abs(got - want).max() <= 2e-6, np.abs(got - want).max()
+        got_w = part.weights_d.copy_to_host()
+        assert np.abs(got_w - want_w[r * 1024:(r + 1) * 1024]).max() <= 1e-6 * max(want_w.max(), 1e-30)
+    assert np.array_equal(parts[0].u_cur_d.copy_to_host(), parts[1].u_cur_d.copy_to_host())
+
+
+def test_update_is_invariant_to_a_cost_offset_and_deterministic():
+    w, _, lin, ang, planner, params = build("c2", 4096)
+    planner.solve()
+    planner.sample_noise()
+    planner.rollout()
+    costs = planner.costs_d.copy_to_host()
+    u_in = planner.u_cur_d.copy_to_host()
+    outs = []
+    for offset in (0.0, 0.0, 512.0):  # 512 keeps every cost exactly representable + shifted
+        planner.set_u(u_in)
+        planner.set_costs(costs + np.float32(offset))
+        planner.update()
+        outs.append((planner.u_cur_d.copy_to_host(), planner.weights_d.copy_to_host()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    shifted_exact = np.array_equal((costs + np.float32(512.0)) - np.float32(512.0), costs)
+    if shifted_exact:
+        assert np.abs(outs[0][0] - outs[2][0]).max() <= 1e-6
+
+
+def test_device_shift_matches_reference_shift():
+    _, _, _, _, planner, _ = build("c2", 1024)
+    u = np.random.default_rng(3).normal(size=(planner.num_steps, 2)).astype(np.float32)
+    for k in (1, 3, planner.num_steps - 1):
+        planner.set_u(u)
+        planner.shift_and_update_on_device(np.array([4.0, 4.0, 0.0]), k)
+        want = u.copy()
+        want[:-k] = want[k:]
+        assert np.array_equal(planner.u_cur_d.copy_to_host(), want)
+
+
+def test_tdm_philox_sampling_follows_the_pmf():
+    from mppi_numba_amd.config import Config
+    from mppi_numba_amd.terrain import TDM_Numba
+    bins, rows, cols, m = 5, 40, 44, 64
+    cfg = Config(T=1.0, dt=0.1, num_grid_samples=m, num_control_rollouts=128, max_speed_padding=1.0,
+                 max_map_dim=(50, 50), use_tdm=True, enforce_recommended_limits=False)
+    pmf = np.zeros((bins, rows, cols), dtype=np.int8)
+    mass = np.array([10, 20, 40, 25, 5], dtype=np.int8)
+    pmf[:] = mass.reshape(-1, 1, 1)
+    td = dict(xlimits=(0, cols * 0.5), ylimits=(0, rows * 0.5), res=0.5,
+              bin_values=np.linspace(0, 1, bins), bin_values_bounds=(0.0, 1.0), det_dynamics_cvar_alpha=1.0)
+    tdm = TDM_Numba(cfg)
+    tdm.set_TDM_from_PMF_grid(pmf, td)
+    pad = tdm.pad_cells
+    first = tdm.sample_grids(1.0).copy_to_host()
+    rp, cp = tdm.get_padded_grid_xy_dim()
+    inner = first[:, pad:pad + rows, pad:pad + cols]
+    ring = first[:, :rp, :cp].copy()
+    ring[:, pad:pad + rows, pad:pad + cols] = 0
+    assert (ring == 0).all(), "padding cells must sample to zero traction"
+    values = tdm.bin_to_int8
+    freq = np.array([(inner == v).mean() for v in values])
+    n = inner.size
+    assert np.abs(freq - mass / 100.0).max() < 5 * np.sqrt(0.25 / n)
+    # alpha_dyn restricts the draw to the lowest alpha_dyn of the CDF (terrain.py:683)
+    low = tdm.sample_grids(0.3).copy_to_host()[:, pad:pad + rows, pad:pad + cols]
+    assert set(np.unique(low)) <= set(values[:2].tolist())
+    f0 = (low == values[0]).mean()
+    assert abs(f0 - 10.0 / 30.0) < 0.02
+    again = tdm.sample_grids(1.0).copy_to_host()
+    assert not np.array_equal(again, first)
