@@ -97,6 +97,18 @@ def algorithmic_bytes(w, n, rp, cp):
     return it, roll
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(w, world_params, lin, ang, planner, budget_s=12.0):
     """The oracle (C restatement of the reference's CPU path) timed on this
     host: noise + rollout + update per iteration, OpenMP over rollouts."""
@@ -113,6 +125,7 @@ def cpu_baseline(w, world_params, lin, ang, planner, budget_s=12.0):
     # bounded sample: fewer rollouts for the CVaR workload (N*M*T is 64x the work)
     n_cpu = n if m == 1 else max(64, n // 32)
     states = O.xoroshiro_init(n_cpu * t, 1)
+    O.set_num_threads(usable_cores())
     threads = O.num_threads()
     iters, t0 = 0, time.perf_counter()
     while True:
@@ -124,7 +137,7 @@ def cpu_baseline(w, world_params, lin, ang, planner, budget_s=12.0):
         O.update_useq(P["lambda_weight"], costs, noise, P["vrange"], P["wrange"], u)
         iters += 1
         el = time.perf_counter() - t0
-        if el > budget_s or iters >= 200:
+        if el > budget_s or iters >= 5000:
             break
     return dict(value=n_cpu * iters / el, unit="rollouts/s", cores=threads, kind="port",
                 sample="%d iterations of {xoroshiro noise, rollout, update} on %d of the %d "

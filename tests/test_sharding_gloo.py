@@ -1,0 +1,102 @@
+"""world_size = 2 over gloo on CPU: the sharded control update.
+
+Each rank owns half of the control samples, reduces them to one packet
+{beta_g, den_g, num_g[T][2]} (what k_weights / k_wsum / k_finish produce on the
+GPU), the packets are all-gathered (RCCL on the GPU, gloo here) and every rank
+applies the combine of k_apply.  The result must equal the reference's
+single-block update (oracle) of the unsharded problem, on every rank, bit for
+bit equal between ranks.  This is the algorithm of update_kernels.h restated in
+numpy on the test side; the GPU test test_sharded_update_equals_single_gpu runs
+the kernels themselves.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def local_packet(costs, noise, lam):
+    """packet of one shard, float64 as on the device"""
+    beta = np.float32(costs.min())
+    w = np.exp(-1.0 / np.float64(np.float32(lam)) * (costs - beta).astype(np.float32).astype(np.float64))
+    w = w.astype(np.float32).astype(np.float64)                     # weights are stored float32
+    num = np.einsum("n,ntc->tc", w, noise.astype(np.float64))
+    return np.concatenate([[np.float64(beta), w.sum()], num.ravel()])
+
+
+def apply_packets(packets, lam, u, vrange, wrange):
+    t = (packets.shape[1] - 2) // 2
+    beta = packets[:, 0].min()
+    scale = np.exp(-1.0 / np.float64(np.float32(lam)) * (packets[:, 0] - beta))
+    den = (scale * packets[:, 1]).sum()
+    num = (scale[:, None] * packets[:, 2:]).sum(axis=0).reshape(t, 2)
+    out = u.astype(np.float32) + (num / den).astype(np.float32)
+    out[:, 0] = np.clip(out[:, 0], np.float32(vrange[0]), np.float32(vrange[1]))
+    out[:, 1] = np.clip(out[:, 1], np.float32(wrange[0]), np.float32(wrange[1]))
+    return out.astype(np.float32)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from helpers import golden, iterations, params_from_golden
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        worst = 0.0
+        for name in ("speedmap_cvar", "det_cvar", "tdm_cvar_odd"):
+            g = golden(name)
+            P = params_from_golden(g)
+            for it in iterations(g):
+                n = it["costs"].shape[0]
+                lo, hi = rank * n // world, (rank + 1) * n // world
+                packet = local_packet(it["costs"][lo:hi], it["noise"][lo:hi], P["lambda_weight"])
+                gathered = [torch.zeros(packet.size, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(gathered, torch.from_numpy(packet))
+                packets = np.stack([t.numpy() for t in gathered])
+                u = apply_packets(packets, P["lambda_weight"], it["u_in"], P["vrange"], P["wrange"])
+                _, want, _ = O.update_useq(P["lambda_weight"], it["costs"], it["noise"], P["vrange"],
+                                           P["wrange"], it["u_in"])
+                worst = max(worst, float(np.abs(u - want).max()))
+                # every rank must hold the same bits
+                mine = torch.from_numpy(u.copy())
+                others = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(others, mine)
+                assert all(torch.equal(o, mine) for o in others)
+        q.put((rank, worst))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_update_over_gloo_world2():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, worst in results:
+        assert worst <= 1e-5 * np.pi, (rank, worst)
+
+
+def test_shard_ranges_cover_all_rollouts():
+    for n, world in ((8192, 1), (8192, 8), (65536, 4)):
+        seen = np.zeros(n, dtype=int)
+        for r in range(world):
+            seen[r * (n // world):(r + 1) * (n // world)] += 1
+        assert (seen == 1).all()
