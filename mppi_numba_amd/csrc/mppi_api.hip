@@ -132,6 +132,7 @@ struct mppi_tdm {
   int bins = 0, rows = 0, cols = 0;
   bool has_risk = false, maps_set = false, one_hot = false;
   bool compact_ok = false;  // masks are 0/1 and every traction byte is in [0,127]: 16-bit cells usable
+  int table_max = 127;      // largest traction byte the sampler can write
   double lo = 0.0, ratio = 0.0;
   uint64_t epoch = 0;         // Philox call counter
   uint64_t maps_version = 0;  // bumped by set_maps
@@ -257,6 +258,8 @@ extern "C" int mppi_tdm_set_maps(mppi_tdm* t, const int8_t* pmf, int bins, int r
   for (size_t c = 0; c < plane && compact; ++c)
     compact = (obstacle[c] == 0 || obstacle[c] == 1) && (unknown[c] == 0 || unknown[c] == 1);
   t->compact_ok = compact;
+  t->table_max = -128;
+  for (int b = 0; b < bins; ++b) t->table_max = std::max(t->table_max, (int)bin_to_int8[b]);
   t->one_hot = one_hot;
   t->bins = bins;
   t->rows = rows;
@@ -406,17 +409,16 @@ struct mppi_planner {
   float2* u = nullptr;        // [T]
   float2* u_prev = nullptr;   // [T]
   float* costs = nullptr;     // [n_local]
-  float* weights = nullptr;   // [n_local], unnormalised exp(-(c-beta_g)/lambda)
-  float* weights_out = nullptr;
-  float* block_min = nullptr;  // [n_local]
-  int n_block_min = 0;
-  double* den_part = nullptr;  // [ceil(n_local/256)]
-  double2* partial = nullptr;  // [n_chunks][T]
-  int n_chunks = 1, chunk = 0;
+  float* weights_out = nullptr;  // [n_local] normalised weights, filled on request
+  float* w_rel = nullptr;      // [n_local] exp(-(c - beta_tile)/lambda)
+  float* tile_beta = nullptr;  // [n_tiles] minimum cost of each tile of 64 rollouts
+  int n_tiles = 0;
+  bool tile_packets_fresh = false;  // w_rel / tile_beta written by the rollout kernel for the current costs
   double* packets = nullptr;  // [world][2+2T]; own packet at [rank]
-  double* weight_scale = nullptr;
+  double* stats = nullptr;    // {beta, den} of the last update
   uint32_t* cells = nullptr;
   size_t cells_capacity = 0;
+  double* cc_scratch = nullptr;  // [T][n_local] control-cost products of the pipelined rollout
   uint16_t* cells16 = nullptr;  // 16-bit cells, row pitch multiple of 8 (LDS window source)
   size_t cells16_capacity = 0;
   int pitch16 = 0;
@@ -461,15 +463,14 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   dev_free(p->u);
   dev_free(p->u_prev);
   dev_free(p->costs);
-  dev_free(p->weights);
   dev_free(p->weights_out);
-  dev_free(p->block_min);
-  dev_free(p->den_part);
-  dev_free(p->partial);
+  dev_free(p->w_rel);
+  dev_free(p->tile_beta);
   dev_free(p->packets);
-  dev_free(p->weight_scale);
+  dev_free(p->stats);
   dev_free(p->cells);
   dev_free(p->cells16);
+  dev_free(p->cc_scratch);
   dev_free(p->sample_costs);
   dev_free(p->states);
   dev_free(p->obs_pos);
@@ -491,32 +492,25 @@ static int planner_alloc(mppi_planner* p) {
   HIP_TRY(hipEventCreate(&p->ev_begin));
   HIP_TRY(hipEventCreate(&p->ev_end));
   for (auto& e : p->ev_stage) HIP_TRY(hipEventCreate(&e));
-  TRY(dev_alloc(&p->noise, N * T));
+  const size_t n_tiled = (size_t)ceil_div((long)N, 64) * 64;  // tile-major arrays cover whole tiles
+  TRY(dev_alloc(&p->noise, n_tiled * T));
   TRY(dev_alloc(&p->staging, N * T));
   TRY(dev_alloc(&p->u, T));
   TRY(dev_alloc(&p->u_prev, T));
   TRY(dev_alloc(&p->costs, N));
-  TRY(dev_alloc(&p->weights, N));
   TRY(dev_alloc(&p->weights_out, N));
-  TRY(dev_alloc(&p->block_min, N));
-  TRY(dev_alloc(&p->den_part, (size_t)ceil_div((long)N, kUpdateThreads)));
-  // weighted-sum grid: (T, n_chunks) workgroups, a few thousand in total
-  int want = ceil_div(2048, (long)T);
-  int max_chunks = ceil_div((long)N, 1024);
-  int nch = want < 1 ? 1 : (want > max_chunks ? max_chunks : want);
-  p->chunk = ceil_div(ceil_div((long)N, nch), kUpdateThreads) * kUpdateThreads;
-  p->n_chunks = ceil_div((long)N, p->chunk);
-  TRY(dev_alloc(&p->partial, (size_t)p->n_chunks * T));
+  p->n_tiles = ceil_div((long)N, 64);
+  TRY(dev_alloc(&p->w_rel, N));
+  TRY(dev_alloc(&p->tile_beta, (size_t)p->n_tiles));
   TRY(dev_alloc(&p->packets, (size_t)c.world_size * packet_len((int)T)));
-  TRY(dev_alloc(&p->weight_scale, (size_t)1));
+  TRY(dev_alloc(&p->stats, (size_t)2));
   TRY(dev_alloc(&p->state_rollout, (size_t)c.num_vis_state_rollouts * (T + 1) * 3));
   HIP_TRY(hipMemsetAsync(p->u, 0, T * sizeof(float2), p->stream));  // u_seq0 = zeros (mppi.py:93)
   HIP_TRY(hipMemsetAsync(p->u_prev, 0, T * sizeof(float2), p->stream));
-  HIP_TRY(hipMemsetAsync(p->noise, 0, N * T * sizeof(float2), p->stream));
+  HIP_TRY(hipMemsetAsync(p->noise, 0, n_tiled * T * sizeof(float2), p->stream));
   HIP_TRY(hipMemsetAsync(p->costs, 0, N * sizeof(float), p->stream));
-  HIP_TRY(hipMemsetAsync(p->weights, 0, N * sizeof(float), p->stream));
-  double one = 1.0;
-  HIP_TRY(hipMemcpyAsync(p->weight_scale, &one, sizeof(double), hipMemcpyHostToDevice, p->stream));
+  const double initial_stats[2] = {0.0, 1.0};
+  HIP_TRY(hipMemcpyAsync(p->stats, initial_stats, sizeof(initial_stats), hipMemcpyHostToDevice, p->stream));
   if (c.rng == MPPI_RNG_XOROSHIRO) {
     // numba creates N*T states on the host, 2^64-jump apart (mppi.py:118); a
     // shard keeps the slice of the global stream array that it owns
@@ -643,6 +637,9 @@ extern "C" int mppi_planner_shift_u(mppi_planner* p, int k) {
   return MPPI_OK;
 }
 
+// largest traction byte that can be in the TDM's grid right now
+static int tdm_max_byte(const mppi_tdm* t) { return t->injected ? (int)t->injected_max : t->table_max; }
+
 // ---- helpers -------------------------------------------------------------------
 static int check_tdms(const mppi_planner* p, const mppi_tdm* lin, const mppi_tdm* ang) {
   if (p->cfg.mode == MPPI_MODE_BAREBONE) return MPPI_OK;
@@ -687,6 +684,8 @@ static DevParams make_dev_params(const mppi_planner* p, const mppi_tdm* lin, con
   d.v_post_den = (double)a.v_post_rollout + 1e-6;
   if (lin) { d.lin_lo = lin->lo; d.lin_ratio = lin->ratio; d.rows = lin->rows; d.cols = lin->cols; }
   if (ang) { d.ang_lo = ang->lo; d.ang_ratio = ang->ratio; }
+  d.lin_max_byte = lin ? tdm_max_byte(lin) : 0;
+  d.ang_max_byte = ang ? tdm_max_byte(ang) : 0;
   d.s0sq = (double)a.u_std[0] * (double)a.u_std[0];
   d.s1sq = (double)a.u_std[1] * (double)a.u_std[1];
   d.n_local = p->n_local;
@@ -750,7 +749,7 @@ static int ensure_packed(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang) {
 
 static int launch_noise(mppi_planner* p) {
   const int N = p->n_local, T = p->cfg.num_steps;
-  long total = (long)N * T;
+  long total = (long)ceil_div(N, 64) * 64 * T;  // one thread per element of the tile-major array
   if (p->cfg.rng == MPPI_RNG_PHILOX) {
     hipLaunchKernelGGL(k_noise_philox, dim3(ceil_div(total, 256)), dim3(256), 0, p->stream, p->noise, N,
                        p->n_offset, T, p->cfg.seed, p->noise_epoch, p->params.u_std[0], p->params.u_std[1]);
@@ -780,7 +779,7 @@ static bool plan_lds_window(const mppi_planner* p, DevParams& d, size_t* lds_byt
     return true;
   }
   double vmax = std::fmax(std::fabs((double)a.vrange[0]), std::fabs((double)a.vrange[1]));
-  double trmax = std::fmax(std::fabs(d.lin_lo), std::fabs(d.lin_lo + 127.0 * d.lin_ratio));
+  double trmax = std::fmax(std::fabs(d.lin_lo), std::fabs(d.lin_lo + (double)d.lin_max_byte * d.lin_ratio));
   double reach_m = (double)T * (double)a.dt * vmax * trmax;
   if (!std::isfinite(reach_m)) return false;
   long reach = (long)std::ceil(reach_m / (double)a.res) + 2;
@@ -804,9 +803,57 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
   const size_t lds_map = sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);  // + staged u[t]
   switch (p->cfg.mode) {
     case MPPI_MODE_DET: {
-      p->n_block_min = ceil_div(N, 64);  // one minimum per wave
+      p->tile_packets_fresh = false;
       size_t lds_win = 0;
-      if (plan_lds_window(p, d, &lds_win)) {
+      bool have_window = plan_lds_window(p, d, &lds_win);
+      if (have_window && EXACT && BOUNDED && d.win_cols == d.pitch16 && d.win_c0 == 0 &&
+          d.win_cols >= d.cols && d.win_r0 == 0 && d.win_rows == d.rows) {
+        // pipelined kernel: needs the whole map in LDS, a heading increment small enough for
+        // the incremental trig (|dt*w*traction| <= 0.36 rad) and a horizon short enough for it
+        const mppi_params& a = p->params;
+        double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
+        double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
+        double dmax = (double)a.dt * wmax * trmax;
+        const size_t map_bytes = lds_win - sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);
+        int pairs = ceil_div(ceil_div(N, 64), p->num_cus);  // wave triples per workgroup
+        if (pairs < 1) pairs = 1;
+        if (pairs > 5) pairs = 5;                            // 15 waves = 960 threads
+        const size_t budget = (size_t)p->lds_per_cu - 1024;
+        auto ring_bytes = [&](int chunk) { return (size_t)pairs * 4 * (size_t)chunk * 64 * sizeof(float2); };
+        int chunk = 0;
+        for (int cnd : {8, 4, 2})
+          if (lds_win + ring_bytes(cnd) <= budget) { chunk = cnd; break; }
+        if (std::isfinite(dmax) && dmax <= 0.36 && T <= 2000 && chunk > 0) {
+          const size_t lds_total = lds_win + ring_bytes(chunk);
+          const int block = 192 * pairs;
+          const int grid = ceil_div(N, 64 * pairs);
+          if (!p->cc_scratch) TRY(dev_alloc(&p->cc_scratch, (size_t)ceil_div(N, 64) * 64 * T));
+          int res_exp = 0;
+          const bool pow2res = std::frexp((double)a.res, &res_exp) == 0.5;  // res == 2^k exactly
+#define MPPI_LAUNCH_PIPE(CH, P2)                                                                      \
+  do {                                                                                                \
+    auto kern = k_rollout_pipe<CH, P2>;                                                               \
+    if (lds_total > 64 * 1024)                                                                        \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));       \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds_total, p->stream, d, p->cells16, p->noise,  \
+                       p->u, p->costs, p->w_rel, p->tile_beta, p->cc_scratch, (int)map_bytes);         \
+  } while (0)
+          if (pow2res) {
+            if (chunk == 8) MPPI_LAUNCH_PIPE(8, true);
+            else if (chunk == 4) MPPI_LAUNCH_PIPE(4, true);
+            else MPPI_LAUNCH_PIPE(2, true);
+          } else {
+            if (chunk == 8) MPPI_LAUNCH_PIPE(8, false);
+            else if (chunk == 4) MPPI_LAUNCH_PIPE(4, false);
+            else MPPI_LAUNCH_PIPE(2, false);
+          }
+#undef MPPI_LAUNCH_PIPE
+          p->tile_packets_fresh = true;
+          break;
+        }
+      }
+      if (have_window) {
         // the window makes it one workgroup per CU: size the workgroup so that the grid
         // is at most one wave of workgroups over the CUs
         // (at least 4 waves: one per SIMD, and four times the lanes to copy the window)
@@ -817,19 +864,19 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
           HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
         hipLaunchKernelGGL(kern, dim3(ceil_div(N, block)), dim3(block), lds_win, p->stream, d, p->cells,
-                           p->cells16, (const int8_t*)nullptr, p->noise, p->u, p->costs, p->block_min);
+                           p->cells16, (const int8_t*)nullptr, p->noise, p->u, p->costs);
       } else {
-        hipLaunchKernelGGL((k_rollout_map<MAP_DET, EXACT, BOUNDED, false>), dim3(p->n_block_min), dim3(64),
+        hipLaunchKernelGGL((k_rollout_map<MAP_DET, EXACT, BOUNDED, false>), dim3(ceil_div(N, 64)), dim3(64),
                            lds_map, p->stream, d, p->cells, (const uint16_t*)nullptr, (const int8_t*)nullptr,
-                           p->noise, p->u, p->costs, p->block_min);
+                           p->noise, p->u, p->costs);
       }
       break;
     }
     case MPPI_MODE_SPEED_MAP:
-      p->n_block_min = ceil_div(N, 64);
-      hipLaunchKernelGGL((k_rollout_map<MAP_SPEED, EXACT, BOUNDED, false>), dim3(p->n_block_min), dim3(64),
+      p->tile_packets_fresh = false;
+      hipLaunchKernelGGL((k_rollout_map<MAP_SPEED, EXACT, BOUNDED, false>), dim3(ceil_div(N, 64)), dim3(64),
                          lds_map, p->stream, d, p->cells, (const uint16_t*)nullptr, (const int8_t*)p->risk_ref,
-                         p->noise, p->u, p->costs, p->block_min);
+                         p->noise, p->u, p->costs);
       break;
     case MPPI_MODE_TDM: {
       int mp2 = next_pow2(M);
@@ -841,15 +888,15 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_tdm<EXACT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       if (p->want_sample_costs && !p->sample_costs) TRY(dev_alloc(&p->sample_costs, (size_t)N * M));
-      p->n_block_min = N;
+      p->tile_packets_fresh = false;
       hipLaunchKernelGGL((k_rollout_tdm<EXACT>), dim3(N), dim3(threads), lds, p->stream, d, p->cells, p->noise,
-                         p->u, p->costs, p->block_min, p->want_sample_costs ? p->sample_costs : nullptr, mp2);
+                         p->u, p->costs, p->want_sample_costs ? p->sample_costs : nullptr, mp2);
       break;
     }
     case MPPI_MODE_BAREBONE:
-      p->n_block_min = ceil_div(N, 64);
-      hipLaunchKernelGGL((k_rollout_barebone<EXACT>), dim3(p->n_block_min), dim3(64), lds, p->stream, d,
-                         p->obs_pos, p->obs_r, p->noise, p->u, p->costs, p->block_min);
+      p->tile_packets_fresh = false;
+      hipLaunchKernelGGL((k_rollout_barebone<EXACT>), dim3(ceil_div(N, 64)), dim3(64), lds, p->stream, d,
+                         p->obs_pos, p->obs_r, p->noise, p->u, p->costs);
       break;
     default:
       return fail(MPPI_ERR_INVALID, "bad mode");
@@ -865,7 +912,7 @@ static int launch_rollout(mppi_planner* p, const DevParams& d) {
   // inside the range of the two-term pi/2 reduction, the kernels drop the libm branch
   const mppi_params& a = p->params;
   double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
-  double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + 127.0 * d.ang_ratio));
+  double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
   if (p->cfg.mode == MPPI_MODE_BAREBONE) trmax = 1.0;
   double theta_bound = std::fabs((double)a.x0[2]) + (double)p->cfg.num_steps * (double)a.dt * wmax * trmax;
   bool bounded = std::isfinite(theta_bound) && theta_bound < 5.0e4;
@@ -873,25 +920,27 @@ static int launch_rollout(mppi_planner* p, const DevParams& d) {
   return bounded ? launch_rollout_t<true, true>(p, d) : launch_rollout_t<true, false>(p, d);
 }
 
-// weights + weighted sums + (single GPU) apply; with several GPUs the packet is
-// left in packets[rank] for the exchange
+// tile-relative weights (unless the rollout kernel just emitted them) + the row kernel:
+// applies the update on a single GPU; with several GPUs leaves this rank's packet in
+// packets[rank] for the exchange
 static int launch_update_local(mppi_planner* p, bool apply_here) {
   const int N = p->n_local, T = p->cfg.num_steps;
   const mppi_params& a = p->params;
   double* my_packet = p->packets + (size_t)p->cfg.rank * packet_len(T);
-  int n_den = ceil_div(N, kUpdateThreads);
-  hipLaunchKernelGGL(k_weights, dim3(n_den), dim3(kUpdateThreads), 0, p->stream, p->costs, N, p->block_min,
-                     p->n_block_min, a.lambda_weight, p->weights, p->den_part, my_packet);
-  hipLaunchKernelGGL(k_wsum, dim3(T, p->n_chunks), dim3(kUpdateThreads), 0, p->stream, p->weights, p->noise, N,
-                     p->chunk, p->partial);
+  if (!p->tile_packets_fresh)
+    hipLaunchKernelGGL(k_tile_weights, dim3(p->n_tiles), dim3(64), 0, p->stream, p->costs, N, a.lambda_weight,
+                       p->w_rel, p->tile_beta);
+  p->tile_packets_fresh = false;
+  const size_t lds = sizeof(float) * (size_t)p->n_tiles;
+  REQUIRE(lds <= 60 * 1024, MPPI_ERR_INVALID, "too many rollouts per GPU for the update kernel (%d)", N);
   if (apply_here)
-    hipLaunchKernelGGL(k_finish<true>, dim3(1), dim3(kUpdateThreads), 0, p->stream, p->partial, p->n_chunks,
-                       p->den_part, n_den, T, my_packet, p->u, p->u_prev, a.vrange[0], a.vrange[1], a.wrange[0],
-                       a.wrange[1], p->weight_scale);
+    hipLaunchKernelGGL(k_update_rows<true>, dim3(T), dim3(kRowThreads), lds, p->stream, p->w_rel, p->tile_beta, N,
+                       p->n_tiles, p->noise, T, a.lambda_weight, my_packet, p->u, p->u_prev, a.vrange[0],
+                       a.vrange[1], a.wrange[0], a.wrange[1], p->stats);
   else
-    hipLaunchKernelGGL(k_finish<false>, dim3(1), dim3(kUpdateThreads), 0, p->stream, p->partial, p->n_chunks,
-                       p->den_part, n_den, T, my_packet, p->u, p->u_prev, a.vrange[0], a.vrange[1], a.wrange[0],
-                       a.wrange[1], p->weight_scale);
+    hipLaunchKernelGGL(k_update_rows<false>, dim3(T), dim3(kRowThreads), lds, p->stream, p->w_rel, p->tile_beta, N,
+                       p->n_tiles, p->noise, T, a.lambda_weight, my_packet, p->u, p->u_prev, a.vrange[0],
+                       a.vrange[1], a.wrange[0], a.wrange[1], p->stats);
   HIP_TRY(hipGetLastError());
   return MPPI_OK;
 }
@@ -900,7 +949,7 @@ static int launch_apply(mppi_planner* p) {
   const mppi_params& a = p->params;
   hipLaunchKernelGGL(k_apply, dim3(1), dim3(kUpdateThreads), 0, p->stream, p->packets, p->cfg.world_size,
                      p->cfg.rank, p->cfg.num_steps, a.lambda_weight, p->u, p->u_prev, a.vrange[0], a.vrange[1],
-                     a.wrange[0], a.wrange[1], p->weight_scale);
+                     a.wrange[0], a.wrange[1], p->stats);
   HIP_TRY(hipGetLastError());
   return MPPI_OK;
 }
@@ -925,14 +974,6 @@ static int launch_update(mppi_planner* p, bool prof) {
                             p->stream));
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[4], p->stream));
   return launch_apply(p);
-}
-
-static int rebuild_block_min(mppi_planner* p) {
-  p->n_block_min = ceil_div(p->n_local, kUpdateThreads);
-  hipLaunchKernelGGL(k_block_min_from_costs, dim3(p->n_block_min), dim3(kUpdateThreads), 0, p->stream, p->costs,
-                     p->n_local, p->block_min);
-  HIP_TRY(hipGetLastError());
-  return MPPI_OK;
 }
 
 static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int iterations) {
@@ -1060,7 +1101,7 @@ extern "C" int mppi_planner_set_costs(mppi_planner* p, const float* costs) {
   REQUIRE(p && costs, MPPI_ERR_INVALID, "NULL argument");
   HIP_TRY(hipSetDevice(p->cfg.device));
   HIP_TRY(hipMemcpyAsync(p->costs, costs, sizeof(float) * (size_t)p->n_local, hipMemcpyHostToDevice, p->stream));
-  TRY(rebuild_block_min(p));
+  p->tile_packets_fresh = false;
   HIP_TRY(hipStreamSynchronize(p->stream));
   return MPPI_OK;
 }
@@ -1085,7 +1126,6 @@ extern "C" int mppi_planner_update(mppi_planner* p) {
   REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
   REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
   HIP_TRY(hipSetDevice(p->cfg.device));
-  if (p->n_block_min == 0) TRY(rebuild_block_min(p));
   TRY(launch_update(p, false));
   HIP_TRY(hipStreamSynchronize(p->stream));
   return MPPI_OK;
@@ -1101,7 +1141,6 @@ extern "C" int mppi_planner_update_local(mppi_planner* p, double* packet) {
   REQUIRE(p && packet, MPPI_ERR_INVALID, "NULL argument");
   REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
   HIP_TRY(hipSetDevice(p->cfg.device));
-  if (p->n_block_min == 0) TRY(rebuild_block_min(p));
   TRY(launch_update_local(p, false));
   const int len = packet_len(p->cfg.num_steps);
   HIP_TRY(hipMemcpyAsync(packet, p->packets + (size_t)p->cfg.rank * len, sizeof(double) * (size_t)len,
@@ -1125,8 +1164,8 @@ extern "C" int mppi_planner_update_apply(mppi_planner* p, const double* packets,
 extern "C" int mppi_planner_get_weights(mppi_planner* p, float* weights) {
   REQUIRE(p && weights, MPPI_ERR_INVALID, "NULL argument");
   HIP_TRY(hipSetDevice(p->cfg.device));
-  hipLaunchKernelGGL(k_scale_weights, dim3(ceil_div(p->n_local, 256)), dim3(256), 0, p->stream, p->weights,
-                     p->weight_scale, p->n_local, p->weights_out);
+  hipLaunchKernelGGL(k_weights_out, dim3(ceil_div(p->n_local, 256)), dim3(256), 0, p->stream, p->costs, p->stats,
+                     p->params.lambda_weight, p->n_local, p->weights_out);
   HIP_TRY(hipGetLastError());
   return copy_out(p, weights, p->weights_out, sizeof(float) * (size_t)p->n_local);
 }

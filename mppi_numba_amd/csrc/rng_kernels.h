@@ -18,6 +18,8 @@
 #include <rocrand/rocrand_kernel.h>
 #include <stdint.h>
 
+#include "device_math.h"
+
 namespace mppi {
 
 // ---------------- xoroshiro128+ (numba/cuda/random.py:45-139) ----------------
@@ -76,13 +78,16 @@ inline void xoroshiro_init_host(uint64_t* states, long n, uint64_t seed) {
 }
 
 // ---------------- control noise ----------------
-// noise[t][n] = u_std * N(0,1); Philox subsequence = global (n, t), offset = epoch
+// noise(t, n) = u_std * N(0,1), tile-major; Philox subsequence = global (n, t), offset = epoch
 __global__ __launch_bounds__(256) void k_noise_philox(float2* __restrict__ noise, int n_local, int n_offset,
                                                       int n_steps, uint64_t seed, uint64_t epoch, float std0,
                                                       float std1) {
+  // thread i <-> element i of the tile-major array: (tile, t, lane)
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (size_t)n_local * n_steps) return;
-  int t = (int)(i / n_local), n = (int)(i % n_local);
+  int lane = (int)(i & 63);
+  size_t row = i >> 6;
+  int t = (int)(row % n_steps), n = (int)(row / n_steps) * 64 + lane;
+  if (n >= n_local) return;
   uint64_t key = (uint64_t)(n_offset + n) * (uint64_t)n_steps + (uint64_t)t;
   rocrand_state_philox4x32_10 st;
   rocrand_init(seed, key, 4ULL * epoch, &st);
@@ -94,8 +99,10 @@ __global__ __launch_bounds__(256) void k_noise_philox(float2* __restrict__ noise
 __global__ __launch_bounds__(256) void k_noise_xoroshiro(float2* __restrict__ noise, uint64_t* __restrict__ states,
                                                          int n_local, int n_steps, float std0, float std1) {
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (size_t)n_local * n_steps) return;
-  int t = (int)(i / n_local), n = (int)(i % n_local);
+  int lane = (int)(i & 63);
+  size_t row = i >> 6;
+  int t = (int)(row % n_steps), n = (int)(row / n_steps) * 64 + lane;
+  if (n >= n_local) return;
   size_t k = (size_t)n * n_steps + t;
   uint64_t s0 = states[2 * k], s1 = states[2 * k + 1];
   double z0 = xoroshiro_normal(s0, s1);

@@ -8,9 +8,11 @@
 //   get_state_rollout_* kernels        mppi.py:1194-1351  -> k_state_rollout_*
 //
 // Device data layout (private to the library):
-//   noise  [T][N] float2      step-major: lane n of a wave reads 8 contiguous
-//                             bytes next to its neighbours at every step, and
-//                             the weighted sum over n of the update streams it
+//   noise  [N/64][T][64] float2   tile-major (device_math.h tile_index): lane n of a
+//                             wave reads 8 contiguous bytes next to its neighbours
+//                             at every step, consecutive steps are adjacent
+//                             512-byte rows, and the weighted sum over n of the
+//                             update still streams 64-element runs
 //   cells  [Rp*Cp] uint32     one word per map cell: lin | ang<<8 | obs<<16 |
 //                             unk<<24 (int8 each) -> ONE gather per step
 //   cellsM [Rp*Cp][M] uint32  the same per traction sample, sample index
@@ -24,6 +26,7 @@
 // register and is written once (the reference does three global RMWs per step).
 #pragma once
 #include "device_math.h"
+#include "update_kernels.h"
 
 namespace mppi {
 
@@ -51,6 +54,7 @@ struct DevParams {
   int win_r0, win_c0;      // first row / column of the window (column multiple of 8)
   int win_rows, win_cols;  // window size; win_cols is a multiple of 8
   int pitch16;             // row pitch of the global 16-bit cell array (multiple of 8)
+  int lin_max_byte, ang_max_byte;  // host-side bounds only (largest traction byte in the grids)
 };
 
 // u[t]/std^2 (float64) for the control-cost term, staged in LDS once per block
@@ -183,12 +187,31 @@ __device__ __forceinline__ void map_step(const DevParams& P, const uint32_t* __r
   st.done = st.done || hit;
 }
 
+__device__ __forceinline__ void copy_window_to_lds(const DevParams& P, const uint16_t* __restrict__ cells16,
+                                                   uint16_t* lds_map) {
+  // full-width window (host-checked): one contiguous run of 16-byte vectors; whole
+  // batches of eight unconditional loads per lane, then the remainder
+  const int total = P.win_rows * (P.win_cols / 8);
+  const uint4* src = reinterpret_cast<const uint4*>(cells16) + ((size_t)P.win_r0 * P.pitch16 + P.win_c0) / 8;
+  uint4* dst = reinterpret_cast<uint4*>(lds_map);
+  const int step = 8 * (int)blockDim.x;
+  const int full = total / step * step;
+  for (int i0 = threadIdx.x; i0 < full; i0 += step) {
+    uint4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = src[i0 + k * (int)blockDim.x];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[i0 + k * (int)blockDim.x] = v[k];
+  }
+  for (int i = full + threadIdx.x; i < total; i += blockDim.x) dst[i] = src[i];
+}
+
 // LDS: [T] double2 control ratios | [T] float2 u | (LDSMAP) window of 16-bit cells
 template <int KIND, bool EXACT, bool BOUNDED, bool LDSMAP>
 __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
                               const uint16_t* __restrict__ cells16, const int8_t* __restrict__ risk,
                               const float2* __restrict__ noise, const float2* __restrict__ u,
-                              float* __restrict__ costs, float* __restrict__ block_min) {
+                              float* __restrict__ costs) {
   extern __shared__ double2 uos[];
   float2* us = reinterpret_cast<float2*>(uos + P.n_steps);  // u[t] staged next to the ratios
   // 16-byte aligned start of the map window
@@ -203,17 +226,7 @@ __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
     const size_t base = ((size_t)P.win_r0 * P.pitch16 + P.win_c0) / 8;
     const int src_pitch = P.pitch16 / 8;
     if (P.win_cols == P.pitch16) {
-      // full-width window: one contiguous run
-      for (int i0 = threadIdx.x; i0 < total; i0 += 8 * blockDim.x) {
-        uint4 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = src[base + min(i0 + k * (int)blockDim.x, total - 1)];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          int i = i0 + k * (int)blockDim.x;
-          if (i < total) dst[i] = v[k];
-        }
-      }
+      copy_window_to_lds(P, cells16, lds_map);
     } else {
       // one wave per row, lanes along the row
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
@@ -228,17 +241,17 @@ __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
   const bool live = n < P.n_local;
   const int nn = live ? n : P.n_local - 1;
   const int N = P.n_local, T = P.n_steps;
-  const float2* col = noise + nn;  // this lane's column of the [T][N] noise
+  const float2* col = noise + tile_index(0, nn, T);  // this lane's column; rows are 64 apart
 
   RolloutState st = {P.x0, P.y0, P.th0, 0.0f, 1e9, false, false};
   float2 e_cur[kNoiseBatch], e_nxt[kNoiseBatch];
   // rows past the horizon are clamped to the last row: every load is unconditional
 #pragma unroll
-  for (int j = 0; j < kNoiseBatch; ++j) e_cur[j] = col[(size_t)min(j, T - 1) * N];
+  for (int j = 0; j < kNoiseBatch; ++j) e_cur[j] = col[(size_t)min(j, T - 1) * 64];
   int t0 = 0;
   for (; t0 + kNoiseBatch <= T; t0 += kNoiseBatch) {
 #pragma unroll
-    for (int j = 0; j < kNoiseBatch; ++j) e_nxt[j] = col[(size_t)min(t0 + kNoiseBatch + j, T - 1) * N];
+    for (int j = 0; j < kNoiseBatch; ++j) e_nxt[j] = col[(size_t)min(t0 + kNoiseBatch + j, T - 1) * 64];
 #pragma unroll
     for (int j = 0; j < kNoiseBatch; ++j)
       map_step<KIND, EXACT, BOUNDED, LDSMAP>(P, cells, risk, lds_map, us[t0 + j], e_cur[j], st);
@@ -259,18 +272,228 @@ __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
   for (t0 = 0; t0 + kNoiseBatch <= T; t0 += kNoiseBatch) {
     double cc[kNoiseBatch];
 #pragma unroll
-    for (int j = 0; j < kNoiseBatch; ++j) cc[j] = control_cost(P, uos[t0 + j], col[(size_t)(t0 + j) * N]);
+    for (int j = 0; j < kNoiseBatch; ++j) cc[j] = control_cost(P, uos[t0 + j], col[(size_t)(t0 + j) * 64]);
 #pragma unroll
     for (int j = 0; j < kNoiseBatch; ++j) cost = EXACT ? (float)((double)cost + cc[j]) : cost + (float)cc[j];
   }
   for (int t = t0; t < T; ++t) {
-    double c1 = control_cost(P, uos[t], col[(size_t)t * N]);
+    double c1 = control_cost(P, uos[t], col[(size_t)t * 64]);
     cost = EXACT ? (float)((double)cost + c1) : cost + (float)c1;
   }
   if (live) costs[n] = cost;
-  // one minimum per wave (the update kernel reduces them): slot = global wave index
-  float m = wave_min_f32(live ? cost : __builtin_inff());
-  if ((threadIdx.x & 63) == 0) block_min[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = m;
+}
+
+// -------------------------------------------------------------------------
+// Pipelined deterministic rollout (MPPI_MODE_DET, exact math, LDS map).
+//
+// At N = 8192 a GPU has 8x more SIMDs than there are waves, and a lone wave
+// issues one float64 instruction per ~5.4 cycles (one float32 per ~2.9): the fused
+// kernel above is bound by its ~190 instructions per step, not by memory.  Here
+// two waves cooperate on every 64 rollouts and only the unavoidable chain stays
+// on the critical wave:
+//   state wave  cell lookup in the LDS map, traction, float64 state update,
+//               rotation of (cos, sin) by the exact heading increment; reads the
+//               clipped controls from a ring and publishes x, y (float32);
+//   cost wave   streams the noise: clipped controls for the NEXT chunk, control-
+//               cost products (to a scratch array for the final accumulation);
+//               one chunk BEHIND the state wave: obstacle / unknown bits of the
+//               visited cell, distance, sqrt, stage cost, goal test, the
+//               float32-rounded accumulation; then terminal and control costs.
+// They meet at one workgroup barrier per chunk of C steps (double-buffered rings).
+// Every rollout sees the same operations with the same rounding points as in
+// k_rollout_map; only the trig is evaluated incrementally.
+// LDS: [T] double2 ratios | [T] float2 u | map window | per pair:
+//      xy[2][C][64] float2, vw[2][C][64] float2.
+// -------------------------------------------------------------------------
+template <int C>
+struct PipeRing {
+  static constexpr int kHalf = C * 64;                                  // entries per buffer
+  static constexpr int kBytesPerPair = 4 * kHalf * (int)sizeof(float2);  // xy[2] + vw[2]
+};
+
+// Roles of the waves of one workgroup (W = blockDim / 192 triples, triple i = waves
+// i, W+i, 2W+i):  producer -> state -> cost, each one chunk behind the previous.
+//   producer  streams the noise: clipped controls of chunk k+1 into ring_vw,
+//             control-cost products into cc_scratch (global, tile-major);
+//   state     integrates chunk k from ring_vw into ring_xy;
+//   cost      costs chunk k-1 from ring_xy; afterwards terminal + control costs.
+// Tile-major arrays: element (t, n) of noise / cc_scratch lives at
+// ((n / 64) * T + t) * 64 + n % 64, i.e. the T x 64 block of one wave is contiguous.
+template <int C, bool POW2RES>
+__global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16,
+                               const float2* __restrict__ noise, const float2* __restrict__ u,
+                               float* __restrict__ costs, float* __restrict__ w_rel,
+                               float* __restrict__ tile_beta, double* __restrict__ cc_scratch, int map_bytes) {
+  extern __shared__ double2 uos[];
+  const int T = P.n_steps, N = P.n_local;
+  float2* us = reinterpret_cast<float2*>(uos + T);
+  uint16_t* lds_map = reinterpret_cast<uint16_t*>(uos + T + (T + 1) / 2);
+  char* ring_base = reinterpret_cast<char*>(lds_map) + map_bytes;
+  const int W = blockDim.x / 192;  // triples per workgroup
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int role = wave / W;  // 0 state, 1 cost, 2 producer
+  const int triple = wave - role * W;
+  using Ring = PipeRing<C>;
+  float2* ring_xy = reinterpret_cast<float2*>(ring_base + (size_t)triple * Ring::kBytesPerPair);
+  float2* ring_vw = ring_xy + 2 * Ring::kHalf;
+
+  copy_window_to_lds(P, cells16, lds_map);
+  for (int t = threadIdx.x; t < T; t += blockDim.x) us[t] = u[t];
+  stage_control_ratios(P, u, uos);  // ends with a barrier
+
+  const int tile = blockIdx.x * W + triple;  // 64 consecutive rollouts
+  const int n = tile * 64 + lane;
+  const bool live = n < N;
+  const size_t tile_base = (size_t)tile * T * 64 + lane;  // + t*64: element (t, n)
+  const int K = (T + C - 1) / C;
+  // barrier schedule (identical for the three roles): one after the producer's
+  // chunk 0, then one per k = 0..K
+
+  if (role == 0) {
+    float x = P.x0, y = P.y0, th = P.th0;
+    double x64 = (double)x, y64 = (double)y, th64 = (double)th;
+    double s, c;
+    sincos_f64<false>(th64, s, c);
+    const double dt64 = (double)P.dt;
+    __syncthreads();  // controls of chunk 0 are in the ring
+    for (int k = 0; k <= K; ++k) {
+      if (k < K) {
+        const float2* in_vw = ring_vw + (size_t)(k & 1) * Ring::kHalf;
+        float2* out_xy = ring_xy + (size_t)(k & 1) * Ring::kHalf;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+          float2 vw = in_vw[j * 64 + lane];
+          int xi, yi;
+          if (POW2RES) {  // res is a power of two: the float32 quotient is exact
+            xi = (int)floorf((x - P.xlo) * P.inv_res);
+            yi = (int)floorf((y - P.ylo) * P.inv_res);
+          } else {
+            xi = floordiv_to_int(x - P.xlo, P.res, P.inv_res);
+            yi = floordiv_to_int(y - P.ylo, P.res, P.inv_res);
+          }
+          xi = clamp_index(xi, P.cols);
+          yi = clamp_index(yi, P.rows);
+          uint32_t c16 = lds_map[yi * P.win_cols + xi];
+          double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), P.lin_lo);
+          double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), P.ang_lo);
+          double q = dt64 * (double)vw.x;  // exact: two float32 factors
+          x = (float)fma(vtr, q * c, x64);
+          y = (float)fma(vtr, q * s, y64);
+          th = (float)fma(wtr, dt64 * (double)vw.y, th64);
+          x64 = (double)x;
+          y64 = (double)y;
+          double th_new = (double)th;
+          rotate_sincos_f64(th_new - th64, s, c);  // exact increment of the ROUNDED heading
+          th64 = th_new;
+          out_xy[j * 64 + lane] = make_float2(x, y);
+        }
+      }
+      __syncthreads();
+    }
+  } else if (role == 2) {
+    // the tile past N (if any) reads the last valid tile's noise and writes nothing
+    const bool tile_ok = tile * 64 < N;
+    const float2* col = noise + (tile_ok ? tile_base : (size_t)0);
+    double* my_cc = cc_scratch + tile_base;
+    float2 e_cur[C], e_nxt[C];
+    auto produce = [&](int chunk, const float2 (&e)[C]) {
+      float2* out_vw = ring_vw + (size_t)(chunk & 1) * Ring::kHalf;
+#pragma unroll
+      for (int j = 0; j < C; ++j) {
+        int t = min(chunk * C + j, T - 1);  // steps past the horizon are produced and ignored
+        float2 ut = us[t];
+        out_vw[j * 64 + lane] = make_float2(clip_f32(ut.x + e[j].x, P.v_lo, P.v_hi),
+                                            clip_f32(ut.y + e[j].y, P.w_lo, P.w_hi));
+        if (tile_ok && chunk * C + j < T) my_cc[(size_t)t * 64] = control_cost(P, uos[t], e[j]);
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < C; ++j) e_cur[j] = col[(size_t)min(j, T - 1) * 64];
+#pragma unroll
+    for (int j = 0; j < C; ++j) e_nxt[j] = col[(size_t)min(C + j, T - 1) * 64];
+    produce(0, e_cur);
+    __syncthreads();
+    for (int k = 0; k <= K; ++k) {
+#pragma unroll
+      for (int j = 0; j < C; ++j) e_cur[j] = e_nxt[j];
+#pragma unroll
+      for (int j = 0; j < C; ++j) e_nxt[j] = col[(size_t)min((k + 2) * C + j, T - 1) * 64];
+      if (k + 1 < K) produce(k + 1, e_cur);
+      __syncthreads();
+    }
+  } else {
+    const double dt64 = (double)P.dt, gt2 = (double)P.gt2;
+    float cost = 0.0f;
+    double d2 = 1e9;
+    bool done = false, reached = false;
+    float px = P.x0, py = P.y0;  // position BEFORE the step being costed
+    __syncthreads();
+    for (int k = 0; k <= K; ++k) {
+      if (k >= 1) {
+        const int t0 = (k - 1) * C;
+        const float2* in_xy = ring_xy + (size_t)((k - 1) & 1) * Ring::kHalf;
+        const int count = min(C, T - t0);
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+          if (j < count) {
+            float2 xy = in_xy[j * 64 + lane];
+            // obstacle / unknown bits of the cell the step STARTED in (mppi.py:971-998)
+            int xi, yi;
+            if (POW2RES) {
+              xi = (int)floorf((px - P.xlo) * P.inv_res);
+              yi = (int)floorf((py - P.ylo) * P.inv_res);
+            } else {
+              xi = floordiv_to_int(px - P.xlo, P.res, P.inv_res);
+              yi = floordiv_to_int(py - P.ylo, P.res, P.inv_res);
+            }
+            uint32_t c16 = lds_map[clamp_index(yi, P.rows) * P.win_cols + clamp_index(xi, P.cols)];
+            double dx = (double)(P.xg - xy.x), dy = (double)(P.yg - xy.y);
+            double nd2 = fma(dx, dx, dy * dy);
+            float c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(nd2), dt64));
+            c1 = c1 + ((c16 & 0x4000u) ? P.obs_cost : 0.0f);
+            c1 = c1 + ((c16 & 0x8000u) ? P.unk_cost : 0.0f);
+            bool hit = nd2 <= gt2;
+            bool act = !done;
+            cost = act ? c1 : cost;
+            d2 = act ? nd2 : d2;
+            reached = reached || (act && hit);
+            done = done || hit;
+            px = xy.x;
+            py = xy.y;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // terminal cost, then the control cost of all T steps (mppi.py:1005-1009); the
+    // products were written by the producer wave of this workgroup before its last barrier
+    double term = (reached ? 0.0 : 1.0) * sqrt(d2) / P.v_post_den;
+    cost = (float)((double)cost + term);
+    // the products come back from L2/HBM with a long latency (they were written by
+    // another wave moments ago): two batches of 24 loads are kept in flight
+    const double* my_cc = cc_scratch + (live ? tile_base : (size_t)lane);
+    constexpr int kTailBatch = 24;
+    double ca[kTailBatch], cb[kTailBatch];
+#pragma unroll
+    for (int j = 0; j < kTailBatch; ++j) ca[j] = my_cc[(size_t)min(j, T - 1) * 64];
+    for (int t0 = 0; t0 < T; t0 += kTailBatch) {
+#pragma unroll
+      for (int j = 0; j < kTailBatch; ++j) cb[j] = my_cc[(size_t)min(t0 + kTailBatch + j, T - 1) * 64];
+      if (t0 + kTailBatch <= T) {
+#pragma unroll
+        for (int j = 0; j < kTailBatch; ++j) cost = (float)((double)cost + ca[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < kTailBatch; ++j)
+          if (t0 + j < T) cost = (float)((double)cost + ca[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < kTailBatch; ++j) ca[j] = cb[j];
+    }
+    if (live) costs[n] = cost;
+    // first half of the control update (update_kernels.h): weights relative to the tile's minimum
+    if (tile * 64 < N) emit_tile_weights(cost, live, P.lambda, n, tile, w_rel, tile_beta);
+  }
 }
 
 // -------------------------------------------------------------------------
@@ -287,8 +510,7 @@ __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
 template <bool EXACT>
 __global__ void k_rollout_tdm(DevParams P, const uint32_t* __restrict__ cellsM,
                               const float2* __restrict__ noise, const float2* __restrict__ u,
-                              float* __restrict__ costs, float* __restrict__ block_min,
-                              float* __restrict__ sample_costs, int m_pow2) {
+                              float* __restrict__ costs, float* __restrict__ sample_costs, int m_pow2) {
   extern __shared__ double2 uos[];
   float* sc = reinterpret_cast<float*>(uos + P.n_steps);
   stage_control_ratios(P, u, uos);
@@ -305,7 +527,7 @@ __global__ void k_rollout_tdm(DevParams P, const uint32_t* __restrict__ cellsM,
     double d2 = 1e9;
     bool reached = false;
     for (int t = 0; t < T; ++t) {
-      float2 e = noise[(size_t)t * N + n];
+      float2 e = noise[tile_index(t, n, T)];
       float2 ut = u[t];
       int xi = clamp_index(floordiv_to_int(x - P.xlo, P.res, P.inv_res), P.cols);
       int yi = clamp_index(floordiv_to_int(y - P.ylo, P.res, P.inv_res), P.rows);
@@ -321,7 +543,7 @@ __global__ void k_rollout_tdm(DevParams P, const uint32_t* __restrict__ cellsM,
       if (o.d2 <= (double)P.gt2) { reached = true; break; }
     }
     for (int t = 0; t < T; ++t) {
-      double cc = control_cost(P, uos[t], noise[(size_t)t * N + n]);
+      double cc = control_cost(P, uos[t], noise[tile_index(t, n, T)]);
       cost = EXACT ? (float)((double)cost + cc) : cost + (float)cc;
     }
     double term = (reached ? 0.0 : 1.0) * sqrt(d2) / P.v_post_den;
@@ -355,9 +577,7 @@ __global__ void k_rollout_tdm(DevParams P, const uint32_t* __restrict__ cellsM,
   }
   if (threadIdx.x == 0) {
     // shared[0]/numel: float32 / int -> float64 -> float32 store (mppi.py:755)
-    float c = (float)((double)sc[0] / (double)numel);
-    costs[n] = c;
-    block_min[n] = c;
+    costs[n] = (float)((double)sc[0] / (double)numel);
   }
 }
 
@@ -370,8 +590,7 @@ __global__ __launch_bounds__(64) void k_rollout_barebone(DevParams P, const floa
                                                          const float* __restrict__ obs_r,
                                                          const float2* __restrict__ noise,
                                                          const float2* __restrict__ u,
-                                                         float* __restrict__ costs,
-                                                         float* __restrict__ block_min) {
+                                                         float* __restrict__ costs) {
   extern __shared__ double2 uos[];
   stage_control_ratios(P, u, uos);
   const int n = blockIdx.x * 64 + threadIdx.x;
@@ -383,7 +602,7 @@ __global__ __launch_bounds__(64) void k_rollout_barebone(DevParams P, const floa
   double d2 = 1e9;
   bool done = false, reached = false;
   for (int t = 0; t < T; ++t) {
-    float2 e = noise[(size_t)t * N + nn];
+    float2 e = noise[tile_index(t, nn, T)];
     float2 ut = u[t];
     float v = clip_f32(ut.x + e.x, P.v_lo, P.v_hi);
     float w = clip_f32(ut.y + e.y, P.w_lo, P.w_hi);
@@ -421,12 +640,10 @@ __global__ __launch_bounds__(64) void k_rollout_barebone(DevParams P, const floa
   }
   cost = (float)((double)cost + (reached ? 0.0 : 1.0) * d2);
   for (int t = 0; t < T; ++t) {
-    double cc = control_cost(P, uos[t], noise[(size_t)t * N + nn]);
+    double cc = control_cost(P, uos[t], noise[tile_index(t, nn, T)]);
     cost = (float)((double)cost + cc);
   }
   if (live) costs[n] = cost;
-  float m = wave_min_f32(live ? cost : __builtin_inff());
-  if (threadIdx.x == 0) block_min[blockIdx.x] = m;
 }
 
 // -------------------------------------------------------------------------
@@ -454,7 +671,7 @@ __global__ void k_state_rollout(DevParams P, const uint32_t* __restrict__ cells,
       v = u_cur[t].x;
       w = u_cur[t].y;
     } else {
-      float2 e = noise[(size_t)t * N + b];
+      float2 e = noise[tile_index(t, b, T)];
       v = clip_f32(u_prev[t].x + e.x, P.v_lo, P.v_hi);
       w = clip_f32(u_prev[t].y + e.y, P.w_lo, P.w_hi);
     }

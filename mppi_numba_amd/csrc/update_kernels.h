@@ -2,12 +2,12 @@
 //
 // Replaces update_useq_numba[1, 32] (mppi.py:1113-1191): one 32-thread block
 // doing N*T*2 float32 atomics.  Here:
-//   k_weights   grid N/256   beta = min cost, w_n = exp(-(c_n-beta)/lambda),
-//                            per-block partial sums of w (float64)
-//   k_wsum      grid (T,NCH) partial[ch][t] = sum_{n in chunk} w_n * eps[t][n]
-//                            (float64 accumulation, wave-shuffle reductions)
-//   k_finish    grid 1       fixed-order sums -> packet {beta, den, num[T][2]}
-//   k_apply     grid 1       combine the packets of all GPUs, u += num/den, clip
+//   tile weights    w_rel[n] = exp(-(c_n - beta_tile)/lambda) per tile of 64 rollouts, emitted
+//                   by the pipelined rollout kernel's epilogue (k_tile_weights otherwise)
+//   k_update_rows   grid T, independent workgroups: rescale by exp(-(beta_tile-beta)/lambda),
+//                   den and num[t] in float64; applies the update (one GPU) or writes the
+//                   rank packet {beta, den, num[T][2]} for the all-gather (several)
+//   k_apply         grid 1: combine the packets of all GPUs, u += num/den, clip
 // Everything is a deterministic tree (no atomics): the same inputs give the
 // same bits on every run, and the result does not depend on the GPU count
 // beyond float64 rounding of the partial sums.
@@ -39,86 +39,6 @@ __global__ __launch_bounds__(kUpdateThreads) void k_block_min_from_costs(const f
   }
 }
 
-// weights[n] = float32(exp(-1/lambda * float32(c_n - beta)))      (mppi.py:1152-1154)
-// den_part[b] = sum over the block's weights (float64)
-__global__ __launch_bounds__(kUpdateThreads) void k_weights(const float* __restrict__ costs, int n,
-                                                            const float* __restrict__ block_min, int n_min,
-                                                            float lambda, float* __restrict__ weights,
-                                                            double* __restrict__ den_part,
-                                                            double* __restrict__ packet) {
-  __shared__ float redf[kUpdateThreads / 64];
-  __shared__ double redd[kUpdateThreads / 64];
-  float m = __builtin_inff();
-  for (int i = threadIdx.x; i < n_min; i += kUpdateThreads) m = fminf(m, block_min[i]);
-  m = wave_min_f32(m);
-  if ((threadIdx.x & 63) == 0) redf[threadIdx.x >> 6] = m;
-  __syncthreads();
-  float beta = redf[0];
-  for (int k = 1; k < kUpdateThreads / 64; ++k) beta = fminf(beta, redf[k]);
-
-  int i = blockIdx.x * kUpdateThreads + threadIdx.x;
-  float w = 0.0f;
-  if (i < n) {
-    double neg_inv_lambda = -1.0 / (double)lambda;
-    w = (float)exp(neg_inv_lambda * (double)(costs[i] - beta));
-    weights[i] = w;
-  }
-  double s = wave_sum_f64((double)w);
-  if ((threadIdx.x & 63) == 0) redd[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double tot = redd[0];
-    for (int k = 1; k < kUpdateThreads / 64; ++k) tot += redd[k];
-    den_part[blockIdx.x] = tot;
-    if (blockIdx.x == 0) packet[0] = (double)beta;
-  }
-}
-
-// partial[ch][t] = sum_{n in chunk ch} w_n * eps[t][n]  (noise is [T][N] float2:
-// the block streams 8-byte elements, coalesced)
-__global__ __launch_bounds__(kUpdateThreads) void k_wsum(const float* __restrict__ weights,
-                                                         const float2* __restrict__ noise, int n, int chunk,
-                                                         double2* __restrict__ partial) {
-  __shared__ double2 red[kUpdateThreads / 64];
-  const int t = blockIdx.x, ch = blockIdx.y;
-  const int lo = ch * chunk;
-  const int hi = min(lo + chunk, n);
-  const float2* row = noise + (size_t)t * n;
-  double ax = 0.0, ay = 0.0;
-  for (int i = lo + threadIdx.x; i < hi; i += kUpdateThreads) {
-    double w = (double)weights[i];
-    float2 e = row[i];
-    ax = fma(w, (double)e.x, ax);
-    ay = fma(w, (double)e.y, ay);
-  }
-  ax = wave_sum_f64(ax);
-  ay = wave_sum_f64(ay);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = make_double2(ax, ay);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double2 tot = red[0];
-    for (int k = 1; k < kUpdateThreads / 64; ++k) {
-      tot.x += red[k].x;
-      tot.y += red[k].y;
-    }
-    partial[(size_t)ch * gridDim.x + t] = tot;
-  }
-}
-
-__device__ __forceinline__ double block_sum_fixed_order(const double* __restrict__ v, int count, double* red) {
-  // each thread sums a strided subset sequentially, then a fixed 64-lane
-  // butterfly and a fixed 4-way sum: deterministic
-  double s = 0.0;
-  for (int i = threadIdx.x; i < count; i += kUpdateThreads) s += v[i];
-  s = wave_sum_f64(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  double tot = red[0];
-  for (int k = 1; k < kUpdateThreads / 64; ++k) tot += red[k];
-  __syncthreads();
-  return tot;
-}
-
 // u[t] = clip(u[t] + num[t]/den); u_prev mirrors it (the reference aliases
 // u_prev_d to u_cur_d before the update, mppi.py:362)
 __device__ __forceinline__ void apply_update(float2* u, float2* u_prev, int t, double nx, double ny, double den,
@@ -130,31 +50,96 @@ __device__ __forceinline__ void apply_update(float2* u, float2* u_prev, int t, d
   u_prev[t] = ut;
 }
 
-// fixed-order reduction of the partials into this GPU's packet; with a single
-// GPU (APPLY) the update is applied in the same launch
+// ---- stage 1: weights relative to the minimum of each tile of 64 rollouts ----------
+// w_rel[n] = float32(exp(-(c_n - beta_tile)/lambda)), tile_beta[tile] = min of the tile's
+// costs.  Needs no global minimum, so the pipelined rollout kernel emits it in its
+// epilogue (one exp per lane); k_tile_weights does it for the other rollout kernels.
+// The identity at the top of this file makes the later rescaling exact.
+__device__ __forceinline__ void emit_tile_weights(float cost, bool live, float lambda, int n, int tile,
+                                                  float* __restrict__ w_rel, float* __restrict__ tile_beta) {
+  float beta = wave_min_f32(live ? cost : __builtin_inff());
+  if (live) w_rel[n] = (float)exp(-1.0 / (double)lambda * (double)(cost - beta));
+  if ((threadIdx.x & 63) == 0) tile_beta[tile] = beta;
+}
+
+__global__ __launch_bounds__(64) void k_tile_weights(const float* __restrict__ costs, int n, float lambda,
+                                                     float* __restrict__ w_rel, float* __restrict__ tile_beta) {
+  int i = blockIdx.x * 64 + threadIdx.x;
+  bool live = i < n;
+  emit_tile_weights(live ? costs[i] : 0.0f, live, lambda, i, blockIdx.x, w_rel, tile_beta);
+}
+
+// ---- stage 2: the update, one launch, T independent workgroups ------------------------
+// Workgroup t: beta = min over tiles; scale_tile = exp(-(beta_tile - beta)/lambda) (LDS);
+// den = sum_n scale*w_rel and num = sum_n scale*w_rel*eps(t, n) in float64 (each thread a
+// strided subset in order, fixed butterfly, fixed wave order: deterministic, and den comes
+// out bit-identical in every workgroup); then
+//   APPLY  (single GPU): u[t] = clip(u[t] + num/den)
+//   !APPLY (one of several GPUs): num -> this rank's packet for the all-gather.
+// stats[0] = beta, stats[1] = den (for the normalised weights the host may ask for).
+constexpr int kRowThreads = 1024;
+
 template <bool APPLY>
-__global__ __launch_bounds__(kUpdateThreads) void k_finish(const double2* __restrict__ partial, int n_chunks,
-                                                           const double* __restrict__ den_part, int n_den,
-                                                           int n_steps, double* __restrict__ packet,
-                                                           float2* __restrict__ u, float2* __restrict__ u_prev,
-                                                           float v_lo, float v_hi, float w_lo, float w_hi,
-                                                           double* __restrict__ weight_scale) {
-  __shared__ double red[kUpdateThreads / 64];
-  double den = block_sum_fixed_order(den_part, n_den, red);
-  if (threadIdx.x == 0) {
-    packet[1] = den;
-    if (APPLY) *weight_scale = 1.0 / den;
+__global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __restrict__ w_rel,
+                                                             const float* __restrict__ tile_beta, int n, int n_tiles,
+                                                             const float2* __restrict__ noise, int n_steps,
+                                                             float lambda, double* __restrict__ rank_packet,
+                                                             float2* __restrict__ u, float2* __restrict__ u_prev,
+                                                             float v_lo, float v_hi, float w_lo, float w_hi,
+                                                             double* __restrict__ stats) {
+  extern __shared__ float scale_sh[];  // [n_tiles]
+  __shared__ double red[kRowThreads / 64][3];
+  __shared__ float redf[kRowThreads / 64];
+  const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float b = __builtin_inff();
+  for (int g = threadIdx.x; g < n_tiles; g += kRowThreads) b = fminf(b, tile_beta[g]);
+  b = wave_min_f32(b);
+  if (lane == 0) redf[wave] = b;
+  __syncthreads();
+  float beta = redf[0];
+  for (int k = 1; k < kRowThreads / 64; ++k) beta = fminf(beta, redf[k]);
+  const double neg_inv_lambda = -1.0 / (double)lambda;
+  for (int g = threadIdx.x; g < n_tiles; g += kRowThreads)
+    scale_sh[g] = (float)exp(neg_inv_lambda * (double)(tile_beta[g] - beta));
+  __syncthreads();
+  double den = 0.0, nx = 0.0, ny = 0.0;
+  for (int i = threadIdx.x; i < n; i += kRowThreads) {  // kRowThreads is a multiple of 64: i>>6 is the tile
+    double w = (double)scale_sh[i >> 6] * (double)w_rel[i];
+    float2 e = noise[tile_index(t, i, n_steps)];
+    den += w;
+    nx = fma(w, (double)e.x, nx);
+    ny = fma(w, (double)e.y, ny);
   }
-  for (int t = threadIdx.x; t < n_steps; t += kUpdateThreads) {
-    double nx = 0.0, ny = 0.0;
-    for (int ch = 0; ch < n_chunks; ++ch) {
-      double2 p = partial[(size_t)ch * n_steps + t];
-      nx += p.x;
-      ny += p.y;
+  den = wave_sum_f64(den);
+  nx = wave_sum_f64(nx);
+  ny = wave_sum_f64(ny);
+  if (lane == 0) {
+    red[wave][0] = den;
+    red[wave][1] = nx;
+    red[wave][2] = ny;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < kRowThreads / 64; ++k) {
+      red[0][0] += red[k][0];
+      red[0][1] += red[k][1];
+      red[0][2] += red[k][2];
     }
-    packet[2 + 2 * t] = nx;
-    packet[3 + 2 * t] = ny;
-    if (APPLY) apply_update(u, u_prev, t, nx, ny, den, v_lo, v_hi, w_lo, w_hi);
+    den = red[0][0];
+    nx = red[0][1];
+    ny = red[0][2];
+    if (APPLY) {
+      apply_update(u, u_prev, t, nx, ny, den, v_lo, v_hi, w_lo, w_hi);
+    } else {
+      rank_packet[2 + 2 * t] = nx;
+      rank_packet[3 + 2 * t] = ny;
+    }
+    if (t == 0) {
+      rank_packet[0] = (double)beta;
+      rank_packet[1] = den;
+      stats[0] = (double)beta;
+      stats[1] = den;
+    }
   }
 }
 
@@ -163,7 +148,7 @@ __global__ __launch_bounds__(kUpdateThreads) void k_apply(const double* __restri
                                                           int rank, int n_steps, float lambda,
                                                           float2* __restrict__ u, float2* __restrict__ u_prev,
                                                           float v_lo, float v_hi, float w_lo, float w_hi,
-                                                          double* __restrict__ weight_scale) {
+                                                          double* __restrict__ stats) {
   const int len = packet_len(n_steps);
   double beta = packets[0];
   for (int g = 1; g < world; ++g) beta = fmin(beta, packets[(size_t)g * len]);
@@ -171,8 +156,10 @@ __global__ __launch_bounds__(kUpdateThreads) void k_apply(const double* __restri
   double den = 0.0;
   for (int g = 0; g < world; ++g)
     den += exp(neg_inv_lambda * (packets[(size_t)g * len] - beta)) * packets[(size_t)g * len + 1];
-  if (threadIdx.x == 0)
-    *weight_scale = exp(neg_inv_lambda * (packets[(size_t)rank * len] - beta)) / den;
+  if (threadIdx.x == 0) {
+    stats[0] = beta;
+    stats[1] = den;
+  }
   for (int t = threadIdx.x; t < n_steps; t += kUpdateThreads) {
     double nx = 0.0, ny = 0.0;
     for (int g = 0; g < world; ++g) {
@@ -184,11 +171,12 @@ __global__ __launch_bounds__(kUpdateThreads) void k_apply(const double* __restri
   }
 }
 
-// normalised weights for the host (weights_d of the reference): w * scale
-__global__ void k_scale_weights(const float* __restrict__ w, const double* __restrict__ scale, int n,
-                                float* __restrict__ out) {
+// normalised weights for the host (weights_d of the reference), on demand:
+// w_n = exp(-(c_n - beta)/lambda) / den with the global beta and den of the last update
+__global__ void k_weights_out(const float* __restrict__ costs, const double* __restrict__ stats, float lambda,
+                              int n, float* __restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (float)((double)w[i] * (*scale));
+  if (i < n) out[i] = (float)(exp(-1.0 / (double)lambda * ((double)costs[i] - stats[0])) / stats[1]);
 }
 
 // device-side shift of the control sequence: u[:-k] = u[k:], tail kept (mppi.py:539-541)
@@ -200,20 +188,20 @@ __global__ void k_shift_u(float2* __restrict__ u, int n_steps, int k) {
   for (int t = threadIdx.x; t + k < n_steps; t += blockDim.x) u[t] = tmp[t + k];
 }
 
-// host layout (N,T,2) <-> device layout [T][N] float2
+// host layout (N,T,2) <-> device tile-major layout
 __global__ void k_noise_to_device_layout(const float2* __restrict__ host_layout, int n, int t_steps,
                                          float2* __restrict__ dev_layout) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)n * t_steps) return;
   int t = (int)(i / n), r = (int)(i % n);
-  dev_layout[i] = host_layout[(size_t)r * t_steps + t];
+  dev_layout[tile_index(t, r, t_steps)] = host_layout[(size_t)r * t_steps + t];
 }
 __global__ void k_noise_to_host_layout(const float2* __restrict__ dev_layout, int n, int t_steps,
                                        float2* __restrict__ host_layout) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)n * t_steps) return;
   int r = (int)(i / t_steps), t = (int)(i % t_steps);
-  host_layout[i] = dev_layout[(size_t)t * n + r];
+  host_layout[i] = dev_layout[tile_index(t, r, t_steps)];
 }
 
 }  // namespace mppi
