@@ -404,7 +404,11 @@ struct mppi_planner {
   hipStream_t stream = nullptr;
   int n_local = 0, n_offset = 0;
   // device buffers
-  float2* noise = nullptr;    // [T][n_local]
+  float2* noise = nullptr;    // tile-major (n_local, T): the buffer the NEXT rollout/update reads
+  float2* noise_buf[2] = {nullptr, nullptr};  // double buffer: noise of iteration k+1 is generated
+  int noise_cur = 0;                           // on noise_stream while iteration k runs
+  bool next_noise_wanted = false;  // the coming rollout launch should also generate noise_buf[cur^1]
+  bool next_noise_done = false;    // ... and it did
   float2* staging = nullptr;  // (n_local,T) host-layout staging for set/get_noise
   float2* u = nullptr;        // [T]
   float2* u_prev = nullptr;   // [T]
@@ -458,7 +462,8 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   (void)hipSetDevice(p->cfg.device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   if (p->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(p->comm);
-  dev_free(p->noise);
+  dev_free(p->noise_buf[0]);
+  dev_free(p->noise_buf[1]);
   dev_free(p->staging);
   dev_free(p->u);
   dev_free(p->u_prev);
@@ -493,7 +498,11 @@ static int planner_alloc(mppi_planner* p) {
   HIP_TRY(hipEventCreate(&p->ev_end));
   for (auto& e : p->ev_stage) HIP_TRY(hipEventCreate(&e));
   const size_t n_tiled = (size_t)ceil_div((long)N, 64) * 64;  // tile-major arrays cover whole tiles
-  TRY(dev_alloc(&p->noise, n_tiled * T));
+  for (int b = 0; b < 2; ++b) {
+    TRY(dev_alloc(&p->noise_buf[b], n_tiled * T));
+    HIP_TRY(hipMemsetAsync(p->noise_buf[b], 0, n_tiled * T * sizeof(float2), p->stream));
+  }
+  p->noise = p->noise_buf[0];
   TRY(dev_alloc(&p->staging, N * T));
   TRY(dev_alloc(&p->u, T));
   TRY(dev_alloc(&p->u_prev, T));
@@ -507,7 +516,6 @@ static int planner_alloc(mppi_planner* p) {
   TRY(dev_alloc(&p->state_rollout, (size_t)c.num_vis_state_rollouts * (T + 1) * 3));
   HIP_TRY(hipMemsetAsync(p->u, 0, T * sizeof(float2), p->stream));  // u_seq0 = zeros (mppi.py:93)
   HIP_TRY(hipMemsetAsync(p->u_prev, 0, T * sizeof(float2), p->stream));
-  HIP_TRY(hipMemsetAsync(p->noise, 0, n_tiled * T * sizeof(float2), p->stream));
   HIP_TRY(hipMemsetAsync(p->costs, 0, N * sizeof(float), p->stream));
   const double initial_stats[2] = {0.0, 1.0};
   HIP_TRY(hipMemcpyAsync(p->stats, initial_stats, sizeof(initial_stats), hipMemcpyHostToDevice, p->stream));
@@ -747,17 +755,26 @@ static int ensure_packed(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang) {
   return MPPI_OK;
 }
 
-static int launch_noise(mppi_planner* p) {
-  const int N = p->n_local, T = p->cfg.num_steps;
-  long total = (long)ceil_div(N, 64) * 64 * T;  // one thread per element of the tile-major array
-  if (p->cfg.rng == MPPI_RNG_PHILOX) {
-    hipLaunchKernelGGL(k_noise_philox, dim3(ceil_div(total, 256)), dim3(256), 0, p->stream, p->noise, N,
-                       p->n_offset, T, p->cfg.seed, p->noise_epoch, p->params.u_std[0], p->params.u_std[1]);
-    ++p->noise_epoch;
-  } else {
-    hipLaunchKernelGGL(k_noise_xoroshiro, dim3(ceil_div(total, 256)), dim3(256), 0, p->stream, p->noise,
-                       p->states, N, T, p->params.u_std[0], p->params.u_std[1]);
-  }
+// describe one noise generation (advances the Philox epoch)
+static NoiseJob make_noise_job(mppi_planner* p, float2* target) {
+  NoiseJob j;
+  j.out = target;
+  j.states = (p->cfg.rng == MPPI_RNG_XOROSHIRO) ? p->states : nullptr;
+  j.seed = p->cfg.seed;
+  j.epoch = p->noise_epoch;
+  j.n_local = p->n_local;
+  j.n_offset = p->n_offset;
+  j.n_steps = p->cfg.num_steps;
+  j.std0 = p->params.u_std[0];
+  j.std1 = p->params.u_std[1];
+  if (p->cfg.rng == MPPI_RNG_PHILOX) ++p->noise_epoch;
+  return j;
+}
+
+static int launch_noise(mppi_planner* p, float2* target) {
+  long total = (long)ceil_div(p->n_local, 64) * 64 * p->cfg.num_steps;  // one thread per element
+  NoiseJob job = make_noise_job(p, target);
+  hipLaunchKernelGGL(k_noise, dim3(ceil_div(total, 256)), dim3(256), 0, p->stream, job);
   HIP_TRY(hipGetLastError());
   return MPPI_OK;
 }
@@ -827,6 +844,15 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
           const size_t lds_total = lds_win + ring_bytes(chunk);
           const int block = 192 * pairs;
           const int grid = ceil_div(N, 64 * pairs);
+          // spare CUs generate the next iteration's noise inside this launch
+          NoiseJob next_job;
+          memset(&next_job, 0, sizeof(next_job));
+          int extra = 0;
+          if (p->next_noise_wanted) {
+            extra = p->num_cus > grid ? p->num_cus - grid : p->num_cus / 4;
+            next_job = make_noise_job(p, p->noise_buf[p->noise_cur ^ 1]);
+            p->next_noise_done = true;
+          }
           if (!p->cc_scratch) TRY(dev_alloc(&p->cc_scratch, (size_t)ceil_div(N, 64) * 64 * T));
           int res_exp = 0;
           const bool pow2res = std::frexp((double)a.res, &res_exp) == 0.5;  // res == 2^k exactly
@@ -836,8 +862,9 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
     if (lds_total > 64 * 1024)                                                                        \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));       \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds_total, p->stream, d, p->cells16, p->noise,  \
-                       p->u, p->costs, p->w_rel, p->tile_beta, p->cc_scratch, (int)map_bytes);         \
+    hipLaunchKernelGGL(kern, dim3(grid + extra), dim3(block), lds_total, p->stream, d, p->cells16,    \
+                       p->noise, p->u, p->costs, p->w_rel, p->tile_beta, p->cc_scratch,                \
+                       (int)map_bytes, grid, next_job);                                                \
   } while (0)
           if (pow2res) {
             if (chunk == 8) MPPI_LAUNCH_PIPE(8, true);
@@ -982,12 +1009,25 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
   TRY(ensure_packed(p, lin, ang));
   DevParams d = make_dev_params(p, lin, ang);
   HIP_TRY(hipEventRecord(p->ev_begin, p->stream));
+  // The noise of iteration k+1 does not depend on iteration k.  When the pipelined rollout
+  // kernel runs, its spare workgroups generate it into the other half of the double buffer
+  // (same launch, no extra dependency); otherwise it is generated in line.
+  bool have_noise = false;
   for (int k = 0; k < iterations; ++k) {
     bool prof = p->profile_stages && k == iterations - 1;
     if (prof) HIP_TRY(hipEventRecord(p->ev_stage[0], p->stream));
-    TRY(launch_noise(p));
+    if (have_noise) {
+      p->noise_cur ^= 1;
+    } else {
+      TRY(launch_noise(p, p->noise_buf[p->noise_cur]));
+    }
+    p->noise = p->noise_buf[p->noise_cur];
+    p->next_noise_wanted = (k + 1 < iterations);
+    p->next_noise_done = false;
     if (prof) HIP_TRY(hipEventRecord(p->ev_stage[1], p->stream));
     TRY(launch_rollout(p, d));
+    have_noise = p->next_noise_done;
+    p->next_noise_wanted = false;
     if (prof) HIP_TRY(hipEventRecord(p->ev_stage[2], p->stream));
     TRY(launch_update(p, prof));
   }
@@ -1056,7 +1096,7 @@ extern "C" int mppi_planner_sample_noise(mppi_planner* p) {
   REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
   REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
   HIP_TRY(hipSetDevice(p->cfg.device));
-  TRY(launch_noise(p));
+  TRY(launch_noise(p, p->noise));
   HIP_TRY(hipStreamSynchronize(p->stream));
   return MPPI_OK;
 }

@@ -78,39 +78,52 @@ inline void xoroshiro_init_host(uint64_t* states, long n, uint64_t seed) {
 }
 
 // ---------------- control noise ----------------
-// noise(t, n) = u_std * N(0,1), tile-major; Philox subsequence = global (n, t), offset = epoch
-__global__ __launch_bounds__(256) void k_noise_philox(float2* __restrict__ noise, int n_local, int n_offset,
-                                                      int n_steps, uint64_t seed, uint64_t epoch, float std0,
-                                                      float std1) {
-  // thread i <-> element i of the tile-major array: (tile, t, lane)
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+// noise(t, n) = u_std * N(0,1), tile-major.
+//   Philox: subsequence = global (n, t), offset = 4*epoch (one counter block per call)
+//   xoroshiro: stream n*T+t, two normals per call (4 draws), state kept (reference-compatible)
+// One description serves the standalone kernel and the extra workgroups of the pipelined
+// rollout kernel, which generate the noise of the NEXT iteration while the current one is
+// integrated.
+struct NoiseJob {
+  float2* out;        // tile-major target buffer (nullptr: nothing to do)
+  uint64_t* states;   // xoroshiro states or nullptr (Philox)
+  uint64_t seed, epoch;
+  int n_local, n_offset, n_steps;
+  float std0, std1;
+};
+
+__device__ __forceinline__ void noise_element(const NoiseJob& j, size_t i) {
+  // element i of the tile-major array: (tile, t, lane)
   int lane = (int)(i & 63);
   size_t row = i >> 6;
-  int t = (int)(row % n_steps), n = (int)(row / n_steps) * 64 + lane;
-  if (n >= n_local) return;
-  uint64_t key = (uint64_t)(n_offset + n) * (uint64_t)n_steps + (uint64_t)t;
-  rocrand_state_philox4x32_10 st;
-  rocrand_init(seed, key, 4ULL * epoch, &st);
-  float2 z = rocrand_normal2(&st);
-  noise[i] = make_float2(std0 * z.x, std1 * z.y);
+  int t = (int)(row % j.n_steps), n = (int)(row / j.n_steps) * 64 + lane;
+  if (n >= j.n_local) return;
+  if (j.states == nullptr) {
+    uint64_t key = (uint64_t)(j.n_offset + n) * (uint64_t)j.n_steps + (uint64_t)t;
+    rocrand_state_philox4x32_10 st;
+    rocrand_init(j.seed, key, 4ULL * j.epoch, &st);
+    float2 z = rocrand_normal2(&st);
+    j.out[i] = make_float2(j.std0 * z.x, j.std1 * z.y);
+  } else {
+    size_t k = (size_t)n * j.n_steps + t;
+    uint64_t s0 = j.states[2 * k], s1 = j.states[2 * k + 1];
+    double z0 = xoroshiro_normal(s0, s1);
+    double z1 = xoroshiro_normal(s0, s1);
+    j.states[2 * k] = s0;
+    j.states[2 * k + 1] = s1;
+    j.out[i] = make_float2((float)((double)j.std0 * z0), (float)((double)j.std1 * z1));
+  }
 }
 
-// reference-compatible: stream n*T+t, two normals per call (4 draws), state kept
-__global__ __launch_bounds__(256) void k_noise_xoroshiro(float2* __restrict__ noise, uint64_t* __restrict__ states,
-                                                         int n_local, int n_steps, float std0, float std1) {
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  int lane = (int)(i & 63);
-  size_t row = i >> 6;
-  int t = (int)(row % n_steps), n = (int)(row / n_steps) * 64 + lane;
-  if (n >= n_local) return;
-  size_t k = (size_t)n * n_steps + t;
-  uint64_t s0 = states[2 * k], s1 = states[2 * k + 1];
-  double z0 = xoroshiro_normal(s0, s1);
-  double z1 = xoroshiro_normal(s0, s1);
-  states[2 * k] = s0;
-  states[2 * k + 1] = s1;
-  noise[i] = make_float2((float)((double)std0 * z0), (float)((double)std1 * z1));
+// workgroups [first_block, gridDim.x) of a launch share the job, grid-stride
+__device__ __forceinline__ void noise_generate(const NoiseJob& j, int first_block) {
+  const size_t total = (size_t)((j.n_local + 63) / 64) * 64 * j.n_steps;
+  const size_t stride = (size_t)(gridDim.x - first_block) * blockDim.x;
+  for (size_t i = (size_t)(blockIdx.x - first_block) * blockDim.x + threadIdx.x; i < total; i += stride)
+    noise_element(j, i);
 }
+
+__global__ __launch_bounds__(256) void k_noise(NoiseJob job) { noise_generate(job, 0); }
 
 // ---------------- traction-map sampling ----------------
 // inverse-CDF draw from the int8 PMF (bins sum to 100), terrain.py:682-689

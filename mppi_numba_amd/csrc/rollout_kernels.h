@@ -26,6 +26,7 @@
 // register and is written once (the reference does three global RMWs per step).
 #pragma once
 #include "device_math.h"
+#include "rng_kernels.h"
 #include "update_kernels.h"
 
 namespace mppi {
@@ -323,8 +324,18 @@ template <int C, bool POW2RES>
 __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16,
                                const float2* __restrict__ noise, const float2* __restrict__ u,
                                float* __restrict__ costs, float* __restrict__ w_rel,
-                               float* __restrict__ tile_beta, double* __restrict__ cc_scratch, int map_bytes) {
+                               float* __restrict__ tile_beta, double* __restrict__ cc_scratch, int map_bytes,
+                               int n_rollout_blocks, NoiseJob next_noise) {
   extern __shared__ double2 uos[];
+  if ((int)blockIdx.x >= n_rollout_blocks) {
+    // spare workgroups: the noise of the NEXT iteration, into the other noise buffer
+    noise_generate(next_noise, n_rollout_blocks);
+    return;
+  }
+  // these few waves are the critical path of the iteration; the noise of the NEXT
+  // iteration is generated concurrently by thousands of throughput-oriented waves on
+  // the same SIMDs: win the issue arbitration against them
+  __builtin_amdgcn_s_setprio(3);
   const int T = P.n_steps, N = P.n_local;
   float2* us = reinterpret_cast<float2*>(uos + T);
   uint16_t* lds_map = reinterpret_cast<uint16_t*>(uos + T + (T + 1) / 2);
