@@ -221,6 +221,10 @@ int mppi_planner_stage_times(mppi_planner* p, float ms[4]);
 /* GPU time (ms, hipEvents on the planner's stream) of the last iterate/solve call */
 int mppi_planner_last_elapsed_ms(mppi_planner* p, float* ms);
 
+/* diagnostic: compares the library's single-block Philox4x32-10 with rocRAND's engine on
+ * 65536 (seed, subsequence, offset) triples; *mismatches must come back 0 */
+int mppi_selftest_philox(int device, int* mismatches);
+
 /* ---- multi-GPU: N sharded over ranks, one RCCL all-gather of (2T+2) floats
  *      per iteration (not in the reference) ------------------------------------ */
 #define MPPI_COMM_ID_BYTES 128

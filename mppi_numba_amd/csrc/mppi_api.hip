@@ -772,7 +772,7 @@ static NoiseJob make_noise_job(mppi_planner* p, float2* target) {
 }
 
 static int launch_noise(mppi_planner* p, float2* target) {
-  long total = (long)ceil_div(p->n_local, 64) * 64 * p->cfg.num_steps;  // one thread per element
+  long total = (long)noise_items(p->n_local, p->cfg.num_steps, p->cfg.rng == MPPI_RNG_PHILOX);  // one thread per item
   NoiseJob job = make_noise_job(p, target);
   hipLaunchKernelGGL(k_noise, dim3(ceil_div(total, 256)), dim3(256), 0, p->stream, job);
   HIP_TRY(hipGetLastError());
@@ -836,7 +836,9 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         if (pairs < 1) pairs = 1;
         if (pairs > 5) pairs = 5;                            // 15 waves = 960 threads
         const size_t budget = (size_t)p->lds_per_cu - 1024;
-        auto ring_bytes = [&](int chunk) { return (size_t)pairs * 4 * (size_t)chunk * 64 * sizeof(float2); };
+        auto ring_bytes = [&](int chunk) {
+          return (size_t)pairs * (4 * (size_t)chunk * 64 * sizeof(float2) + 2 * (size_t)chunk * 64);
+        };
         int chunk = 0;
         for (int cnd : {8, 4, 2})
           if (lds_win + ring_bytes(cnd) <= budget) { chunk = cnd; break; }
@@ -848,8 +850,8 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
           NoiseJob next_job;
           memset(&next_job, 0, sizeof(next_job));
           int extra = 0;
-          if (p->next_noise_wanted) {
-            extra = p->num_cus > grid ? p->num_cus - grid : p->num_cus / 4;
+          if (p->next_noise_wanted && grid < p->num_cus) {  // (no spare CU otherwise: generated in line)
+            extra = p->num_cus - grid;
             next_job = make_noise_job(p, p->noise_buf[p->noise_cur ^ 1]);
             p->next_noise_done = true;
           }
@@ -1262,6 +1264,21 @@ extern "C" int mppi_planner_last_elapsed_ms(mppi_planner* p, float* ms) {
   REQUIRE(p && ms, MPPI_ERR_INVALID, "NULL argument");
   TRY(finish_timing(p));
   *ms = p->last_elapsed_ms;
+  return MPPI_OK;
+}
+
+extern "C" int mppi_selftest_philox(int device, int* mismatches) {
+  REQUIRE(mismatches, MPPI_ERR_INVALID, "NULL argument");
+  mppi_device_props pr;
+  TRY(mppi_device_props_get(device, &pr));
+  HIP_TRY(hipSetDevice(device));
+  int* d = nullptr;
+  TRY(dev_alloc(&d, (size_t)1));
+  HIP_TRY(hipMemset(d, 0, sizeof(int)));
+  hipLaunchKernelGGL(k_philox_selftest, dim3(256), dim3(256), 0, 0, d);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(mismatches, d, sizeof(int), hipMemcpyDeviceToHost));
+  dev_free(d);
   return MPPI_OK;
 }
 

@@ -78,10 +78,37 @@ inline void xoroshiro_init_host(uint64_t* states, long n, uint64_t seed) {
 }
 
 // ---------------- control noise ----------------
+// Philox4x32-10 counter block (Salmon et al. 2011), the generator of rocRAND's
+// rocrand_state_philox4x32_10: counter {lo, hi, subsequence lo, subsequence hi}, key = seed.
+// rocrand_init() + rocrand4() compute one block to initialise and a second one eagerly;
+// here exactly one block is computed per four normals.  k_philox_selftest checks this
+// function against rocRAND's engine bit for bit (tests/test_gpu_scale.py).
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    unsigned int hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    unsigned int hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+
+// Box-Muller on two 32-bit words, as rocRAND's box_muller() maps them (u in (0,1], angle
+// in (0, 2pi]) but with the hardware log2 / sqrt / sin / cos (v_sin_f32 takes turns)
+__device__ __forceinline__ float2 box_muller_fast(unsigned int x, unsigned int y) {
+  float u = fmaf((float)x, 2.3283064365386963e-10f, 2.3283064365386963e-10f);
+  float turn = fmaf((float)y, 2.3283064365386963e-10f, 2.3283064365386963e-10f);
+  float s = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u));  // -2 ln u = -2 ln2 log2 u
+  return make_float2(s * __builtin_amdgcn_sinf(turn), s * __builtin_amdgcn_cosf(turn));
+}
+
 // noise(t, n) = u_std * N(0,1), tile-major.
-//   Philox: subsequence = global (n, t), offset = 4*epoch (one counter block per call)
+//   Philox: one counter block per (global rollout n, step pair t/2): counter.zw = n*ceil(T/2)+t/2,
+//           counter.xy = call epoch -> independent of the number of GPUs, nothing stored
 //   xoroshiro: stream n*T+t, two normals per call (4 draws), state kept (reference-compatible)
-// One description serves the standalone kernel and the extra workgroups of the pipelined
+// One description serves the standalone kernel and the spare workgroups of the pipelined
 // rollout kernel, which generate the noise of the NEXT iteration while the current one is
 // integrated.
 struct NoiseJob {
@@ -92,19 +119,26 @@ struct NoiseJob {
   float std0, std1;
 };
 
-__device__ __forceinline__ void noise_element(const NoiseJob& j, size_t i) {
-  // element i of the tile-major array: (tile, t, lane)
-  int lane = (int)(i & 63);
-  size_t row = i >> 6;
-  int t = (int)(row % j.n_steps), n = (int)(row / j.n_steps) * 64 + lane;
-  if (n >= j.n_local) return;
+// work item i: Philox -> (tile, step pair, lane); xoroshiro -> (tile, step, lane)
+__device__ __forceinline__ void noise_item(const NoiseJob& j, size_t i) {
+  const int lane = (int)(i & 63);
+  const size_t row = i >> 6;
   if (j.states == nullptr) {
-    uint64_t key = (uint64_t)(j.n_offset + n) * (uint64_t)j.n_steps + (uint64_t)t;
-    rocrand_state_philox4x32_10 st;
-    rocrand_init(j.seed, key, 4ULL * j.epoch, &st);
-    float2 z = rocrand_normal2(&st);
-    j.out[i] = make_float2(j.std0 * z.x, j.std1 * z.y);
+    const int pairs = (j.n_steps + 1) / 2;
+    const int tp = (int)(row % pairs), tile = (int)(row / pairs);
+    const int n = tile * 64 + lane;
+    if (n >= j.n_local) return;
+    uint64_t sub = (uint64_t)(j.n_offset + n) * (uint64_t)pairs + (uint64_t)tp;
+    uint4 r = philox4x32_10(make_uint4((unsigned int)j.epoch, (unsigned int)(j.epoch >> 32), (unsigned int)sub,
+                                       (unsigned int)(sub >> 32)),
+                            make_uint2((unsigned int)j.seed, (unsigned int)(j.seed >> 32)));
+    float2 a = box_muller_fast(r.x, r.y), b = box_muller_fast(r.z, r.w);
+    float2* o = j.out + ((size_t)tile * j.n_steps + 2 * tp) * 64 + lane;
+    o[0] = make_float2(j.std0 * a.x, j.std1 * a.y);
+    if (2 * tp + 1 < j.n_steps) o[64] = make_float2(j.std0 * b.x, j.std1 * b.y);
   } else {
+    const int t = (int)(row % j.n_steps), n = (int)(row / j.n_steps) * 64 + lane;
+    if (n >= j.n_local) return;
     size_t k = (size_t)n * j.n_steps + t;
     uint64_t s0 = j.states[2 * k], s1 = j.states[2 * k + 1];
     double z0 = xoroshiro_normal(s0, s1);
@@ -115,15 +149,34 @@ __device__ __forceinline__ void noise_element(const NoiseJob& j, size_t i) {
   }
 }
 
+__host__ __device__ inline size_t noise_items(int n_local, int n_steps, bool philox) {
+  return (size_t)((n_local + 63) / 64) * 64 * (size_t)(philox ? (n_steps + 1) / 2 : n_steps);
+}
+
 // workgroups [first_block, gridDim.x) of a launch share the job, grid-stride
 __device__ __forceinline__ void noise_generate(const NoiseJob& j, int first_block) {
-  const size_t total = (size_t)((j.n_local + 63) / 64) * 64 * j.n_steps;
+  const size_t total = noise_items(j.n_local, j.n_steps, j.states == nullptr);
   const size_t stride = (size_t)(gridDim.x - first_block) * blockDim.x;
   for (size_t i = (size_t)(blockIdx.x - first_block) * blockDim.x + threadIdx.x; i < total; i += stride)
-    noise_element(j, i);
+    noise_item(j, i);
 }
 
 __global__ __launch_bounds__(256) void k_noise(NoiseJob job) { noise_generate(job, 0); }
+
+// out[0] = number of (seed, subsequence, offset) triples for which philox4x32_10() differs
+// from rocRAND's own engine
+__global__ void k_philox_selftest(int* out) {
+  unsigned int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t seed = 0x1234ABCD5678EF01ULL * (tid % 7 + 1), sub = (uint64_t)tid * 0x9E3779B97F4A7C15ULL,
+           block = (uint64_t)tid * 977u + (tid % 3 ? 0 : 0xFFFFFFFF0ULL);
+  rocrand_state_philox4x32_10 st;
+  rocrand_init(seed, sub, 4ULL * block, &st);
+  uint4 want = rocrand4(&st);
+  uint4 got = philox4x32_10(make_uint4((unsigned int)block, (unsigned int)(block >> 32), (unsigned int)sub,
+                                       (unsigned int)(sub >> 32)),
+                            make_uint2((unsigned int)seed, (unsigned int)(seed >> 32)));
+  if (got.x != want.x || got.y != want.y || got.z != want.z || got.w != want.w) atomicAdd(out, 1);
+}
 
 // ---------------- traction-map sampling ----------------
 // inverse-CDF draw from the int8 PMF (bins sum to 100), terrain.py:682-689

@@ -308,8 +308,9 @@ __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
 // -------------------------------------------------------------------------
 template <int C>
 struct PipeRing {
-  static constexpr int kHalf = C * 64;                                  // entries per buffer
-  static constexpr int kBytesPerPair = 4 * kHalf * (int)sizeof(float2);  // xy[2] + vw[2]
+  static constexpr int kHalf = C * 64;  // entries per buffer
+  // xy[2][C][64] float2 + vw[2][C][64] float2 + flags[2][C][64] bytes
+  static constexpr int kBytesPerPair = 4 * kHalf * (int)sizeof(float2) + 2 * kHalf;
 };
 
 // Roles of the waves of one workgroup (W = blockDim / 192 triples, triple i = waves
@@ -347,6 +348,7 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
   using Ring = PipeRing<C>;
   float2* ring_xy = reinterpret_cast<float2*>(ring_base + (size_t)triple * Ring::kBytesPerPair);
   float2* ring_vw = ring_xy + 2 * Ring::kHalf;
+  uint8_t* ring_flags = reinterpret_cast<uint8_t*>(ring_vw + 2 * Ring::kHalf);
 
   copy_window_to_lds(P, cells16, lds_map);
   for (int t = threadIdx.x; t < T; t += blockDim.x) us[t] = u[t];
@@ -371,6 +373,7 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
       if (k < K) {
         const float2* in_vw = ring_vw + (size_t)(k & 1) * Ring::kHalf;
         float2* out_xy = ring_xy + (size_t)(k & 1) * Ring::kHalf;
+        uint8_t* out_flags = ring_flags + (size_t)(k & 1) * Ring::kHalf;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
           float2 vw = in_vw[j * 64 + lane];
@@ -397,6 +400,7 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
           rotate_sincos_f64(th_new - th64, s, c);  // exact increment of the ROUNDED heading
           th64 = th_new;
           out_xy[j * 64 + lane] = make_float2(x, y);
+          out_flags[j * 64 + lane] = (uint8_t)(c16 >> 14);  // obstacle | unknown << 1 of the cell just left
         }
       }
       __syncthreads();
@@ -437,40 +441,31 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
     float cost = 0.0f;
     double d2 = 1e9;
     bool done = false, reached = false;
-    float px = P.x0, py = P.y0;  // position BEFORE the step being costed
+    const double* my_cc = cc_scratch + (live ? tile_base : (size_t)lane);
     __syncthreads();
     for (int k = 0; k <= K; ++k) {
       if (k >= 1) {
         const int t0 = (k - 1) * C;
         const float2* in_xy = ring_xy + (size_t)((k - 1) & 1) * Ring::kHalf;
+        const uint8_t* in_flags = ring_flags + (size_t)((k - 1) & 1) * Ring::kHalf;
         const int count = min(C, T - t0);
 #pragma unroll
         for (int j = 0; j < C; ++j) {
           if (j < count) {
             float2 xy = in_xy[j * 64 + lane];
             // obstacle / unknown bits of the cell the step STARTED in (mppi.py:971-998)
-            int xi, yi;
-            if (POW2RES) {
-              xi = (int)floorf((px - P.xlo) * P.inv_res);
-              yi = (int)floorf((py - P.ylo) * P.inv_res);
-            } else {
-              xi = floordiv_to_int(px - P.xlo, P.res, P.inv_res);
-              yi = floordiv_to_int(py - P.ylo, P.res, P.inv_res);
-            }
-            uint32_t c16 = lds_map[clamp_index(yi, P.rows) * P.win_cols + clamp_index(xi, P.cols)];
+            uint32_t fl = in_flags[j * 64 + lane];
             double dx = (double)(P.xg - xy.x), dy = (double)(P.yg - xy.y);
             double nd2 = fma(dx, dx, dy * dy);
             float c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(nd2), dt64));
-            c1 = c1 + ((c16 & 0x4000u) ? P.obs_cost : 0.0f);
-            c1 = c1 + ((c16 & 0x8000u) ? P.unk_cost : 0.0f);
+            c1 = c1 + ((fl & 1u) ? P.obs_cost : 0.0f);
+            c1 = c1 + ((fl & 2u) ? P.unk_cost : 0.0f);
             bool hit = nd2 <= gt2;
             bool act = !done;
             cost = act ? c1 : cost;
             d2 = act ? nd2 : d2;
             reached = reached || (act && hit);
             done = done || hit;
-            px = xy.x;
-            py = xy.y;
           }
         }
       }
@@ -480,16 +475,16 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
     // products were written by the producer wave of this workgroup before its last barrier
     double term = (reached ? 0.0 : 1.0) * sqrt(d2) / P.v_post_den;
     cost = (float)((double)cost + term);
-    // the products come back from L2/HBM with a long latency (they were written by
-    // another wave moments ago): two batches of 24 loads are kept in flight
-    const double* my_cc = cc_scratch + (live ? tile_base : (size_t)lane);
+    // two batches of loads in flight (they come back from L2 with a long latency).
+    // Starting them inside the step loop made the compiler keep the 96 batch registers
+    // live across it and cost 7 us; wider single batches were no better.
     constexpr int kTailBatch = 24;
     double ca[kTailBatch], cb[kTailBatch];
 #pragma unroll
     for (int j = 0; j < kTailBatch; ++j) ca[j] = my_cc[(size_t)min(j, T - 1) * 64];
-    for (int t0 = 0; t0 < T; t0 += kTailBatch) {
 #pragma unroll
-      for (int j = 0; j < kTailBatch; ++j) cb[j] = my_cc[(size_t)min(t0 + kTailBatch + j, T - 1) * 64];
+    for (int j = 0; j < kTailBatch; ++j) cb[j] = my_cc[(size_t)min(kTailBatch + j, T - 1) * 64];
+    for (int t0 = 0; t0 < T; t0 += kTailBatch) {
       if (t0 + kTailBatch <= T) {
 #pragma unroll
         for (int j = 0; j < kTailBatch; ++j) cost = (float)((double)cost + ca[j]);
@@ -500,6 +495,8 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
       }
 #pragma unroll
       for (int j = 0; j < kTailBatch; ++j) ca[j] = cb[j];
+#pragma unroll
+      for (int j = 0; j < kTailBatch; ++j) cb[j] = my_cc[(size_t)min(t0 + 2 * kTailBatch + j, T - 1) * 64];
     }
     if (live) costs[n] = cost;
     // first half of the control update (update_kernels.h): weights relative to the tile's minimum

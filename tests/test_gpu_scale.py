@@ -84,6 +84,16 @@ def test_fast_math_close_to_exact():
     assert np.quantile(rel, 0.99) < 1e-5
 
 
+def test_philox_block_is_rocrands_philox():
+    """The library computes one Philox4x32-10 block per four normals itself; it must be
+    rocRAND's generator bit for bit."""
+    import ctypes as C
+    from mppi_numba_amd import _lib
+    bad = C.c_int(-1)
+    _lib.call("mppi_selftest_philox", 0, C.byref(bad))
+    assert bad.value == 0
+
+
 def test_philox_noise_statistics_and_epochs():
     w, cfg, lin, ang, planner, params = build("c2", 8192)
     planner.sample_noise()
