@@ -86,11 +86,13 @@ WORKLOADS = {
 
 
 def algorithmic_bytes(w, n, rp, cp):
-    """SURVEY.md section 8d.  Returns (bytes per iteration, bytes per rollout-kernel launch)."""
+    """SURVEY.md section 8d.  Returns (bytes per iteration, bytes per rollout-kernel launch).
+    The pipelined rollout launch (det mode) also writes the noise of the following iteration:
+    8 (noise read) + 4 (map bytes) + 8 (noise write) per rollout-step."""
     t, m = w["t"], w["m"]
     if m == 1:
         it = n * t * 28 + n * 16 + 32 * t + 4 * rp * cp
-        roll = n * t * (8 + 4) + n * 4 + 8 * t + 4 * rp * cp
+        roll = n * t * (8 + 4 + 8) + n * 4 + 8 * t + 4 * rp * cp
     else:
         it = 4 * n * m * t + 24 * n * t + 16 * n + 2 * m * rp * cp
         roll = 4 * n * m * t + 8 * n * t + 4 * n + 2 * m * rp * cp
@@ -235,7 +237,7 @@ def main():
     stage = dict(noise=0.0, rollout=0.0, update=0.0, collective=0.0)
     reps = 50
     for _ in range(reps):
-        planner.iterate_async(1)
+        planner.iterate_async(3)  # the middle iteration is profiled: steady state
         planner.synchronize()
         for k, v in planner.stage_times_ms().items():
             stage[k] += v / reps
@@ -246,6 +248,12 @@ def main():
         return
 
     bytes_iter, bytes_roll = algorithmic_bytes(w, n_local, rp, cp)
+    traffic = None
+    try:  # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            traffic = json.load(fh).get(args.workload, {}).get("dominant_kernel_hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
     roll_s = stage["rollout"] * 1e-3
     achieved = bytes_roll / roll_s / 1e9
     out = {
@@ -261,9 +269,9 @@ def main():
                    "sharding": "control samples over ranks, 1 all-gather of (2T+2) f64 per step"},
         "gpu_ms_per_step_events": gpu_ms / args.steps,
         "kernel_ms": stage,
-        "roofline": {"bound": "hbm", "kernel": "k_rollout (dominant kernel)",
+        "roofline": {"bound": "hbm", "kernel": "k_rollout_pipe (rollout + next iteration's noise)" if m == 1 else "k_rollout_tdm",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_roll,
                      "kernel_ms": stage["rollout"]},
         "roofline_iteration": {"bound": "hbm", "achieved": bytes_iter / (ms_per_step * 1e-3) / 1e9,

@@ -447,7 +447,7 @@ struct mppi_planner {
   uint64_t packed_lin_grid = ~0ULL, packed_ang_grid = ~0ULL, packed_lin_maps = ~0ULL;
   // timing
   hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-  hipEvent_t ev_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   bool profile_stages = false;
   float stage_ms[4] = {0, 0, 0, 0};
   float last_elapsed_ms = 0.f;
@@ -1016,7 +1016,9 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
   // (same launch, no extra dependency); otherwise it is generated in line.
   bool have_noise = false;
   for (int k = 0; k < iterations; ++k) {
-    bool prof = p->profile_stages && k == iterations - 1;
+    // profiled iteration: a steady-state one when there is one (its rollout launch then
+    // also carries the noise of the following iteration), else the last
+    bool prof = p->profile_stages && k == (iterations >= 3 ? iterations - 2 : iterations - 1);
     if (prof) HIP_TRY(hipEventRecord(p->ev_stage[0], p->stream));
     if (have_noise) {
       p->noise_cur ^= 1;
@@ -1032,6 +1034,7 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
     p->next_noise_wanted = false;
     if (prof) HIP_TRY(hipEventRecord(p->ev_stage[2], p->stream));
     TRY(launch_update(p, prof));
+    if (prof) HIP_TRY(hipEventRecord(p->ev_stage[5], p->stream));
   }
   HIP_TRY(hipEventRecord(p->ev_end, p->stream));
   p->elapsed_pending = true;
@@ -1050,7 +1053,7 @@ static int finish_timing(mppi_planner* p) {
     HIP_TRY(hipEventElapsedTime(&roll, p->ev_stage[1], p->ev_stage[2]));
     HIP_TRY(hipEventElapsedTime(&upd, p->ev_stage[2], p->ev_stage[3]));
     HIP_TRY(hipEventElapsedTime(&coll, p->ev_stage[3], p->ev_stage[4]));
-    HIP_TRY(hipEventElapsedTime(&tail, p->ev_stage[4], p->ev_end));
+    HIP_TRY(hipEventElapsedTime(&tail, p->ev_stage[4], p->ev_stage[5]));
     p->stage_ms[0] = noise;
     p->stage_ms[1] = roll;
     p->stage_ms[2] = upd + tail;
