@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -789,27 +790,32 @@ static bool plan_lds_window(const mppi_planner* p, DevParams& d, size_t* lds_byt
   if (!p->cells16_valid || p->cfg.mode != MPPI_MODE_DET) return false;
   const mppi_params& a = p->params;
   d.pitch16 = p->pitch16;
-  size_t whole = (size_t)d.rows * p->pitch16 * sizeof(uint16_t);
-  if (head + whole <= budget) {
-    d.win_r0 = 0; d.win_c0 = 0; d.win_rows = d.rows; d.win_cols = p->pitch16;
-    *lds_bytes = head + whole;
-    return true;
-  }
+  const size_t whole = (size_t)d.rows * p->pitch16 * sizeof(uint16_t);
+  // cells reachable from x0 within the horizon (plus a margin), columns in multiples of 8
   double vmax = std::fmax(std::fabs((double)a.vrange[0]), std::fabs((double)a.vrange[1]));
   double trmax = std::fmax(std::fabs(d.lin_lo), std::fabs(d.lin_lo + (double)d.lin_max_byte * d.lin_ratio));
   double reach_m = (double)T * (double)a.dt * vmax * trmax;
-  if (!std::isfinite(reach_m)) return false;
-  long reach = (long)std::ceil(reach_m / (double)a.res) + 2;
-  long xi0 = (long)std::floor(((double)a.x0[0] - (double)a.xlo) / (double)a.res);
-  long yi0 = (long)std::floor(((double)a.x0[1] - (double)a.ylo) / (double)a.res);
-  long r0 = std::max(0L, yi0 - reach), r1 = std::min((long)d.rows, yi0 + reach + 1);
-  long c0 = std::max(0L, xi0 - reach) / 8 * 8;
-  long c1 = std::min((long)p->pitch16, (std::min((long)d.cols, xi0 + reach + 1) + 7) / 8 * 8);
-  if (r1 <= r0 || c1 <= c0) return false;
-  size_t bytes = (size_t)(r1 - r0) * (size_t)(c1 - c0) * sizeof(uint16_t);
-  if (head + bytes > budget) return false;
-  d.win_r0 = (int)r0; d.win_c0 = (int)c0; d.win_rows = (int)(r1 - r0); d.win_cols = (int)(c1 - c0);
-  *lds_bytes = head + bytes;
+  size_t bytes = whole + 1;
+  long r0 = 0, r1 = d.rows, c0 = 0, c1 = p->pitch16;
+  if (std::isfinite(reach_m)) {
+    long reach = (long)std::ceil(reach_m / (double)a.res) + 2;
+    long xi0 = (long)std::floor(((double)a.x0[0] - (double)a.xlo) / (double)a.res);
+    long yi0 = (long)std::floor(((double)a.x0[1] - (double)a.ylo) / (double)a.res);
+    r0 = std::max(0L, yi0 - reach);
+    r1 = std::min((long)d.rows, yi0 + reach + 1);
+    c0 = std::max(0L, xi0 - reach) / 8 * 8;
+    c1 = std::min((long)p->pitch16, (std::min((long)d.cols, xi0 + reach + 1) + 7) / 8 * 8);
+    if (r1 > r0 && c1 > c0) bytes = (size_t)(r1 - r0) * (size_t)(c1 - c0) * sizeof(uint16_t);
+  }
+  if (bytes < whole) {  // the reach window is smaller: less to copy, more LDS left
+    if (head + bytes > budget) return false;
+    d.win_r0 = (int)r0; d.win_c0 = (int)c0; d.win_rows = (int)(r1 - r0); d.win_cols = (int)(c1 - c0);
+    *lds_bytes = head + bytes;
+    return true;
+  }
+  if (head + whole > budget) return false;
+  d.win_r0 = 0; d.win_c0 = 0; d.win_rows = d.rows; d.win_cols = p->pitch16;
+  *lds_bytes = head + whole;
   return true;
 }
 
@@ -823,8 +829,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
       p->tile_packets_fresh = false;
       size_t lds_win = 0;
       bool have_window = plan_lds_window(p, d, &lds_win);
-      if (have_window && EXACT && BOUNDED && d.win_cols == d.pitch16 && d.win_c0 == 0 &&
-          d.win_cols >= d.cols && d.win_r0 == 0 && d.win_rows == d.rows) {
+      if (have_window && EXACT && BOUNDED) {
         // pipelined kernel: needs the whole map in LDS, a heading increment small enough for
         // the incremental trig (|dt*w*traction| <= 0.36 rad) and a horizon short enough for it
         const mppi_params& a = p->params;
@@ -843,24 +848,28 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         for (int cnd : {8, 4, 2})
           if (lds_win + ring_bytes(cnd) <= budget) { chunk = cnd; break; }
         if (std::isfinite(dmax) && dmax <= 0.36 && T <= 2000 && chunk > 0) {
-          const size_t lds_total = lds_win + ring_bytes(chunk);
+          // control-cost products in LDS when there is room, else in a global scratch array
+          const size_t cc_bytes = (size_t)pairs * T * 64 * sizeof(double);
+          const bool cc_lds = lds_win + ring_bytes(chunk) + cc_bytes <= budget;
+          const size_t lds_total = lds_win + ring_bytes(chunk) + (cc_lds ? cc_bytes : 0);
           const int block = 192 * pairs;
           const int grid = ceil_div(N, 64 * pairs);
           // spare CUs generate the next iteration's noise inside this launch
           NoiseJob next_job;
           memset(&next_job, 0, sizeof(next_job));
           int extra = 0;
-          if (p->next_noise_wanted && grid < p->num_cus) {  // (no spare CU otherwise: generated in line)
+          static const bool no_fused_noise = getenv("MPPI_NO_FUSED_NOISE") != nullptr;  // developer switch
+          if (p->next_noise_wanted && grid < p->num_cus && !no_fused_noise) {  // (no spare CU otherwise: in line)
             extra = p->num_cus - grid;
             next_job = make_noise_job(p, p->noise_buf[p->noise_cur ^ 1]);
             p->next_noise_done = true;
           }
-          if (!p->cc_scratch) TRY(dev_alloc(&p->cc_scratch, (size_t)ceil_div(N, 64) * 64 * T));
+          if (!cc_lds && !p->cc_scratch) TRY(dev_alloc(&p->cc_scratch, (size_t)ceil_div(N, 64) * 64 * T));
           int res_exp = 0;
           const bool pow2res = std::frexp((double)a.res, &res_exp) == 0.5;  // res == 2^k exactly
-#define MPPI_LAUNCH_PIPE(CH, P2)                                                                      \
+#define MPPI_LAUNCH_PIPE(CH, P2, CL)                                                                  \
   do {                                                                                                \
-    auto kern = k_rollout_pipe<CH, P2>;                                                               \
+    auto kern = k_rollout_pipe<CH, P2, CL>;                                                           \
     if (lds_total > 64 * 1024)                                                                        \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));       \
@@ -868,15 +877,17 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
                        p->noise, p->u, p->costs, p->w_rel, p->tile_beta, p->cc_scratch,                \
                        (int)map_bytes, grid, next_job);                                                \
   } while (0)
-          if (pow2res) {
-            if (chunk == 8) MPPI_LAUNCH_PIPE(8, true);
-            else if (chunk == 4) MPPI_LAUNCH_PIPE(4, true);
-            else MPPI_LAUNCH_PIPE(2, true);
-          } else {
-            if (chunk == 8) MPPI_LAUNCH_PIPE(8, false);
-            else if (chunk == 4) MPPI_LAUNCH_PIPE(4, false);
-            else MPPI_LAUNCH_PIPE(2, false);
-          }
+#define MPPI_LAUNCH_PIPE_C(P2, CL)            \
+  do {                                        \
+    if (chunk == 8) MPPI_LAUNCH_PIPE(8, P2, CL);      \
+    else if (chunk == 4) MPPI_LAUNCH_PIPE(4, P2, CL); \
+    else MPPI_LAUNCH_PIPE(2, P2, CL);                 \
+  } while (0)
+          if (pow2res && cc_lds) MPPI_LAUNCH_PIPE_C(true, true);
+          else if (pow2res) MPPI_LAUNCH_PIPE_C(true, false);
+          else if (cc_lds) MPPI_LAUNCH_PIPE_C(false, true);
+          else MPPI_LAUNCH_PIPE_C(false, false);
+#undef MPPI_LAUNCH_PIPE_C
 #undef MPPI_LAUNCH_PIPE
           p->tile_packets_fresh = true;
           break;

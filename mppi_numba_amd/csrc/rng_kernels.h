@@ -119,14 +119,13 @@ struct NoiseJob {
   float std0, std1;
 };
 
-// work item i: Philox -> (tile, step pair, lane); xoroshiro -> (tile, step, lane)
-__device__ __forceinline__ void noise_item(const NoiseJob& j, size_t i) {
-  const int lane = (int)(i & 63);
-  const size_t row = i >> 6;
+// one ROW of 64 lanes per wave iteration: Philox -> (tile, step pair), xoroshiro -> (tile, step)
+// (32-bit row arithmetic: the 64-bit divisions of a flat index cost more than the generator)
+__device__ __forceinline__ void noise_row(const NoiseJob& j, unsigned int row, int lane) {
   if (j.states == nullptr) {
-    const int pairs = (j.n_steps + 1) / 2;
-    const int tp = (int)(row % pairs), tile = (int)(row / pairs);
-    const int n = tile * 64 + lane;
+    const unsigned int pairs = (unsigned int)(j.n_steps + 1) / 2u;
+    const unsigned int tile = row / pairs, tp = row - tile * pairs;
+    const int n = (int)tile * 64 + lane;
     if (n >= j.n_local) return;
     uint64_t sub = (uint64_t)(j.n_offset + n) * (uint64_t)pairs + (uint64_t)tp;
     uint4 r = philox4x32_10(make_uint4((unsigned int)j.epoch, (unsigned int)(j.epoch >> 32), (unsigned int)sub,
@@ -135,9 +134,11 @@ __device__ __forceinline__ void noise_item(const NoiseJob& j, size_t i) {
     float2 a = box_muller_fast(r.x, r.y), b = box_muller_fast(r.z, r.w);
     float2* o = j.out + ((size_t)tile * j.n_steps + 2 * tp) * 64 + lane;
     o[0] = make_float2(j.std0 * a.x, j.std1 * a.y);
-    if (2 * tp + 1 < j.n_steps) o[64] = make_float2(j.std0 * b.x, j.std1 * b.y);
+    if (2 * (int)tp + 1 < j.n_steps) o[64] = make_float2(j.std0 * b.x, j.std1 * b.y);
   } else {
-    const int t = (int)(row % j.n_steps), n = (int)(row / j.n_steps) * 64 + lane;
+    const unsigned int steps = (unsigned int)j.n_steps;
+    const unsigned int tile = row / steps, t = row - tile * steps;
+    const int n = (int)tile * 64 + lane;
     if (n >= j.n_local) return;
     size_t k = (size_t)n * j.n_steps + t;
     uint64_t s0 = j.states[2 * k], s1 = j.states[2 * k + 1];
@@ -145,7 +146,7 @@ __device__ __forceinline__ void noise_item(const NoiseJob& j, size_t i) {
     double z1 = xoroshiro_normal(s0, s1);
     j.states[2 * k] = s0;
     j.states[2 * k + 1] = s1;
-    j.out[i] = make_float2((float)((double)j.std0 * z0), (float)((double)j.std1 * z1));
+    j.out[(size_t)row * 64 + lane] = make_float2((float)((double)j.std0 * z0), (float)((double)j.std1 * z1));
   }
 }
 
@@ -153,15 +154,16 @@ __host__ __device__ inline size_t noise_items(int n_local, int n_steps, bool phi
   return (size_t)((n_local + 63) / 64) * 64 * (size_t)(philox ? (n_steps + 1) / 2 : n_steps);
 }
 
-// workgroups [first_block, gridDim.x) of a launch share the job, grid-stride
-__device__ __forceinline__ void noise_generate(const NoiseJob& j, int first_block) {
-  const size_t total = noise_items(j.n_local, j.n_steps, j.states == nullptr);
-  const size_t stride = (size_t)(gridDim.x - first_block) * blockDim.x;
-  for (size_t i = (size_t)(blockIdx.x - first_block) * blockDim.x + threadIdx.x; i < total; i += stride)
-    noise_item(j, i);
+// wave `wave_id` of `n_waves` cooperating waves: rows wave_id, wave_id + n_waves, ...
+__device__ __forceinline__ void noise_generate(const NoiseJob& j, unsigned int wave_id, unsigned int n_waves) {
+  const unsigned int rows = (unsigned int)(noise_items(j.n_local, j.n_steps, j.states == nullptr) >> 6);
+  const int lane = threadIdx.x & 63;
+  for (unsigned int row = wave_id; row < rows; row += n_waves) noise_row(j, row, lane);
 }
 
-__global__ __launch_bounds__(256) void k_noise(NoiseJob job) { noise_generate(job, 0); }
+__global__ __launch_bounds__(256) void k_noise(NoiseJob job) {
+  noise_generate(job, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), gridDim.x * (blockDim.x >> 6));
+}
 
 // out[0] = number of (seed, subsequence, offset) triples for which philox4x32_10() differs
 // from rocRAND's own engine

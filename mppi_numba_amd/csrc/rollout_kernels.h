@@ -188,23 +188,34 @@ __device__ __forceinline__ void map_step(const DevParams& P, const uint32_t* __r
   st.done = st.done || hit;
 }
 
+// Copies the map window into LDS with the threads [first_thread, first_thread + n_threads)
+// of the workgroup.  Window columns [win_c0, win_c0 + win_cols) are multiples of 8 cells =
+// 16-byte vectors.  Batches of eight loads per lane, no branch inside a batch: indices past
+// the end are clamped to the last vector, which is then simply written again.
 __device__ __forceinline__ void copy_window_to_lds(const DevParams& P, const uint16_t* __restrict__ cells16,
-                                                   uint16_t* lds_map) {
-  // full-width window (host-checked): one contiguous run of 16-byte vectors; whole
-  // batches of eight unconditional loads per lane, then the remainder
-  const int total = P.win_rows * (P.win_cols / 8);
+                                                   uint16_t* lds_map, int first_thread, int n_threads) {
+  const int tid = (int)threadIdx.x - first_thread;
+  if (tid < 0 || tid >= n_threads) return;
+  const int vec_per_row = P.win_cols / 8;
+  const int total = P.win_rows * vec_per_row;
+  const int src_pitch = P.pitch16 / 8;
   const uint4* src = reinterpret_cast<const uint4*>(cells16) + ((size_t)P.win_r0 * P.pitch16 + P.win_c0) / 8;
   uint4* dst = reinterpret_cast<uint4*>(lds_map);
-  const int step = 8 * (int)blockDim.x;
-  const int full = total / step * step;
-  for (int i0 = threadIdx.x; i0 < full; i0 += step) {
+  const bool flat = (vec_per_row == src_pitch);  // full-width window: one contiguous run
+  const int step = 8 * n_threads;
+  for (int i0 = tid; i0 < total; i0 += step) {
     uint4 v[8];
+    int idx[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = src[i0 + k * (int)blockDim.x];
+    for (int k = 0; k < 8; ++k) {
+      int i = min(i0 + k * n_threads, total - 1);
+      idx[k] = i;
+      int r = flat ? 0 : i / vec_per_row;
+      v[k] = src[flat ? (size_t)i : (size_t)r * src_pitch + (i - r * vec_per_row)];
+    }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) dst[i0 + k * (int)blockDim.x] = v[k];
+    for (int k = 0; k < 8; ++k) dst[idx[k]] = v[k];
   }
-  for (int i = full + threadIdx.x; i < total; i += blockDim.x) dst[i] = src[i];
 }
 
 // LDS: [T] double2 control ratios | [T] float2 u | (LDSMAP) window of 16-bit cells
@@ -218,23 +229,7 @@ __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
   // 16-byte aligned start of the map window
   uint16_t* lds_map = reinterpret_cast<uint16_t*>(uos + P.n_steps + (P.n_steps + 1) / 2);
   if (LDSMAP) {
-    // coalesced 16-byte copies (window columns are multiples of 8 cells); eight
-    // independent loads per lane are issued before the first LDS write
-    const int vec_per_row = P.win_cols / 8;
-    const int total = P.win_rows * vec_per_row;
-    const uint4* src = reinterpret_cast<const uint4*>(cells16);
-    uint4* dst = reinterpret_cast<uint4*>(lds_map);
-    const size_t base = ((size_t)P.win_r0 * P.pitch16 + P.win_c0) / 8;
-    const int src_pitch = P.pitch16 / 8;
-    if (P.win_cols == P.pitch16) {
-      copy_window_to_lds(P, cells16, lds_map);
-    } else {
-      // one wave per row, lanes along the row
-      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-      for (int r = wave; r < P.win_rows; r += n_waves)
-        for (int c8 = lane; c8 < vec_per_row; c8 += 64)
-          dst[r * vec_per_row + c8] = src[base + (size_t)r * src_pitch + c8];
-    }
+    copy_window_to_lds(P, cells16, lds_map, 0, (int)blockDim.x);
   }
   for (int t = threadIdx.x; t < P.n_steps; t += blockDim.x) us[t] = u[t];
   stage_control_ratios(P, u, uos);
@@ -321,7 +316,7 @@ struct PipeRing {
 //   cost      costs chunk k-1 from ring_xy; afterwards terminal + control costs.
 // Tile-major arrays: element (t, n) of noise / cc_scratch lives at
 // ((n / 64) * T + t) * 64 + n % 64, i.e. the T x 64 block of one wave is contiguous.
-template <int C, bool POW2RES>
+template <int C, bool POW2RES, bool CC_LDS>
 __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16,
                                const float2* __restrict__ noise, const float2* __restrict__ u,
                                float* __restrict__ costs, float* __restrict__ w_rel,
@@ -329,8 +324,12 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
                                int n_rollout_blocks, NoiseJob next_noise) {
   extern __shared__ double2 uos[];
   if ((int)blockIdx.x >= n_rollout_blocks) {
-    // spare workgroups: the noise of the NEXT iteration, into the other noise buffer
-    noise_generate(next_noise, n_rollout_blocks);
+    // spare workgroups: the noise of the NEXT iteration, into the other noise buffer.
+    // (Also giving every rollout group a fourth, noise-generating wave was measured: the
+    // extra waves on the rollout CUs cost the critical waves more than they saved.)
+    if (next_noise.out)
+      noise_generate(next_noise, (blockIdx.x - n_rollout_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6),
+                     (gridDim.x - n_rollout_blocks) * (blockDim.x >> 6));
     return;
   }
   // these few waves are the critical path of the iteration; the noise of the NEXT
@@ -349,10 +348,14 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
   float2* ring_xy = reinterpret_cast<float2*>(ring_base + (size_t)triple * Ring::kBytesPerPair);
   float2* ring_vw = ring_xy + 2 * Ring::kHalf;
   uint8_t* ring_flags = reinterpret_cast<uint8_t*>(ring_vw + 2 * Ring::kHalf);
+  // control-cost products of this triple's 64 rollouts, [T][64] float64, when LDS has room
+  double* cc_lds = reinterpret_cast<double*>(ring_base + (size_t)W * Ring::kBytesPerPair) + (size_t)triple * T * 64;
 
-  copy_window_to_lds(P, cells16, lds_map);
+  // the control sequence first (small), so that the producer waves can publish chunk 0
+  // while the state and cost waves copy the map window
   for (int t = threadIdx.x; t < T; t += blockDim.x) us[t] = u[t];
   stage_control_ratios(P, u, uos);  // ends with a barrier
+  copy_window_to_lds(P, cells16, lds_map, 0, 128 * W);  // waves of roles 0 and 1
 
   const int tile = blockIdx.x * W + triple;  // 64 consecutive rollouts
   const int n = tile * 64 + lane;
@@ -385,8 +388,10 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
             xi = floordiv_to_int(x - P.xlo, P.res, P.inv_res);
             yi = floordiv_to_int(y - P.ylo, P.res, P.inv_res);
           }
-          xi = clamp_index(xi, P.cols);
-          yi = clamp_index(yi, P.rows);
+          // the window holds every cell reachable within the horizon (host-proved); the
+          // clamp is for memory safety only
+          xi = clamp_index(xi - P.win_c0, P.win_cols);
+          yi = clamp_index(yi - P.win_r0, P.win_rows);
           uint32_t c16 = lds_map[yi * P.win_cols + xi];
           double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), P.lin_lo);
           double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), P.ang_lo);
@@ -409,7 +414,7 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
     // the tile past N (if any) reads the last valid tile's noise and writes nothing
     const bool tile_ok = tile * 64 < N;
     const float2* col = noise + (tile_ok ? tile_base : (size_t)0);
-    double* my_cc = cc_scratch + tile_base;
+    double* my_cc = CC_LDS ? cc_lds + lane : cc_scratch + tile_base;
     float2 e_cur[C], e_nxt[C];
     auto produce = [&](int chunk, const float2 (&e)[C]) {
       float2* out_vw = ring_vw + (size_t)(chunk & 1) * Ring::kHalf;
@@ -441,7 +446,7 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
     float cost = 0.0f;
     double d2 = 1e9;
     bool done = false, reached = false;
-    const double* my_cc = cc_scratch + (live ? tile_base : (size_t)lane);
+    const double* my_cc = CC_LDS ? cc_lds + lane : cc_scratch + (live ? tile_base : (size_t)lane);
     __syncthreads();
     for (int k = 0; k <= K; ++k) {
       if (k >= 1) {
@@ -449,24 +454,27 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
         const float2* in_xy = ring_xy + (size_t)((k - 1) & 1) * Ring::kHalf;
         const uint8_t* in_flags = ring_flags + (size_t)((k - 1) & 1) * Ring::kHalf;
         const int count = min(C, T - t0);
+        auto cost_step = [&](int j) {
+          float2 xy = in_xy[j * 64 + lane];
+          // obstacle / unknown bits of the cell the step STARTED in (mppi.py:971-998)
+          uint32_t fl = in_flags[j * 64 + lane];
+          double dx = (double)(P.xg - xy.x), dy = (double)(P.yg - xy.y);
+          double nd2 = fma(dx, dx, dy * dy);
+          float c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(nd2), dt64));
+          c1 = c1 + ((fl & 1u) ? P.obs_cost : 0.0f);
+          c1 = c1 + ((fl & 2u) ? P.unk_cost : 0.0f);
+          bool hit = nd2 <= gt2;
+          bool act = !done;
+          cost = act ? c1 : cost;
+          d2 = act ? nd2 : d2;
+          reached = reached || (act && hit);
+          done = done || hit;
+        };
+        if (count == C) {  // straight-line: the LDS reads of the whole chunk are hoisted
 #pragma unroll
-        for (int j = 0; j < C; ++j) {
-          if (j < count) {
-            float2 xy = in_xy[j * 64 + lane];
-            // obstacle / unknown bits of the cell the step STARTED in (mppi.py:971-998)
-            uint32_t fl = in_flags[j * 64 + lane];
-            double dx = (double)(P.xg - xy.x), dy = (double)(P.yg - xy.y);
-            double nd2 = fma(dx, dx, dy * dy);
-            float c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(nd2), dt64));
-            c1 = c1 + ((fl & 1u) ? P.obs_cost : 0.0f);
-            c1 = c1 + ((fl & 2u) ? P.unk_cost : 0.0f);
-            bool hit = nd2 <= gt2;
-            bool act = !done;
-            cost = act ? c1 : cost;
-            d2 = act ? nd2 : d2;
-            reached = reached || (act && hit);
-            done = done || hit;
-          }
+          for (int j = 0; j < C; ++j) cost_step(j);
+        } else {
+          for (int j = 0; j < count; ++j) cost_step(j);
         }
       }
       __syncthreads();
