@@ -86,9 +86,11 @@ inline void xoroshiro_init_host(uint64_t* states, long n, uint64_t seed) {
 __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    unsigned int hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-    unsigned int hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    // one 32x32->64 multiply (v_mad_u64_u32) per product instead of mul_hi + mul_lo
+    unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x;
+    unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c.z;
+    c = make_uint4((unsigned int)(p1 >> 32) ^ c.y ^ k.x, (unsigned int)p1, (unsigned int)(p0 >> 32) ^ c.w ^ k.y,
+                   (unsigned int)p0);
     k.x += 0x9E3779B9u;
     k.y += 0xBB67AE85u;
   }
