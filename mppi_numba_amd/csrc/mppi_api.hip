@@ -929,6 +929,25 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       if (p->want_sample_costs && !p->sample_costs) TRY(dev_alloc(&p->sample_costs, (size_t)N * M));
       p->tile_packets_fresh = false;
+      {
+        const mppi_params& a = p->params;
+        double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
+        double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
+        double dmax = (double)a.dt * wmax * trmax;
+        const size_t lds_fast = (sizeof(double2) + sizeof(double)) * (size_t)T + sizeof(float) * (size_t)mp2;
+        if (EXACT && BOUNDED && std::isfinite(dmax) && dmax <= 0.36 && T <= 2000 && lds_fast <= 64 * 1024) {
+          int res_exp = 0;
+          const bool pow2res = std::frexp((double)a.res, &res_exp) == 0.5;
+          float* sc_out = p->want_sample_costs ? p->sample_costs : nullptr;
+          if (pow2res)
+            hipLaunchKernelGGL((k_rollout_tdm_fast<true>), dim3(N), dim3(threads), lds_fast, p->stream, d, p->cells,
+                               p->noise, p->u, p->costs, sc_out, mp2);
+          else
+            hipLaunchKernelGGL((k_rollout_tdm_fast<false>), dim3(N), dim3(threads), lds_fast, p->stream, d, p->cells,
+                               p->noise, p->u, p->costs, sc_out, mp2);
+          break;
+        }
+      }
       hipLaunchKernelGGL((k_rollout_tdm<EXACT>), dim3(N), dim3(threads), lds, p->stream, d, p->cells, p->noise,
                          p->u, p->costs, p->want_sample_costs ? p->sample_costs : nullptr, mp2);
       break;

@@ -598,6 +598,117 @@ __global__ void k_rollout_tdm(DevParams P, const uint32_t* __restrict__ cellsM,
 }
 
 // -------------------------------------------------------------------------
+// Stochastic rollouts, throughput-tuned variant (exact math, bounded heading
+// increment).  With N*M/64 waves (8 per SIMD at N=4096, M=128) this mode is bound by
+// VALU throughput, so the instruction count per (n, m, t) is what matters:
+//   * everything that depends only on (n, t) -- clipped controls, dt*v and dt*w in
+//     float64, the control-cost products -- is computed once per workgroup into LDS
+//     instead of once per lane;
+//   * (cos, sin) by rotation with the exact increment of the rounded heading;
+//   * plain floor(x * 2^k) for power-of-two resolutions;
+//   * no divergent break: a `done` predicate, and a wave-uniform early exit.
+// Same rounding points as k_rollout_tdm (the generic kernel stays as the fallback).
+// LDS: [T] double2 {dt*v, dt*w} | [T] double control-cost products | [Mp] float costs.
+// -------------------------------------------------------------------------
+template <bool POW2RES>
+__global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cellsM,
+                                   const float2* __restrict__ noise, const float2* __restrict__ u,
+                                   float* __restrict__ costs, float* __restrict__ sample_costs, int m_pow2) {
+  extern __shared__ double2 qd_sh[];
+  const int T = P.n_steps, M = P.n_grids;
+  double* cc_sh = reinterpret_cast<double*>(qd_sh + T);
+  float* sc = reinterpret_cast<float*>(cc_sh + T);
+  const int n = blockIdx.x;
+  const double dt64 = (double)P.dt;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    float2 ut = u[t];
+    float2 e = noise[tile_index(t, n, T)];
+    float v = clip_f32(ut.x + e.x, P.v_lo, P.v_hi);
+    float w = clip_f32(ut.y + e.y, P.w_lo, P.w_hi);
+    qd_sh[t] = make_double2(dt64 * (double)v, dt64 * (double)w);
+    cc_sh[t] = control_cost(P, make_double2((double)ut.x / P.s0sq, (double)ut.y / P.s1sq), e);
+  }
+  __syncthreads();
+  const double gt2 = (double)P.gt2;
+  for (int m = threadIdx.x; m < m_pow2; m += blockDim.x) {
+    if (m >= M) {
+      sc[m] = -__builtin_inff();  // padding sorts to the tail
+      continue;
+    }
+    float x = P.x0, y = P.y0, th = P.th0, cost = 0.0f;
+    double x64 = (double)x, y64 = (double)y, th64 = (double)th, d2 = 1e9;
+    double s, c;
+    sincos_f64<false>(th64, s, c);
+    bool done = false, reached = false;
+    for (int t = 0; t < T; ++t) {
+      double2 qd = qd_sh[t];
+      int xi, yi;
+      if (POW2RES) {
+        xi = (int)floorf((x - P.xlo) * P.inv_res);
+        yi = (int)floorf((y - P.ylo) * P.inv_res);
+      } else {
+        xi = floordiv_to_int(x - P.xlo, P.res, P.inv_res);
+        yi = floordiv_to_int(y - P.ylo, P.res, P.inv_res);
+      }
+      xi = clamp_index(xi, P.cols);
+      yi = clamp_index(yi, P.rows);
+      uint32_t cell = cellsM[(size_t)(yi * P.cols + xi) * M + m];
+      double vtr = fma(P.lin_ratio, (double)(int)(int8_t)(cell & 0xff), P.lin_lo);
+      double wtr = fma(P.ang_ratio, (double)(int)(int8_t)((cell >> 8) & 0xff), P.ang_lo);
+      float nx = (float)fma(vtr, qd.x * c, x64);
+      float ny = (float)fma(vtr, qd.x * s, y64);
+      float nth = (float)fma(wtr, qd.y, th64);
+      double dx = (double)(P.xg - nx), dy = (double)(P.yg - ny);
+      double nd2 = fma(dx, dx, dy * dy);
+      float c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(nd2), dt64));
+      c1 = c1 + (float)(int8_t)((cell >> 16) & 0xff) * P.obs_cost;
+      c1 = c1 + (float)(int8_t)(cell >> 24) * P.unk_cost;
+      bool hit = nd2 <= gt2;
+      bool act = !done;
+      // the state may run on after the goal: only cost, d2 and the flags are frozen
+      x = nx; y = ny; th = nth;
+      x64 = (double)nx; y64 = (double)ny;
+      double th_new = (double)nth;
+      rotate_sincos_f64(th_new - th64, s, c);
+      th64 = th_new;
+      cost = act ? c1 : cost;
+      d2 = act ? nd2 : d2;
+      reached = reached || (act && hit);
+      done = done || hit;
+      if (__all(done)) break;
+    }
+    // control cost of all T steps, then the terminal cost (mppi.py:706-713)
+    for (int t = 0; t < T; ++t) cost = (float)((double)cost + cc_sh[t]);
+    double term = (reached ? 0.0 : 1.0) * sqrt(d2) / P.v_post_den;
+    cost = (float)((double)cost + term);
+    sc[m] = cost;
+    if (sample_costs) sample_costs[(size_t)n * M + m] = cost;
+  }
+  __syncthreads();
+  if (P.cvar_alpha < 1.0f) {
+    for (int k = 2; k <= m_pow2; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = threadIdx.x; i < m_pow2; i += blockDim.x) {
+          int q = i ^ j;
+          if (q > i) {
+            float a = sc[i], b = sc[q];
+            bool desc = ((i & k) == 0);
+            if (desc ? (a < b) : (a > b)) { sc[i] = b; sc[q] = a; }
+          }
+        }
+        __syncthreads();
+      }
+  }
+  const int numel = P.numel;
+  for (int st = 1; st < numel; st <<= 1) {
+    for (int i = threadIdx.x; i < M; i += blockDim.x)
+      if ((i % (2 * st) == 0) && (i + st < numel)) sc[i] = sc[i] + sc[i + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) costs[n] = (float)((double)sc[0] / (double)numel);
+}
+
+// -------------------------------------------------------------------------
 // barebone notebook rollout: nominal unicycle, quadratic distance cost, disc
 // obstacles tested at the post-step position.
 // -------------------------------------------------------------------------
