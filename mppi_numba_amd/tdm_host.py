@@ -107,3 +107,79 @@ def as_device_float(values):
     everything else float64)."""
     arr = np.asarray(values)
     return arr if arr.dtype in (np.float32, np.float64) else arr.astype(np.float64)
+
+
+def cvar_bin_of_distribution(values, pmf, alpha):
+    """Index of the first bin whose value is >= the mean of the worst `alpha` fraction of a
+    (values, pmf) distribution; the plain mean for alpha == 1 (terrain.py:226-257).  None when
+    no bin qualifies (the reference then trips its own assert)."""
+    if alpha == 1.0:
+        expected = 0.0
+        for val, mass in zip(values, pmf):
+            expected += mass * val
+    else:
+        cum, expected, hit = 0.0, 0.0, False
+        for val, mass in zip(values, pmf):
+            cum += mass
+            expected += mass * val
+            if cum >= alpha:
+                if cum > 0:
+                    expected /= cum
+                hit = True
+                break
+        if not hit:
+            return None
+    for idx, val in enumerate(values):
+        if expected <= val:
+            return idx
+    return None
+
+
+def semantic_pmf_grid(semantic_grid, terrain_of_id, terrain2pmf, num_pmf_bins, bounds_f32, mode, alpha):
+    """PMF grid (and, in speed-map mode, the unpadded int8 risk traction layer) of a grid
+    of semantic ids (terrain.py:219-325).  mode: 'tdm' | 'det' | 'speed'.  Every cell of
+    one terrain type gets the same column, so the work is per unique id."""
+    rows, cols = semantic_grid.shape
+    pmf_grid = np.zeros((num_pmf_bins, rows, cols), dtype=np.int8)
+    ids = np.unique(semantic_grid)
+    risk = None
+    if mode == "det":
+        for sid in ids:
+            values, pmf = terrain2pmf[terrain_of_id(sid)]
+            column = np.zeros(num_pmf_bins, dtype=np.int8)
+            chosen = cvar_bin_of_distribution(values, pmf, alpha)
+            if chosen is not None:
+                column[chosen] = 100
+            assert column.sum() == 100
+            pmf_grid[:, semantic_grid == sid] = column.reshape(-1, 1)
+    elif mode == "speed":
+        pmf_grid[-1, :, :] = np.int8(100)
+        layers = len(terrain2pmf[terrain_of_id(ids[0])][1])
+        pmf_f = np.zeros((layers, rows, cols), dtype=float)  # sums to 1 along axis 0
+        val_f = np.zeros((layers, rows, cols), dtype=float)
+        for sid in ids:
+            values, pmf = terrain2pmf[terrain_of_id(sid)]
+            mask = semantic_grid == sid
+            pmf_f[:, mask] = np.reshape(pmf, (layers, 1))
+            val_f[:, mask] = np.reshape(values, (layers, 1))
+        cum = pmf_f.cumsum(axis=0)
+        wv_cum = np.cumsum(pmf_f * val_f, axis=0)
+        span = bounds_f32[1] - bounds_f32[0]
+        if alpha == 1.0:
+            scaled = 100 * (wv_cum[-1] - bounds_f32[0]) / span
+        else:
+            layer = np.argmax(cum >= alpha, axis=0)
+            rr, cc = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
+            cvar = wv_cum[layer, rr, cc] / cum[layer, rr, cc]  # (no epsilon in this entry point)
+            scaled = 100 * np.asarray((cvar - bounds_f32[0]) / span)
+        risk = np.reshape(scaled, (1, rows, cols)).astype(np.int8)
+    elif mode == "tdm":
+        for sid in ids:
+            values, pmf = terrain2pmf[terrain_of_id(sid)]
+            column = np.int8(np.asarray(pmf) * 100)
+            column[-1] = np.int8(100) - np.sum(column[:-1])
+            assert column.sum() == 100
+            pmf_grid[:, semantic_grid == sid] = column.reshape(-1, 1)
+    else:
+        raise AssertionError("TDM cannot be set up")
+    return pmf_grid, risk

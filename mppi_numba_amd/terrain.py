@@ -195,44 +195,21 @@ class TDM_Numba(object):
         assert bin_values[0] == 0, "Assume minimum bin value is 0 for now"
         assert bin_values_bounds[0] == 0, "Assume minimum traction is 0 for now"
 
-        self.pmf_grid = np.zeros((num_pmf_bins, num_rows, num_cols), dtype=np.int8)
-        ids = np.unique(self.semantic_grid)
-        risk_padded = None
-
         if self.use_det_dynamics:
-            # every cell of one terrain type gets the same one-hot column
-            for sid in ids:
-                values, pmf = self.terrain2pmf[self.id2terrain_fn(sid)]
-                chosen = self._bin_for_cvar(values, pmf, det_dynamics_cvar_alpha)
-                column = np.zeros(num_pmf_bins, dtype=np.int8)
-                if chosen is not None:
-                    column[chosen] = 100
-                assert column.sum() == 100
-                self.pmf_grid[:, self.semantic_grid == sid] = column.reshape(-1, 1)
-
+            mode = "det"
         elif self.use_nom_dynamics_with_speed_map:
-            self.pmf_grid[-1, :, :] = np.int8(100)
-            layers = len(self.terrain2pmf[self.id2terrain_fn(ids[0])][1])
-            pmf_f = np.zeros((layers, num_rows, num_cols), dtype=float)  # sums to 1 along axis 0
-            val_f = np.zeros((layers, num_rows, num_cols), dtype=float)
-            for sid in ids:
-                values, pmf = self.terrain2pmf[self.id2terrain_fn(sid)]
-                mask = self.semantic_grid == sid
-                pmf_f[:, mask] = np.reshape(pmf, (layers, 1))
-                val_f[:, mask] = np.reshape(values, (layers, 1))
-            risk = self._risk_traction(pmf_f, val_f, det_dynamics_cvar_alpha, eps=0.0)
-            risk_padded, _, _ = self.set_padding_risk_traction(risk, self.max_speed_padding, self.dt,
-                                                               res, xlimits, ylimits)
-
+            mode = "speed"
         elif self.use_tdm:
-            for sid in ids:
-                values, pmf = self.terrain2pmf[self.id2terrain_fn(sid)]
-                column = np.int8(np.asarray(pmf) * 100)
-                column[-1] = np.int8(100) - np.sum(column[:-1])
-                assert column.sum() == 100
-                self.pmf_grid[:, self.semantic_grid == sid] = column.reshape(-1, 1)
+            mode = "tdm"
         else:
             assert False, "TDM cannot be set up"
+        self.pmf_grid, risk = tdm_host.semantic_pmf_grid(
+            self.semantic_grid, self.id2terrain_fn, self.terrain2pmf, num_pmf_bins,
+            self.bin_values_bounds, mode, det_dynamics_cvar_alpha)
+        risk_padded = None
+        if risk is not None:
+            risk_padded, _, _ = self.set_padding_risk_traction(risk, self.max_speed_padding, self.dt,
+                                                               res, xlimits, ylimits)
 
         padded_pmf_grid, self.padded_xlimits, self.padded_ylimits = self.set_padding(
             self.pmf_grid, self.max_speed_padding, self.dt, res, xlimits, ylimits)
@@ -244,48 +221,6 @@ class TDM_Numba(object):
         original = copy.deepcopy(self.semantic_grid)
         self.semantic_grid = original[:rows_p - 2 * self.pad_cells, :cols_p - 2 * self.pad_cells]
         self.pmf_grid_initialized = True
-
-    @staticmethod
-    def _bin_for_cvar(values, pmf, alpha):
-        """Index of the first bin whose value is >= the mean of the worst alpha
-        fraction of the (values, pmf) distribution; plain mean for alpha == 1."""
-        if alpha == 1.0:
-            expected = 0.0
-            for val, mass in zip(values, pmf):
-                expected += mass * val
-        else:
-            cum, expected, hit = 0.0, 0.0, False
-            for val, mass in zip(values, pmf):
-                cum += mass
-                expected += mass * val
-                if cum >= alpha:
-                    if cum > 0:
-                        expected /= cum
-                    hit = True
-                    break
-            if not hit:
-                return None
-        for idx, val in enumerate(values):
-            if expected <= val:
-                return idx
-        return None
-
-    def _risk_traction(self, pmf_f, val_f, alpha, eps):
-        """int8 map (1, rows, cols) of 100*(CVaR_alpha traction - lo)/(hi - lo),
-        truncated (terrain.py:305-325 with eps=0, 475-491 with eps=1e-6)."""
-        _, rows, cols = pmf_f.shape
-        cum = pmf_f.cumsum(axis=0)
-        wv_cum = np.cumsum(pmf_f * val_f, axis=0)
-        lo = self.bin_values_bounds[0]
-        span = self.bin_values_bounds[1] - self.bin_values_bounds[0]
-        if alpha == 1.0:
-            scaled = 100 * (wv_cum[-1] - lo) / span
-        else:
-            layer = np.argmax(cum >= alpha, axis=0)
-            rr, cc = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
-            cvar = wv_cum[layer, rr, cc] / (cum[layer, rr, cc] + eps)
-            scaled = 100 * np.asarray((cvar - lo) / span)
-        return np.reshape(scaled, (1, rows, cols)).astype(np.int8)
 
     def get_padded_grid_xy_dim(self):
         if self.pmf_grid_initialized:

@@ -429,6 +429,52 @@ def gen_barebone(with_obstacles):
     return out
 
 
+def gen_semantic(mode_kw, alpha, tag_seed):
+    """set_TDM_from_semantic_grid (terrain.py:183-342): a 9x11 grid of three terrain types
+    with made-up (values, pmf) pairs; plain strings stand in for the Terrain objects (the
+    TDM only uses them as dictionary keys)."""
+    rng = np.random.default_rng(tag_seed)
+    rows, cols, res, bins = 9, 11, 1.0, 7
+    sg = rng.integers(0, 3, size=(rows, cols))
+    values = np.array([0.0, 0.1, 0.3, 0.35, 0.7, 0.9, 1.0])
+    id2name = {0: "dirt", 1: "grass", 2: "mud"}
+    name2terrain = {k: "TERRAIN_" + k for k in id2name.values()}
+    terrain2pmf = {}
+    pmfs = {}
+    for name, conc in (("dirt", [1, 1, 2, 4, 8, 8, 3]), ("grass", [1, 3, 5, 5, 3, 2, 1]), ("mud", [6, 6, 4, 2, 1, 1, 1])):
+        pmf = rng.dirichlet(np.asarray(conc, dtype=float))
+        terrain2pmf[name2terrain[name]] = (values, pmf)
+        pmfs[name] = pmf
+    obstacle = (rng.random((rows, cols)) < 0.1).astype(np.int8)
+    unknown = (rng.random((rows, cols)) < 0.1).astype(np.int8)
+    use_tdm = bool(mode_kw.get("use_tdm"))
+    cfg = _make_cfg(24, T=1.0, dt=0.1, num_grid_samples=6 if use_tdm else 4, max_speed_padding=5.0,
+                    tdm_sample_thread_dim=(4, 4), num_vis_state_rollouts=3, max_map_dim=(14, 16), seed=1,
+                    **mode_kw)
+    lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
+    for tdm in (lin, ang):
+        tdm.set_TDM_from_semantic_grid(sg, res, bins, values, np.array([0.0, 1.0]), (0.0, cols * res),
+                                       (0.0, rows * res), id2name, name2terrain, terrain2pmf,
+                                       det_dynamics_cvar_alpha=alpha, obstacle_map=obstacle, unknown_map=unknown)
+    planner = MPPI_Numba(cfg)
+    params = _params(x0=(3.2, 2.6, 0.4), xgoal=(8.5, 6.5), dt=cfg.dt, num_opt=1, cvar_alpha=0.5,
+                     alpha_dyn=1.0, dist_weight=1.0)
+    planner.setup(params, lin, ang)
+    rec = _UpdateRecorder(planner, MPPI_Numba.update_useq_numba)
+    planner.update_useq_numba = rec
+    out = {}
+    out.update(_cfg_arrays(cfg))
+    out.update(dict(in_semantic_grid=sg, in_values=values, in_obstacle_map=obstacle, in_unknown_map=unknown,
+                    in_pmf_dirt=pmfs["dirt"], in_pmf_grass=pmfs["grass"], in_pmf_mud=pmfs["mud"],
+                    in_alpha=np.float64(-1.0 if alpha is None else alpha), in_res=np.float64(res)))
+    out.update(_params_arrays(params))
+    out.update(_run_closed_loop(planner, lin, ang, params, 1, rec))
+    out.update(_tdm_arrays("lin", lin))
+    out["lin_semantic_grid_after"] = np.asarray(lin.semantic_grid)
+    out.update(_flatten_records(rec.records))
+    return out
+
+
 FIXTURES = {
     "rng_xoroshiro": gen_rng,
     "det_cvar": gen_det,
@@ -439,6 +485,10 @@ FIXTURES = {
     "tdm_mean_alpha_dyn": gen_tdm_mean_alpha_dyn,
     "tdm_cvar_odd": gen_tdm_cvar_odd,
     "tdm_oversized_mean": gen_tdm_oversized_mean,
+    "semantic_tdm": lambda: gen_semantic(dict(use_tdm=True), None, 21),
+    "semantic_det": lambda: gen_semantic(dict(use_det_dynamics=True), 0.3, 22),
+    "semantic_det_mean": lambda: gen_semantic(dict(use_det_dynamics=True), 1.0, 23),
+    "semantic_speedmap": lambda: gen_semantic(dict(use_nom_dynamics_with_speed_map=True), 0.3, 24),
     "barebone_flat": lambda: gen_barebone(False),
     "barebone_obstacles": lambda: gen_barebone(True),
 }

@@ -198,3 +198,94 @@ def test_barebone_end_to_end_xoroshiro():
         u0 = g["solve%d_useq" % s][0]
         x = x + cfg.dt * np.array([u0[0] * np.cos(x[2]), u0[0] * np.sin(x[2]), u0[1]])
         planner.shift_and_update(x, g["solve%d_useq" % s].copy(), num_shifts=1)
+
+
+@pytest.mark.parametrize("name", ["semantic_tdm", "semantic_det", "semantic_det_mean", "semantic_speedmap"])
+def test_semantic_grid_end_to_end_xoroshiro(name):
+    """set_TDM_from_semantic_grid -> solve(), from the seed, against the reference."""
+    from test_host_and_abi import semantic_inputs
+    from gpu_helpers import config_from_golden
+    from mppi_numba_amd.mppi import MPPI_Numba
+    from mppi_numba_amd.terrain import TDM_Numba
+    g = golden(name)
+    values, id2name, name2terrain, terrain2pmf, alpha = semantic_inputs(g)
+    mode_name = {"semantic_tdm": "tdm", "semantic_det": "det", "semantic_det_mean": "det",
+                 "semantic_speedmap": "speedmap"}[name]
+    cfg = config_from_golden(mode_name, g, rng="xoroshiro")
+    rows, cols = g["in_semantic_grid"].shape
+    res = float(g["in_res"])
+    lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
+    for tdm in (lin, ang):
+        tdm.set_TDM_from_semantic_grid(g["in_semantic_grid"], res, len(values), values, np.array([0.0, 1.0]),
+                                       (0.0, cols * res), (0.0, rows * res), id2name, name2terrain, terrain2pmf,
+                                       det_dynamics_cvar_alpha=alpha, obstacle_map=g["in_obstacle_map"],
+                                       unknown_map=g["in_unknown_map"])
+    assert (lin.pmf_grid_d.copy_to_host() == g["lin_pmf_grid_padded"]).all()
+    assert (np.asarray(lin.semantic_grid) == g["lin_semantic_grid_after"]).all()
+    planner = MPPI_Numba(cfg)
+    P = params_from_golden(g)
+    planner.setup(P, lin, ang)
+    useq = planner.solve()
+    want = g["solve0_lin_sample_grid"]
+    got = lin.sample_grid_batch_d.copy_to_host()[:, :want.shape[1], :want.shape[2]]
+    assert (got == want).all()
+    it = iterations(g)[0]
+    assert ulp_diff_f32(planner.noise_samples_d.copy_to_host(), it["noise"]).max() == 0
+    assert ulp_diff_f32(planner.costs_d.copy_to_host(), it["costs"]).max() == 0
+    assert (np.abs(useq.astype(np.float64) - g["solve0_useq"]) / control_scale(P)).max() <= 1e-5
+
+
+def test_closed_loop_reaches_goal_like_test_ipynb():
+    """The acceptance demo of the reference (test.ipynb:381-433): 9x9 semantic world,
+    closed loop solve -> simulate on a sampled ground-truth traction grid ->
+    shift_and_update, until the goal is reached.  Default generator (Philox)."""
+    from mppi_numba_amd.config import Config
+    from mppi_numba_amd.mppi import MPPI_Numba
+    from mppi_numba_amd.terrain import TDM_Numba, TractionGrid
+    rng = np.random.default_rng(7)
+    rows = cols = 9
+    res = 1.0
+    bins = 12
+    sg = (rng.random((rows, cols)) < 0.4).astype(int)  # 0 dirt, 1 vegetation
+    sg[0, 0] = sg[-1, -1] = 0
+    values = np.concatenate([[0.0], (np.arange(bins - 2) + 0.5) / (bins - 2), [1.0]])
+
+    def pmf_of(center, width):
+        p = np.exp(-0.5 * ((values - center) / width) ** 2)
+        p[0] = p[-1] = 0.0
+        return p / p.sum()
+
+    id2name = {0: "dirt", 1: "veg"}
+    name2terrain = {"dirt": "T_DIRT", "veg": "T_VEG"}
+    terrain2pmf = {"T_DIRT": (values, pmf_of(0.8, 0.08)), "T_VEG": (values, pmf_of(0.45, 0.2))}
+    cfg = Config(T=8.0, dt=0.1, num_grid_samples=256, num_control_rollouts=1024, max_speed_padding=3.0,
+                 num_vis_state_rollouts=8, max_map_dim=(15, 15), seed=1, use_tdm=True)
+    lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
+    for tdm in (lin, ang):
+        tdm.set_TDM_from_semantic_grid(sg, res, bins, values, np.array([0.0, 1.0]), (0.0, cols * res),
+                                       (0.0, rows * res), id2name, name2terrain, terrain2pmf)
+    x0 = np.array([0.5, 0.5, np.pi / 4])
+    xgoal = np.array([8.5, 8.5])
+    params = dict(x0=x0, xgoal=xgoal, dt=cfg.dt, goal_tolerance=0.5, v_post_rollout=0.01, lambda_weight=1.0,
+                  cvar_alpha=0.8, alpha_dyn=1.0, num_opt=1, u_std=np.array([1.0, 1.0]),
+                  vrange=np.array([0.0, 3.0]), wrange=np.array([-np.pi, np.pi]))
+    planner = MPPI_Numba(cfg)
+    planner.setup(params, lin, ang)
+    # ground truth: each cell at its terrain's mean traction
+    mean_tr = {0: float((values * terrain2pmf["T_DIRT"][1]).sum()), 1: float((values * terrain2pmf["T_VEG"][1]).sum())}
+    truth = np.vectorize(mean_tr.get)(sg).astype(float)
+    world = TractionGrid(truth, truth, res=res)
+    x = x0.copy()
+    reached_at = None
+    for step in range(250):
+        useq = planner.solve()
+        assert useq is not None and np.isfinite(useq).all()
+        l, a = world.get(x[0], x[1])
+        x = x + cfg.dt * np.array([l * useq[0, 0] * np.cos(x[2]), l * useq[0, 0] * np.sin(x[2]), a * useq[0, 1]])
+        planner.shift_and_update(x, useq, num_shifts=1)
+        if np.linalg.norm(x[:2] - xgoal) <= params["goal_tolerance"]:
+            reached_at = step
+            break
+    assert reached_at is not None, "robot at %s after 250 steps" % x
+    sr = planner.get_state_rollout()
+    assert sr.shape == (cfg.num_vis_state_rollouts, cfg.num_steps + 1, 3) and np.isfinite(sr).all()

@@ -145,3 +145,38 @@ def test_bin_table_truncates_in_device_dtype():
     b64 = tdm_host.bin_table(np.array([0.0, 0.35, 1.0]), np.array([0.0, 1.0]))
     b32 = tdm_host.bin_table(np.array([0.0, 0.35, 1.0], dtype=np.float32), np.array([0.0, 1.0], dtype=np.float32))
     assert list(b64) == [0, 35, 100] and list(b32) == [0, 34, 100]
+
+
+SEMANTIC = {"semantic_tdm": "tdm", "semantic_det": "det", "semantic_det_mean": "det", "semantic_speedmap": "speed"}
+
+
+def semantic_inputs(g):
+    values = g["in_values"]
+    id2name = {0: "dirt", 1: "grass", 2: "mud"}
+    name2terrain = {k: "TERRAIN_" + k for k in id2name.values()}
+    terrain2pmf = {name2terrain[k]: (values, g["in_pmf_" + k]) for k in id2name.values()}
+    alpha = float(g["in_alpha"])
+    return values, id2name, name2terrain, terrain2pmf, (None if alpha < 0 else alpha)
+
+
+@pytest.mark.parametrize("name", sorted(SEMANTIC))
+def test_semantic_grid_preprocessing_vs_reference(name):
+    """set_TDM_from_semantic_grid's host part (terrain.py:183-342)."""
+    g = golden(name)
+    values, id2name, name2terrain, terrain2pmf, alpha = semantic_inputs(g)
+    bounds = np.array([0.0, 1.0], dtype=np.float32)
+    pmf, risk = tdm_host.semantic_pmf_grid(g["in_semantic_grid"], lambda sid: name2terrain[id2name[sid]],
+                                           terrain2pmf, len(values), bounds, SEMANTIC[name], alpha)
+    assert (pmf == g["lin_pmf_grid_unpadded"]).all()
+    max_map_dim = tuple(int(v) for v in g["cfg_max_map_dim"])
+    vr, vc, pad, _, _ = tdm_host.padding_info(pmf.shape, max_map_dim, float(g["cfg_max_speed_padding"]),
+                                              float(g["cfg_dt"]), float(g["in_res"]))
+    assert (tdm_host.pad_pmf(pmf, vr, vc, pad) == g["lin_pmf_grid_padded"]).all()
+    if risk is not None:
+        assert (tdm_host.pad_layer(risk, vr, vc, pad) == g["lin_risk_traction_map_padded"]).all()
+    # this entry point keeps the caller's float64 bin values on the device (terrain.py:332):
+    # 0.35 truncates to 35 here, to 34 through set_TDM_from_PMF_grid's float32 copy
+    assert g["lin_bin_values"].dtype == np.float64
+    table = tdm_host.bin_table(tdm_host.as_device_float(values), tdm_host.as_device_float(np.array([0.0, 1.0])))
+    assert table[3] == 35
+    assert set(np.unique(g["lin_sample_grid"])) <= set(table.tolist())
