@@ -1014,7 +1014,8 @@ static int launch_apply(mppi_planner* p) {
 }
 
 static int launch_update(mppi_planner* p, bool prof) {
-  if (p->cfg.world_size == 1) {
+  // (a communicator on a single rank is honoured too: it exercises the same path as N ranks)
+  if (p->cfg.world_size == 1 && !p->comm) {
     TRY(launch_update_local(p, true));
     if (prof) {
       HIP_TRY(hipEventRecord(p->ev_stage[3], p->stream));

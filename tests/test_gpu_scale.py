@@ -218,3 +218,21 @@ def test_tdm_philox_sampling_follows_the_pmf():
     assert abs(f0 - 10.0 / 30.0) < 0.02
     again = tdm.sample_grids(1.0).copy_to_host()
     assert not np.array_equal(again, first)
+
+
+def test_rccl_path_on_a_single_rank_matches_the_local_path():
+    """One GPU is all a test box has: a 1-rank RCCL communicator still runs the multi-GPU
+    code path (rank packet -> ncclAllGather on the planner's stream -> k_apply) and must
+    give the bits of the local path."""
+    from mppi_numba_amd.mppi import comm_unique_id
+    _, _, _, _, local, _ = build("c2", 2048)
+    _, _, _, _, comm, _ = build("c2", 2048)
+    comm.comm_init(comm_unique_id())
+    for planner in (local, comm):
+        planner.solve()
+        planner.iterate_async(4)
+        planner.synchronize()
+    assert np.array_equal(local.u_cur_d.copy_to_host(), comm.u_cur_d.copy_to_host())
+    assert np.array_equal(local.costs_d.copy_to_host(), comm.costs_d.copy_to_host())
+    w1, w2 = local.weights_d.copy_to_host(), comm.weights_d.copy_to_host()
+    assert np.abs(w1 - w2).max() <= 1e-7 * w1.max()
