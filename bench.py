@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--math", default="exact", choices=["exact", "fast"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "host"],
+                    help="multi-GPU packet exchange: RCCL all-gather on the stream (default) or, for debugging "
+                         "on a box where several ranks must share one GPU, host-staged over gloo")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -200,10 +203,24 @@ def main():
         planner.setup(params, lin, ang)
     rp, cp = lin.pmf_grid_d.shape[1:]
 
-    if world > 1:
+    if world > 1 and args.exchange == "rccl":
         ids = [comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         planner.comm_init(ids[0])
+
+    if world > 1 and args.exchange == "host":
+        import torch
+
+        def iterate(k):  # one launch sequence per iteration, packets over gloo
+            for _ in range(k):
+                planner.sample_noise()
+                planner.rollout()
+                mine = torch.from_numpy(planner.update_local())
+                gathered = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(gathered, mine)
+                planner.update_apply(np.stack([g.numpy() for g in gathered]))
+        planner.iterate_async = iterate
+        planner.solve = lambda: iterate(1)
 
     def barrier():
         if dist is not None:
@@ -235,7 +252,7 @@ def main():
     # ---- per-kernel durations with HIP events on the planner's stream ---------------
     planner.set_profiling(True)
     stage = dict(noise=0.0, rollout=0.0, update=0.0, collective=0.0)
-    reps = 50
+    reps = 0 if (world > 1 and args.exchange == "host") else 50
     for _ in range(reps):
         planner.iterate_async(3)  # the middle iteration is profiled: steady state
         planner.synchronize()
@@ -255,7 +272,7 @@ def main():
     except (OSError, ValueError):
         pass
     roll_s = stage["rollout"] * 1e-3
-    achieved = bytes_roll / roll_s / 1e9
+    achieved = bytes_roll / roll_s / 1e9 if roll_s > 0 else 0.0
     out = {
         "metric": "rollouts/sec (MPPI iteration = noise + rollout + update)",
         "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps,
