@@ -221,6 +221,9 @@ int mppi_planner_stage_times(mppi_planner* p, float ms[4]);
 /* GPU time (ms, hipEvents on the planner's stream) of the last iterate/solve call */
 int mppi_planner_last_elapsed_ms(mppi_planner* p, float* ms);
 
+/* diagnostic: which rollout kernel variant (and its launch geometry) the last rollout used */
+int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity);
+
 /* diagnostic: compares the library's single-block Philox4x32-10 with rocRAND's engine on
  * 65536 (seed, subsequence, offset) triples; *mismatches must come back 0 */
 int mppi_selftest_philox(int device, int* mismatches);

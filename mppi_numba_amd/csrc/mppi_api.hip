@@ -408,6 +408,7 @@ struct mppi_planner {
   float2* noise = nullptr;    // tile-major (n_local, T): the buffer the NEXT rollout/update reads
   float2* noise_buf[2] = {nullptr, nullptr};  // double buffer: noise of iteration k+1 is generated
   int noise_cur = 0;                           // on noise_stream while iteration k runs
+  std::string last_rollout;        // which rollout kernel variant the last launch used (diagnostic)
   bool next_noise_wanted = false;  // the coming rollout launch should also generate noise_buf[cur^1]
   bool next_noise_done = false;    // ... and it did
   float2* staging = nullptr;  // (n_local,T) host-layout staging for set/get_noise
@@ -888,6 +889,15 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
           else if (cc_lds) MPPI_LAUNCH_PIPE_C(false, true);
           else MPPI_LAUNCH_PIPE_C(false, false);
 #undef MPPI_LAUNCH_PIPE_C
+          {
+            char buf[256];
+            snprintf(buf, sizeof(buf),
+                     "k_rollout_pipe chunk=%d pow2res=%d cc_lds=%d triples_per_wg=%d window=%dx%d@(%d,%d) lds=%zu "
+                     "noise_blocks=%d",
+                     chunk, (int)pow2res, (int)cc_lds, pairs, d.win_rows, d.win_cols, d.win_r0, d.win_c0, lds_total,
+                     extra);
+            p->last_rollout = buf;
+          }
 #undef MPPI_LAUNCH_PIPE
           p->tile_packets_fresh = true;
           break;
@@ -905,10 +915,12 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
         hipLaunchKernelGGL(kern, dim3(ceil_div(N, block)), dim3(block), lds_win, p->stream, d, p->cells,
                            p->cells16, (const int8_t*)nullptr, p->noise, p->u, p->costs);
+        p->last_rollout = "k_rollout_map det lds_window exact=" + std::to_string((int)EXACT);
       } else {
         hipLaunchKernelGGL((k_rollout_map<MAP_DET, EXACT, BOUNDED, false>), dim3(ceil_div(N, 64)), dim3(64),
                            lds_map, p->stream, d, p->cells, (const uint16_t*)nullptr, (const int8_t*)nullptr,
                            p->noise, p->u, p->costs);
+        p->last_rollout = "k_rollout_map det global_cells exact=" + std::to_string((int)EXACT);
       }
       break;
     }
@@ -917,6 +929,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
       hipLaunchKernelGGL((k_rollout_map<MAP_SPEED, EXACT, BOUNDED, false>), dim3(ceil_div(N, 64)), dim3(64),
                          lds_map, p->stream, d, p->cells, (const uint16_t*)nullptr, (const int8_t*)p->risk_ref,
                          p->noise, p->u, p->costs);
+      p->last_rollout = "k_rollout_map speed_map global_cells exact=" + std::to_string((int)EXACT);
       break;
     case MPPI_MODE_TDM: {
       int mp2 = next_pow2(M);
@@ -945,17 +958,20 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
           else
             hipLaunchKernelGGL((k_rollout_tdm_fast<false>), dim3(N), dim3(threads), lds_fast, p->stream, d, p->cells,
                                p->noise, p->u, p->costs, sc_out, mp2);
+          p->last_rollout = std::string("k_rollout_tdm_fast pow2res=") + (pow2res ? "1" : "0");
           break;
         }
       }
       hipLaunchKernelGGL((k_rollout_tdm<EXACT>), dim3(N), dim3(threads), lds, p->stream, d, p->cells, p->noise,
                          p->u, p->costs, p->want_sample_costs ? p->sample_costs : nullptr, mp2);
+      p->last_rollout = "k_rollout_tdm exact=" + std::to_string((int)EXACT);
       break;
     }
     case MPPI_MODE_BAREBONE:
       p->tile_packets_fresh = false;
       hipLaunchKernelGGL((k_rollout_barebone<EXACT>), dim3(ceil_div(N, 64)), dim3(64), lds, p->stream, d,
                          p->obs_pos, p->obs_r, p->noise, p->u, p->costs);
+      p->last_rollout = "k_rollout_barebone exact=" + std::to_string((int)EXACT);
       break;
     default:
       return fail(MPPI_ERR_INVALID, "bad mode");
@@ -1298,6 +1314,12 @@ extern "C" int mppi_planner_last_elapsed_ms(mppi_planner* p, float* ms) {
   REQUIRE(p && ms, MPPI_ERR_INVALID, "NULL argument");
   TRY(finish_timing(p));
   *ms = p->last_elapsed_ms;
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity) {
+  REQUIRE(p && buf && capacity > 0, MPPI_ERR_INVALID, "bad argument");
+  snprintf(buf, (size_t)capacity, "%s", p->last_rollout.c_str());
   return MPPI_OK;
 }
 

@@ -345,6 +345,12 @@ class MPPI_Numba(object):
     def synchronize(self):
         _lib.call("mppi_planner_synchronize", self._handle)
 
+    def last_rollout_kernel(self):
+        """Which kernel variant the last rollout launch used (diagnostic string)."""
+        buf = C.create_string_buffer(512)
+        _lib.call("mppi_planner_describe_last_rollout", self._handle, buf, 512)
+        return buf.value.decode()
+
     def set_profiling(self, enabled):
         _lib.call("mppi_planner_set_profiling", self._handle, int(bool(enabled)))
 

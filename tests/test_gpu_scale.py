@@ -236,3 +236,70 @@ def test_rccl_path_on_a_single_rank_matches_the_local_path():
     assert np.array_equal(local.costs_d.copy_to_host(), comm.costs_d.copy_to_host())
     w1, w2 = local.weights_d.copy_to_host(), comm.weights_d.copy_to_host()
     assert np.abs(w1 - w2).max() <= 1e-7 * w1.max()
+
+
+def custom_world(rows, cols, res, seed):
+    rng = np.random.default_rng(seed)
+    bins = 8
+    raw = rng.dirichlet(np.ones(bins), size=(rows, cols))
+    p = np.floor(raw * 100).astype(np.int64)
+    p[..., -1] += 100 - p.sum(axis=-1)
+    pmf = np.ascontiguousarray(np.moveaxis(p, -1, 0)).astype(np.int8)
+    obstacle = (rng.random((rows, cols)) < 0.03).astype(np.int8)
+    unknown = (rng.random((rows, cols)) < 0.03).astype(np.int8)
+    td = dict(xlimits=(0.0, cols * res), ylimits=(0.0, rows * res), res=res, bin_values=np.linspace(0, 1, bins),
+              bin_values_bounds=(0.0, 1.0), det_dynamics_cvar_alpha=0.5)
+    return pmf, obstacle, unknown, td
+
+
+@pytest.mark.parametrize("label,rows,cols,res,n,t_steps,x0,pad_speed,expect", [
+    ("non power-of-two resolution: exact floor division", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0,
+     ["k_rollout_pipe", "pow2res=0"]),
+    ("resolution 0.1: cell borders every few float32 ulps", 200, 200, 0.1, 2048, 80, (7.33, 8.21, -2.0), 3.0,
+     ["k_rollout_pipe", "pow2res=0", "cc_lds=1"]),
+    ("four wave triples per workgroup", 256, 256, 0.25, 65536, 40, (20.0, 30.0, 0.3), 5.0,
+     ["k_rollout_pipe", "triples_per_wg=4"]),
+    ("four triples, long horizon: smaller chunk", 256, 256, 0.25, 65536, 120, (30.0, 30.0, 0.3), 5.0,
+     ["k_rollout_pipe", "triples_per_wg=4", "cc_lds=0"]),
+    ("reach window larger than LDS: global 32-bit cell path", 700, 700, 0.05, 2048, 100, (17.0, 18.0, 1.0), 3.0,
+     ["k_rollout_map det global_cells"]),
+    ("whole-map window, control-cost products in global scratch", 270, 250, 0.25, 2048, 200, (30.0, 33.0, 0.0), 5.0,
+     ["k_rollout_pipe", "cc_lds=0", "window=274x"]),
+])
+def test_det_rollout_variants_vs_oracle(label, rows, cols, res, n, t_steps, x0, pad_speed, expect):
+    """Every code path of the deterministic rollout (pipelined / fused, LDS window kinds,
+    chunk sizes, exact floor division) against the oracle on random PMF worlds."""
+    from mppi_numba_amd.config import Config
+    from mppi_numba_amd.mppi import MPPI_Numba
+    from mppi_numba_amd.terrain import TDM_Numba
+    pmf, obstacle, unknown, td = custom_world(rows, cols, res, seed=rows + cols)
+    pad = int(np.ceil(pad_speed * 0.1 / res))
+    cfg = Config(T=t_steps * 0.1, dt=0.1, num_grid_samples=1, num_control_rollouts=n, max_speed_padding=pad_speed,
+                 num_vis_state_rollouts=1, max_map_dim=(rows + 2 * pad, cols + 2 * pad), seed=3,
+                 enforce_recommended_limits=False, use_det_dynamics=True)
+    assert cfg.num_steps == t_steps
+    lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
+    lin.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)
+    ang.set_TDM_from_PMF_grid(pmf[:, ::-1].copy(), td, obstacle, unknown)
+    planner = MPPI_Numba(cfg)
+    params = bench.make_params("c2")
+    params.update(x0=np.array(x0), xgoal=np.array([x0[0] + 3.0, x0[1] + 2.0]), lambda_weight=5.0)
+    planner.setup(params, lin, ang)
+    planner.solve()
+    planner.iterate_async(3)
+    planner.synchronize()
+    planner.sample_noise()
+    noise, u_in = planner.noise_samples_d.copy_to_host(), planner.u_cur_d.copy_to_host()
+    planner.rollout()
+    kernel = planner.last_rollout_kernel()
+    for token in expect:
+        assert token in kernel, "%s: expected %r in %r" % (label, token, kernel)
+    got = planner.costs_d.copy_to_host()
+    w = dict(m=1)
+    want = oracle_costs(w, params, lin, ang, noise, u_in)
+    ulps = ulp_diff_f32(got, want)
+    assert (ulps == 0).mean() >= 0.999, "%s: exact fraction %.5f, max ulp %d" % (label, (ulps == 0).mean(), ulps.max())
+    assert (np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max() < 1e-6, label
+    planner.update()
+    _, u_ref, _ = O.update_useq(params["lambda_weight"], want, noise, params["vrange"], params["wrange"], u_in)
+    assert (np.abs(planner.u_cur_d.copy_to_host() - u_ref) / np.array([3.0, np.pi])).max() <= 1e-5, label
