@@ -843,11 +843,15 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         if (pairs > 5) pairs = 5;                            // 15 waves = 960 threads
         const size_t budget = (size_t)p->lds_per_cu - 1024;
         auto ring_bytes = [&](int chunk) {
-          return (size_t)pairs * (4 * (size_t)chunk * 64 * sizeof(float2) + 2 * (size_t)chunk * 64);
+          return (size_t)pairs * (2 * (size_t)chunk * 64 * (sizeof(float2) + sizeof(double2)) + 2 * (size_t)chunk * 64);
         };
         int chunk = 0;
-        for (int cnd : {8, 4, 2})
-          if (lds_win + ring_bytes(cnd) <= budget) { chunk = cnd; break; }
+        for (;;) {  // fewer triples per workgroup (more workgroups than CUs) before giving the kernel up
+          for (int cnd : {8, 4, 2})
+            if (lds_win + ring_bytes(cnd) <= budget) { chunk = cnd; break; }
+          if (chunk > 0 || pairs == 1) break;
+          --pairs;
+        }
         if (std::isfinite(dmax) && dmax <= 0.36 && T <= 2000 && chunk > 0) {
           // control-cost products in LDS when there is room, else in a global scratch array
           const size_t cc_bytes = (size_t)pairs * T * 64 * sizeof(double);

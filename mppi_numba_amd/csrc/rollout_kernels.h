@@ -304,8 +304,8 @@ __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
 template <int C>
 struct PipeRing {
   static constexpr int kHalf = C * 64;  // entries per buffer
-  // xy[2][C][64] float2 + vw[2][C][64] float2 + flags[2][C][64] bytes
-  static constexpr int kBytesPerPair = 4 * kHalf * (int)sizeof(float2) + 2 * kHalf;
+  // xy[2][C][64] float2 + qd[2][C][64] double2 {dt*v, dt*w} + flags[2][C][64] bytes
+  static constexpr int kBytesPerPair = 2 * kHalf * (int)sizeof(float2) + 2 * kHalf * (int)sizeof(double2) + 2 * kHalf;
 };
 
 // Roles of the waves of one workgroup (W = blockDim / 192 triples, triple i = waves
@@ -346,8 +346,8 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
   const int triple = wave - role * W;
   using Ring = PipeRing<C>;
   float2* ring_xy = reinterpret_cast<float2*>(ring_base + (size_t)triple * Ring::kBytesPerPair);
-  float2* ring_vw = ring_xy + 2 * Ring::kHalf;
-  uint8_t* ring_flags = reinterpret_cast<uint8_t*>(ring_vw + 2 * Ring::kHalf);
+  double2* ring_qd = reinterpret_cast<double2*>(ring_xy + 2 * Ring::kHalf);
+  uint8_t* ring_flags = reinterpret_cast<uint8_t*>(ring_qd + 2 * Ring::kHalf);
   // control-cost products of this triple's 64 rollouts, [T][64] float64, when LDS has room
   double* cc_lds = reinterpret_cast<double*>(ring_base + (size_t)W * Ring::kBytesPerPair) + (size_t)triple * T * 64;
 
@@ -374,12 +374,12 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
     __syncthreads();  // controls of chunk 0 are in the ring
     for (int k = 0; k <= K; ++k) {
       if (k < K) {
-        const float2* in_vw = ring_vw + (size_t)(k & 1) * Ring::kHalf;
+        const double2* in_qd = ring_qd + (size_t)(k & 1) * Ring::kHalf;
         float2* out_xy = ring_xy + (size_t)(k & 1) * Ring::kHalf;
         uint8_t* out_flags = ring_flags + (size_t)(k & 1) * Ring::kHalf;
 #pragma unroll
         for (int j = 0; j < C; ++j) {
-          float2 vw = in_vw[j * 64 + lane];
+          double2 qd = in_qd[j * 64 + lane];  // {dt*v, dt*w}: exact products of float32 factors
           int xi, yi;
           if (POW2RES) {  // res is a power of two: the float32 quotient is exact
             xi = (int)floorf((x - P.xlo) * P.inv_res);
@@ -392,13 +392,12 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
           // clamp is for memory safety only
           xi = clamp_index(xi - P.win_c0, P.win_cols);
           yi = clamp_index(yi - P.win_r0, P.win_rows);
-          uint32_t c16 = lds_map[yi * P.win_cols + xi];
+          uint32_t c16 = lds_map[__mul24(yi, P.win_cols) + xi];  // 24-bit multiply: full rate
           double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), P.lin_lo);
           double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), P.ang_lo);
-          double q = dt64 * (double)vw.x;  // exact: two float32 factors
-          x = (float)fma(vtr, q * c, x64);
-          y = (float)fma(vtr, q * s, y64);
-          th = (float)fma(wtr, dt64 * (double)vw.y, th64);
+          x = (float)fma(vtr, qd.x * c, x64);
+          y = (float)fma(vtr, qd.x * s, y64);
+          th = (float)fma(wtr, qd.y, th64);
           x64 = (double)x;
           y64 = (double)y;
           double th_new = (double)th;
@@ -417,13 +416,14 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
     double* my_cc = CC_LDS ? cc_lds + lane : cc_scratch + tile_base;
     float2 e_cur[C], e_nxt[C];
     auto produce = [&](int chunk, const float2 (&e)[C]) {
-      float2* out_vw = ring_vw + (size_t)(chunk & 1) * Ring::kHalf;
+      double2* out_qd = ring_qd + (size_t)(chunk & 1) * Ring::kHalf;
+      const double dt64 = (double)P.dt;
 #pragma unroll
       for (int j = 0; j < C; ++j) {
         int t = min(chunk * C + j, T - 1);  // steps past the horizon are produced and ignored
         float2 ut = us[t];
-        out_vw[j * 64 + lane] = make_float2(clip_f32(ut.x + e[j].x, P.v_lo, P.v_hi),
-                                            clip_f32(ut.y + e[j].y, P.w_lo, P.w_hi));
+        out_qd[j * 64 + lane] = make_double2(dt64 * (double)clip_f32(ut.x + e[j].x, P.v_lo, P.v_hi),
+                                             dt64 * (double)clip_f32(ut.y + e[j].y, P.w_lo, P.w_hi));
         if (tile_ok && chunk * C + j < T) my_cc[(size_t)t * 64] = control_cost(P, uos[t], e[j]);
       }
     };
