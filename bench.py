@@ -15,6 +15,9 @@ Workloads (synthetic; BASELINE.json configs[1..3]):
   c2  use_det_dynamics, N=8192 per GPU, T=100, 256x256 nominal traction grid
   c3  use_tdm (CVaR), N=4096 x M=128, 16-bin PMF, 256x256
   c4  use_det_dynamics, N=65536 per GPU, T=200, CVaR-bin traction
+  c5  batched multi-query: 64 independent problems (own start / goal) x N=4096 per GPU, T=100,
+      one launch over (problem, rollout); with several GPUs every rank solves its own 64
+      problems (no exchange at all)
 Multi-GPU is weak scaling: every rank owns `N` control samples of a global
 problem of N*world samples (noise is keyed by the global sample index).
 
@@ -82,7 +85,17 @@ WORKLOADS = {
                label="CVaR MPPI, N=4096/GPU x M=128 traction samples, 16-bin PMF, 256x256"),
     "c4": dict(n=65536, t=200, m=1, mode=dict(use_det_dynamics=True),
                label="Unicycle MPPI det-dyn (CVaR-bin traction), N=65536/GPU, T=200, 256x256"),
+    "c5": dict(n=4096, t=100, m=1, problems=64, mode=dict(use_det_dynamics=True),
+               label="Batched multi-query: 64 problems/GPU x N=4096, T=100, det-dyn, 256x256 CVaR-bin traction"),
 }
+
+
+def batch_problems(count, rng):
+    """Start states and goals spread over the 64 m x 64 m map (c5)."""
+    x0s = np.stack([rng.uniform(2, 62, count), rng.uniform(2, 62, count), rng.uniform(-np.pi, np.pi, count)],
+                   axis=1).astype(np.float32)
+    goals = np.stack([rng.uniform(4, 60, count), rng.uniform(4, 60, count)], axis=1).astype(np.float32)
+    return x0s, goals
 
 
 def algorithmic_bytes(w, n, rp, cp):
@@ -123,7 +136,7 @@ def cpu_baseline(w, world_params, lin, ang, planner, budget_s=12.0):
     lin_g = lin.sample_grid_batch_d.copy_to_host()
     ang_g = ang.sample_grid_batch_d.copy_to_host()
     obs, unk = lin.obstacle_map_d.copy_to_host(), lin.unknown_map_d.copy_to_host()
-    u = planner.u_cur_d.copy_to_host()
+    u = planner.u_cur_d.copy_to_host().reshape(-1, t, 2)[0]  # (problem 0 of a batched handle)
     # bounded sample: fewer rollouts for the CVaR workload (N*M*T is 64x the work)
     n_cpu = n if m == 1 else max(64, n // 32)
     states = O.xoroshiro_init(n_cpu * t, 1)
@@ -153,6 +166,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--n", type=int, default=None, help="override the rollouts per GPU (experiments)")
+    ap.add_argument("--problems", type=int, default=None, help="c5: problems per GPU (default 64)")
     ap.add_argument("--math", default="exact", choices=["exact", "fast"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "host"],
@@ -180,9 +195,12 @@ def main():
     from mppi_numba_amd.mppi import MPPI_Numba, comm_unique_id
     from mppi_numba_amd.terrain import TDM_Numba
 
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload])
+    if args.n:
+        w["n"] = args.n
     n_local, t_steps, m = w["n"], w["t"], w["m"]
-    n_global = n_local * world
+    problems = (args.problems or w["problems"]) if "problems" in w else 0
+    n_global = n_local if problems else n_local * world  # c5: the ranks are independent
     device = local_rank % max(1, _lib.device_count())
 
     import contextlib
@@ -190,7 +208,8 @@ def main():
     quiet = contextlib.redirect_stdout(io.StringIO())  # the mirror prints like the reference does
     with quiet:
         cfg = Config(T=t_steps * 0.1, dt=0.1, num_grid_samples=m, num_control_rollouts=n_global,
-                     max_speed_padding=5.0, num_vis_state_rollouts=1, max_map_dim=(260, 260), seed=1,
+                     max_speed_padding=5.0, num_vis_state_rollouts=1, max_map_dim=(260, 260),
+                     seed=1 + (rank if problems else 0),
                      enforce_recommended_limits=False, math=args.math, device=device, **w["mode"])
         assert cfg.num_steps == t_steps, cfg.num_steps
         world_rng = np.random.default_rng(0)
@@ -198,17 +217,22 @@ def main():
         lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
         lin.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
         ang.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
-        planner = MPPI_Numba(cfg, rank=rank, world_size=world)
         params = make_params(args.workload)
-        planner.setup(params, lin, ang)
+        if problems:
+            from mppi_numba_amd.batch import MPPI_Batch
+            planner = MPPI_Batch(cfg, problems)
+            planner.setup(params, lin, ang, *batch_problems(problems, np.random.default_rng(100 + rank)))
+        else:
+            planner = MPPI_Numba(cfg, rank=rank, world_size=world)
+            planner.setup(params, lin, ang)
     rp, cp = lin.pmf_grid_d.shape[1:]
 
-    if world > 1 and args.exchange == "rccl":
+    if world > 1 and args.exchange == "rccl" and not problems:
         ids = [comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         planner.comm_init(ids[0])
 
-    if world > 1 and args.exchange == "host":
+    if world > 1 and args.exchange == "host" and not problems:
         import torch
 
         def iterate(k):  # one launch sequence per iteration, packets over gloo
@@ -247,12 +271,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = 1e3 * elapsed / args.steps
-    value = n_global * args.steps / elapsed
+    rollouts_per_step = (problems * n_local * world) if problems else n_global
+    value = rollouts_per_step * args.steps / elapsed
 
     # ---- per-kernel durations with HIP events on the planner's stream ---------------
     planner.set_profiling(True)
     stage = dict(noise=0.0, rollout=0.0, update=0.0, collective=0.0)
-    reps = 0 if (world > 1 and args.exchange == "host") else 50
+    reps = 0 if (world > 1 and args.exchange == "host" and not problems) else 50
     for _ in range(reps):
         planner.iterate_async(3)  # the middle iteration is profiled: steady state
         planner.synchronize()
@@ -264,7 +289,7 @@ def main():
         barrier()
         return
 
-    bytes_iter, bytes_roll = algorithmic_bytes(w, n_local, rp, cp)
+    bytes_iter, bytes_roll = algorithmic_bytes(w, n_local * max(1, problems), rp, cp)
     traffic = None
     try:  # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
@@ -283,7 +308,10 @@ def main():
         "config": {"workload": w["label"], "rollouts_per_gpu": n_local, "global_rollouts": n_global,
                    "horizon_steps": t_steps, "traction_samples": m, "padded_grid": [int(rp), int(cp)],
                    "rng": "rocRAND philox4x32-10", "math": args.math,
-                   "sharding": "control samples over ranks, 1 all-gather of (2T+2) f64 per step"},
+                   "problems_per_gpu": problems or 1,
+                   "rollout_kernel": planner.last_rollout_kernel(),
+                   "sharding": "independent problems over ranks, no exchange" if problems else
+                               "control samples over ranks, 1 all-gather of (2T+2) f64 per step"},
         "gpu_ms_per_step_events": gpu_ms / args.steps,
         "kernel_ms": stage,
         "roofline": {"bound": "hbm", "kernel": "k_rollout_pipe (rollout + next iteration's noise)" if m == 1 else "k_rollout_tdm",

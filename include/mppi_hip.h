@@ -141,6 +141,8 @@ typedef struct mppi_planner_cfg {
   int rank;                   /* this handle owns rollouts
                                  [rank*N/world, (rank+1)*N/world)               */
   int world_size;
+  int num_instances;          /* batched multi-query extension (below): B
+                                 problems in one handle; 0 or 1 = one problem   */
   uint64_t seed;
 } mppi_planner_cfg;
 
@@ -178,6 +180,17 @@ int mppi_planner_set_params(mppi_planner* p, const mppi_params* params);
 int mppi_planner_set_disc_obstacles(mppi_planner* p, const float* positions, const float* radii,
                                     int count);
 
+/* ---- batched multi-query (not in the reference; BASELINE.json configs[4]) ------
+ * One handle solves B = cfg.num_instances independent MPPI problems per launch.
+ * They share the maps and every field of mppi_params except the start state and
+ * the goal; each has its own N = num_control_rollouts samples, control sequence,
+ * minimum cost and normaliser.  Instance b is bit-identical to a single-instance
+ * handle given the same noise.  Array shapes with B > 1: u (B,T,2), costs and
+ * weights (B,N_local), noise (B*N_local,T,2), packets B*(2T+2) doubles per rank.
+ * Needs N/world_size to be a multiple of 64; not available in MPPI_MODE_BAREBONE.
+ * x0: (count,3) float32, xgoal: (count,2) float32; count must equal B. */
+int mppi_planner_set_instances(mppi_planner* p, int count, const float* x0, const float* xgoal);
+
 /* mppi.py:539-542 shift_optimal_control_sequence / mppi.py:305,375 copy_to_host */
 int mppi_planner_set_u(mppi_planner* p, const float* u);
 int mppi_planner_get_u(mppi_planner* p, float* u);
@@ -209,6 +222,9 @@ int mppi_planner_get_weights(mppi_planner* p, float* weights);               /* 
 
 /* mppi.py:545-608 get_state_rollout -> (V, T+1, 3) */
 int mppi_planner_get_state_rollout(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, float* out);
+/* the same for problem `instance` of a batched handle (get_state_rollout = instance 0) */
+int mppi_planner_get_instance_state_rollout(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int instance,
+                                            float* out);
 
 /* xoroshiro-compatible generator only: copy the (N_local*T, 2) uint64 states */
 int mppi_planner_rng_states(mppi_planner* p, uint64_t* out, long capacity, long* count);

@@ -48,7 +48,8 @@ class PlannerCfg(C.Structure):
         ("device", C.c_int), ("mode", C.c_int), ("num_control_rollouts", C.c_int),
         ("num_steps", C.c_int), ("num_grid_samples", C.c_int),
         ("num_vis_state_rollouts", C.c_int), ("rng", C.c_int), ("math", C.c_int),
-        ("rank", C.c_int), ("world_size", C.c_int), ("seed", C.c_uint64),
+        ("rank", C.c_int), ("world_size", C.c_int), ("num_instances", C.c_int),
+        ("seed", C.c_uint64),
     ]
 
 
@@ -104,6 +105,8 @@ SIGNATURES = {
     "mppi_planner_update": [_vp],
     "mppi_planner_get_weights": [_vp, _f32p],
     "mppi_planner_get_state_rollout": [_vp, _vp, _vp, _f32p],
+    "mppi_planner_get_instance_state_rollout": [_vp, _vp, _vp, C.c_int, _f32p],
+    "mppi_planner_set_instances": [_vp, C.c_int, _f32p, _f32p],
     "mppi_planner_rng_states": [_vp, _u64p, C.c_long, C.POINTER(C.c_long)],
     "mppi_planner_set_profiling": [_vp, C.c_int],
     "mppi_planner_stage_times": [_vp, _f32p],

@@ -404,6 +404,13 @@ struct mppi_planner {
   mppi_planner_cfg cfg;
   hipStream_t stream = nullptr;
   int n_local = 0, n_offset = 0;
+  // batched multi-query: B problems, each n_inst rollouts (inst_tiles tiles of 64) on this GPU;
+  // n_local = B * n_inst.  Per-problem start / goal / window origin live in inst_dev.
+  int B = 1, n_inst = 0, inst_tiles = 0;
+  std::vector<BatchInst> inst_host;
+  BatchInst* inst_dev = nullptr;
+  bool inst_set = false, inst_dirty = false;
+  float2* u_host = nullptr;  // pinned (B,T) landing buffer of solve(): no pageable D2H on the hot path
   // device buffers
   float2* noise = nullptr;    // tile-major (n_local, T): the buffer the NEXT rollout/update reads
   float2* noise_buf[2] = {nullptr, nullptr};  // double buffer: noise of iteration k+1 is generated
@@ -464,6 +471,8 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   (void)hipSetDevice(p->cfg.device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   if (p->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(p->comm);
+  dev_free(p->inst_dev);
+  if (p->u_host) (void)hipHostFree(p->u_host);
   dev_free(p->noise_buf[0]);
   dev_free(p->noise_buf[1]);
   dev_free(p->staging);
@@ -506,25 +515,32 @@ static int planner_alloc(mppi_planner* p) {
   }
   p->noise = p->noise_buf[0];
   TRY(dev_alloc(&p->staging, N * T));
-  TRY(dev_alloc(&p->u, T));
-  TRY(dev_alloc(&p->u_prev, T));
+  const size_t B = (size_t)p->B;
+  TRY(dev_alloc(&p->u, B * T));
+  TRY(dev_alloc(&p->u_prev, B * T));
+  TRY(dev_alloc(&p->inst_dev, B));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->u_host), B * T * sizeof(float2), hipHostMallocDefault));
+  p->inst_host.assign(B, BatchInst{});
   TRY(dev_alloc(&p->costs, N));
   TRY(dev_alloc(&p->weights_out, N));
   p->n_tiles = ceil_div((long)N, 64);
   TRY(dev_alloc(&p->w_rel, N));
   TRY(dev_alloc(&p->tile_beta, (size_t)p->n_tiles));
-  TRY(dev_alloc(&p->packets, (size_t)c.world_size * packet_len((int)T)));
-  TRY(dev_alloc(&p->stats, (size_t)2));
+  TRY(dev_alloc(&p->packets, (size_t)c.world_size * B * packet_len((int)T)));
+  TRY(dev_alloc(&p->stats, 2 * B));
   TRY(dev_alloc(&p->state_rollout, (size_t)c.num_vis_state_rollouts * (T + 1) * 3));
-  HIP_TRY(hipMemsetAsync(p->u, 0, T * sizeof(float2), p->stream));  // u_seq0 = zeros (mppi.py:93)
-  HIP_TRY(hipMemsetAsync(p->u_prev, 0, T * sizeof(float2), p->stream));
+  HIP_TRY(hipMemsetAsync(p->u, 0, B * T * sizeof(float2), p->stream));  // u_seq0 = zeros (mppi.py:93)
+  HIP_TRY(hipMemsetAsync(p->u_prev, 0, B * T * sizeof(float2), p->stream));
   HIP_TRY(hipMemsetAsync(p->costs, 0, N * sizeof(float), p->stream));
-  const double initial_stats[2] = {0.0, 1.0};
-  HIP_TRY(hipMemcpyAsync(p->stats, initial_stats, sizeof(initial_stats), hipMemcpyHostToDevice, p->stream));
+  {
+    std::vector<double> initial_stats(2 * B);
+    for (size_t b = 0; b < B; ++b) { initial_stats[2 * b] = 0.0; initial_stats[2 * b + 1] = 1.0; }
+    HIP_TRY(hipMemcpy(p->stats, initial_stats.data(), sizeof(double) * 2 * B, hipMemcpyHostToDevice));
+  }
   if (c.rng == MPPI_RNG_XOROSHIRO) {
     // numba creates N*T states on the host, 2^64-jump apart (mppi.py:118); a
     // shard keeps the slice of the global stream array that it owns
-    long total = (long)c.num_control_rollouts * c.num_steps;
+    long total = (long)c.num_control_rollouts * (long)B * c.num_steps;  // rank-major over (rank, problem, rollout)
     std::vector<uint64_t> host(2 * (size_t)total);
     xoroshiro_init_host(host.data(), total, c.seed);
     p->n_states = (long)N * (long)T;
@@ -557,15 +573,26 @@ extern "C" int mppi_planner_create(const mppi_planner_cfg* cfg, mppi_planner** o
   REQUIRE(strncmp(pr.gcn_arch, "gfx950", 6) == 0, MPPI_ERR_NO_DEVICE,
           "device %d is %s; this library is built for gfx950 (MI355X) only", cfg->device, pr.gcn_arch);
   HIP_TRY(hipSetDevice(cfg->device));
-  const int n_local = cfg->num_control_rollouts / cfg->world_size;
+  const int n_problems = cfg->num_instances > 1 ? cfg->num_instances : 1;
+  const int n_inst = cfg->num_control_rollouts / cfg->world_size;
+  REQUIRE(cfg->num_instances >= 0 && n_problems <= 65535, MPPI_ERR_INVALID, "bad num_instances %d",
+          cfg->num_instances);
+  REQUIRE(n_problems == 1 || (n_inst % 64 == 0 && cfg->mode != MPPI_MODE_BAREBONE), MPPI_ERR_INVALID,
+          "num_instances > 1 needs num_control_rollouts/world_size (%d) to be a multiple of 64 and a map mode",
+          n_inst);
+  REQUIRE((long)n_problems * n_inst <= (1L << 30), MPPI_ERR_INVALID, "too many rollouts per GPU");
+  const int n_local = n_problems * n_inst;
   const int device_cus = pr.compute_units, device_lds = pr.lds_bytes_per_cu;
-  REQUIRE(cfg->num_vis_state_rollouts <= n_local || cfg->mode == MPPI_MODE_TDM, MPPI_ERR_INVALID,
+  REQUIRE(cfg->num_vis_state_rollouts <= n_inst || cfg->mode == MPPI_MODE_TDM, MPPI_ERR_INVALID,
           "num_vis_state_rollouts exceeds local rollouts");
   REQUIRE(cfg->mode != MPPI_MODE_TDM || cfg->num_vis_state_rollouts <= cfg->num_grid_samples, MPPI_ERR_INVALID,
           "num_vis_state_rollouts exceeds num_grid_samples");
   mppi_planner* p = new mppi_planner();
   p->cfg = *cfg;
   p->n_local = n_local;
+  p->B = n_problems;
+  p->n_inst = n_inst;
+  p->inst_tiles = ceil_div(n_inst, 64);
   p->n_offset = cfg->rank * p->n_local;
   p->num_cus = device_cus > 0 ? device_cus : 256;
   p->lds_per_cu = device_lds >= 64 * 1024 ? device_lds : 64 * 1024;
@@ -589,6 +616,7 @@ extern "C" int mppi_planner_set_params(mppi_planner* p, const mppi_params* param
   REQUIRE(params->u_std[0] > 0.0f && params->u_std[1] > 0.0f, MPPI_ERR_INVALID, "u_std must be > 0");
   p->params = *params;
   p->params_set = true;
+  p->inst_dirty = true;  // the per-problem window origins depend on the reach
   return MPPI_OK;
 }
 
@@ -625,25 +653,45 @@ static int copy_out(mppi_planner* p, void* dst, const void* src, size_t bytes) {
 
 extern "C" int mppi_planner_set_u(mppi_planner* p, const float* u) {
   REQUIRE(p && u, MPPI_ERR_INVALID, "NULL argument");
-  return copy_in(p, p->u, u, sizeof(float2) * (size_t)p->cfg.num_steps);
+  return copy_in(p, p->u, u, sizeof(float2) * (size_t)p->B * (size_t)p->cfg.num_steps);
 }
 extern "C" int mppi_planner_get_u(mppi_planner* p, float* u) {
   REQUIRE(p && u, MPPI_ERR_INVALID, "NULL argument");
-  return copy_out(p, u, p->u, sizeof(float2) * (size_t)p->cfg.num_steps);
+  return copy_out(p, u, p->u, sizeof(float2) * (size_t)p->B * (size_t)p->cfg.num_steps);
 }
 extern "C" int mppi_planner_get_u_prev(mppi_planner* p, float* u) {
   REQUIRE(p && u, MPPI_ERR_INVALID, "NULL argument");
-  return copy_out(p, u, p->u_prev, sizeof(float2) * (size_t)p->cfg.num_steps);
+  return copy_out(p, u, p->u_prev, sizeof(float2) * (size_t)p->B * (size_t)p->cfg.num_steps);
 }
 
 extern "C" int mppi_planner_shift_u(mppi_planner* p, int k) {
   REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
   if (k <= 0 || k >= p->cfg.num_steps) return MPPI_OK;  // u[:-k] = u[k:] is empty then
   HIP_TRY(hipSetDevice(p->cfg.device));
-  hipLaunchKernelGGL(k_shift_u, dim3(1), dim3(256), sizeof(float2) * (size_t)p->cfg.num_steps, p->stream, p->u,
+  hipLaunchKernelGGL(k_shift_u, dim3(p->B), dim3(256), sizeof(float2) * (size_t)p->cfg.num_steps, p->stream, p->u,
                      p->cfg.num_steps, k);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(p->stream));
+  return MPPI_OK;
+}
+
+// Batched multi-query: the start state and the goal of every problem (everything else is
+// shared through mppi_params).  With count == 1 a single-problem handle takes the same
+// kernel path as a batch (the parity tests compare the two).
+extern "C" int mppi_planner_set_instances(mppi_planner* p, int count, const float* x0, const float* xgoal) {
+  REQUIRE(p && x0 && xgoal, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(count == p->B, MPPI_ERR_INVALID, "count %d != num_instances %d of this handle", count, p->B);
+  REQUIRE(p->cfg.mode != MPPI_MODE_BAREBONE, MPPI_ERR_INVALID, "no instances in the barebone mode");
+  for (int b = 0; b < count; ++b) {
+    BatchInst& I = p->inst_host[(size_t)b];
+    I.x0 = x0[3 * b]; I.y0 = x0[3 * b + 1]; I.th0 = x0[3 * b + 2];
+    I.xg = xgoal[2 * b]; I.yg = xgoal[2 * b + 1];
+    REQUIRE(std::isfinite(I.x0) && std::isfinite(I.y0) && std::isfinite(I.th0) && std::isfinite(I.xg) &&
+                std::isfinite(I.yg),
+            MPPI_ERR_INVALID, "instance %d: non-finite start or goal", b);
+  }
+  p->inst_set = true;
+  p->inst_dirty = true;
   return MPPI_OK;
 }
 
@@ -702,6 +750,9 @@ static DevParams make_dev_params(const mppi_planner* p, const mppi_tdm* lin, con
   d.n_steps = p->cfg.num_steps;
   d.n_grids = p->cfg.num_grid_samples;
   d.n_obstacles = p->n_obstacles;
+  d.inst = p->inst_set ? p->inst_dev : nullptr;
+  d.inst_tiles = p->inst_tiles;
+  d.n_inst = p->n_inst;
   return d;
 }
 
@@ -784,7 +835,7 @@ static int launch_noise(mppi_planner* p, float2* target) {
 // Decide whether the deterministic rollout can keep its map in LDS: the 16-bit cell
 // window must cover every cell reachable from x0 within the horizon and fit next to
 // the staged controls.  Fills the window fields of `d`.
-static bool plan_lds_window(const mppi_planner* p, DevParams& d, size_t* lds_bytes) {
+static bool plan_lds_window(mppi_planner* p, DevParams& d, size_t* lds_bytes) {
   const int T = p->cfg.num_steps;
   const size_t head = sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);
   const size_t budget = (size_t)p->lds_per_cu - 1024;  // leave room for the runtime's own use
@@ -798,6 +849,33 @@ static bool plan_lds_window(const mppi_planner* p, DevParams& d, size_t* lds_byt
   double reach_m = (double)T * (double)a.dt * vmax * trmax;
   size_t bytes = whole + 1;
   long r0 = 0, r1 = d.rows, c0 = 0, c1 = p->pitch16;
+  if (p->inst_set) {
+    // batched handle: one window SIZE for all problems (the full reach square, clipped to the
+    // map size), one ORIGIN per problem, shifted inwards at the map border
+    for (BatchInst& I : p->inst_host) I.win_r0 = I.win_c0 = 0;
+    if (std::isfinite(reach_m)) {
+      long reach = (long)std::ceil(reach_m / (double)a.res) + 2;
+      long wr = std::min((long)d.rows, 2 * reach + 1);
+      long wc = std::min((long)p->pitch16, (2 * reach + 1 + 7) / 8 * 8 + 8);
+      size_t wbytes = (size_t)wr * (size_t)wc * sizeof(uint16_t);
+      if (wbytes < whole) {
+        if (head + wbytes > budget) return false;
+        for (BatchInst& I : p->inst_host) {
+          long xi0 = (long)std::floor(((double)I.x0 - (double)a.xlo) / (double)a.res);
+          long yi0 = (long)std::floor(((double)I.y0 - (double)a.ylo) / (double)a.res);
+          I.win_r0 = (int)std::min(std::max(0L, yi0 - reach), (long)d.rows - wr);
+          I.win_c0 = (int)std::min(std::max(0L, xi0 - reach) / 8 * 8, (long)p->pitch16 - wc);
+        }
+        d.win_r0 = 0; d.win_c0 = 0; d.win_rows = (int)wr; d.win_cols = (int)wc;
+        *lds_bytes = head + wbytes;
+        return true;
+      }
+    }
+    if (head + whole > budget) return false;
+    d.win_r0 = 0; d.win_c0 = 0; d.win_rows = d.rows; d.win_cols = p->pitch16;
+    *lds_bytes = head + whole;
+    return true;
+  }
   if (std::isfinite(reach_m)) {
     long reach = (long)std::ceil(reach_m / (double)a.res) + 2;
     long xi0 = (long)std::floor(((double)a.x0[0] - (double)a.xlo) / (double)a.res);
@@ -820,6 +898,15 @@ static bool plan_lds_window(const mppi_planner* p, DevParams& d, size_t* lds_byt
   return true;
 }
 
+// per-problem start / goal / window origin -> device, when they changed
+static int upload_instances(mppi_planner* p) {
+  if (!p->inst_set || !p->inst_dirty) return MPPI_OK;
+  HIP_TRY(hipMemcpyAsync(p->inst_dev, p->inst_host.data(), sizeof(BatchInst) * (size_t)p->B,
+                         hipMemcpyHostToDevice, p->stream));
+  p->inst_dirty = false;
+  return MPPI_OK;
+}
+
 template <bool EXACT, bool BOUNDED>
 static int launch_rollout_t(mppi_planner* p, DevParams d) {
   const int N = p->n_local, T = p->cfg.num_steps, M = p->cfg.num_grid_samples;
@@ -830,7 +917,9 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
       p->tile_packets_fresh = false;
       size_t lds_win = 0;
       bool have_window = plan_lds_window(p, d, &lds_win);
-      if (have_window && EXACT && BOUNDED) {
+      TRY(upload_instances(p));
+      static const bool no_pipe = getenv("MPPI_NO_PIPE") != nullptr;  // developer switch (ablation)
+      if (have_window && EXACT && BOUNDED && !no_pipe) {
         // pipelined kernel: needs the whole map in LDS, a heading increment small enough for
         // the incremental trig (|dt*w*traction| <= 0.36 rad) and a horizon short enough for it
         const mppi_params& a = p->params;
@@ -841,6 +930,8 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         int pairs = ceil_div(ceil_div(N, 64), p->num_cus);  // wave triples per workgroup
         if (pairs < 1) pairs = 1;
         if (pairs > 5) pairs = 5;                            // 15 waves = 960 threads
+        // batched handle: the triples of a workgroup share one problem's window and controls
+        if (p->inst_set) while (p->inst_tiles % pairs != 0) --pairs;
         const size_t budget = (size_t)p->lds_per_cu - 1024;
         auto ring_bytes = [&](int chunk) {
           return (size_t)pairs * (2 * (size_t)chunk * 64 * (sizeof(float2) + sizeof(double2)) + 2 * (size_t)chunk * 64);
@@ -851,8 +942,14 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
             if (lds_win + ring_bytes(cnd) <= budget) { chunk = cnd; break; }
           if (chunk > 0 || pairs == 1) break;
           --pairs;
+          if (p->inst_set) while (p->inst_tiles % pairs != 0) --pairs;
         }
-        if (std::isfinite(dmax) && dmax <= 0.36 && T <= 2000 && chunk > 0) {
+        // The pipelined kernel is the low-latency choice: it wins while one workgroup per CU covers
+        // the problem with at most three triples (measured, profiles/r01_ablation.md: 1 triple
+        // 53 vs 79 us, 2 triples 76 vs 83 us, 4 triples a tie, two rounds 162 vs 88 us at T=200).
+        // Beyond that the fused kernel below, 4..16 waves per CU, has the better throughput.
+        const bool latency_regime = pairs <= 3 && ceil_div(ceil_div(N, 64), pairs) <= p->num_cus;
+        if (std::isfinite(dmax) && dmax <= 0.36 && T <= 2000 && chunk > 0 && latency_regime) {
           // control-cost products in LDS when there is room, else in a global scratch array
           const size_t cc_bytes = (size_t)pairs * T * 64 * sizeof(double);
           const bool cc_lds = lds_win + ring_bytes(chunk) + cc_bytes <= budget;
@@ -897,9 +994,9 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
             char buf[256];
             snprintf(buf, sizeof(buf),
                      "k_rollout_pipe chunk=%d pow2res=%d cc_lds=%d triples_per_wg=%d window=%dx%d@(%d,%d) lds=%zu "
-                     "noise_blocks=%d",
+                     "noise_blocks=%d problems=%d",
                      chunk, (int)pow2res, (int)cc_lds, pairs, d.win_rows, d.win_cols, d.win_r0, d.win_c0, lds_total,
-                     extra);
+                     extra, p->inst_set ? p->B : 0);
             p->last_rollout = buf;
           }
 #undef MPPI_LAUNCH_PIPE
@@ -907,19 +1004,28 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
           break;
         }
       }
-      if (have_window) {
+      static const bool no_window = getenv("MPPI_NO_WINDOW") != nullptr;  // developer switch (ablation)
+      if (have_window && !no_window) {
         // the window makes it one workgroup per CU: size the workgroup so that the grid
         // is at most one wave of workgroups over the CUs
         // (at least 4 waves: one per SIMD, and four times the lanes to copy the window)
         int waves = ceil_div(ceil_div(N, 64), p->num_cus);
-        int block = 64 * (waves < 4 ? 4 : (waves > 16 ? 16 : waves));
+        waves = waves < 4 ? 4 : (waves > 16 ? 16 : waves);
+        // batched handle: a workgroup stays inside one problem
+        if (p->inst_set) while (p->inst_tiles % waves != 0) --waves;
+        int block = 64 * waves;
         auto kern = k_rollout_map<MAP_DET, EXACT, BOUNDED, true>;
         if (lds_win > 64 * 1024)
           HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
         hipLaunchKernelGGL(kern, dim3(ceil_div(N, block)), dim3(block), lds_win, p->stream, d, p->cells,
                            p->cells16, (const int8_t*)nullptr, p->noise, p->u, p->costs);
-        p->last_rollout = "k_rollout_map det lds_window exact=" + std::to_string((int)EXACT);
+        {
+          char buf[200];
+          snprintf(buf, sizeof(buf), "k_rollout_map det lds_window exact=%d waves_per_wg=%d window=%dx%d problems=%d",
+                   (int)EXACT, waves, d.win_rows, d.win_cols, p->inst_set ? p->B : 0);
+          p->last_rollout = buf;
+        }
       } else {
         hipLaunchKernelGGL((k_rollout_map<MAP_DET, EXACT, BOUNDED, false>), dim3(ceil_div(N, 64)), dim3(64),
                            lds_map, p->stream, d, p->cells, (const uint16_t*)nullptr, (const int8_t*)nullptr,
@@ -930,6 +1036,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
     }
     case MPPI_MODE_SPEED_MAP:
       p->tile_packets_fresh = false;
+      TRY(upload_instances(p));
       hipLaunchKernelGGL((k_rollout_map<MAP_SPEED, EXACT, BOUNDED, false>), dim3(ceil_div(N, 64)), dim3(64),
                          lds_map, p->stream, d, p->cells, (const uint16_t*)nullptr, (const int8_t*)p->risk_ref,
                          p->noise, p->u, p->costs);
@@ -946,6 +1053,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       if (p->want_sample_costs && !p->sample_costs) TRY(dev_alloc(&p->sample_costs, (size_t)N * M));
       p->tile_packets_fresh = false;
+      TRY(upload_instances(p));
       {
         const mppi_params& a = p->params;
         double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
@@ -985,6 +1093,8 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
 }
 
 static int launch_rollout(mppi_planner* p, const DevParams& d) {
+  REQUIRE(p->B == 1 || p->inst_set, MPPI_ERR_STATE,
+          "num_instances = %d: call mppi_planner_set_instances before solving", p->B);
   REQUIRE((size_t)p->cfg.num_steps * sizeof(double2) <= 64 * 1024, MPPI_ERR_INVALID, "num_steps %d too large",
           p->cfg.num_steps);
   // |theta| can never exceed |theta0| + T*dt*max|w|*max(traction): when that is far
@@ -993,7 +1103,12 @@ static int launch_rollout(mppi_planner* p, const DevParams& d) {
   double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
   double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
   if (p->cfg.mode == MPPI_MODE_BAREBONE) trmax = 1.0;
-  double theta_bound = std::fabs((double)a.x0[2]) + (double)p->cfg.num_steps * (double)a.dt * wmax * trmax;
+  double th0_max = std::fabs((double)a.x0[2]);
+  if (p->inst_set) {
+    th0_max = 0.0;
+    for (const BatchInst& I : p->inst_host) th0_max = std::fmax(th0_max, std::fabs((double)I.th0));
+  }
+  double theta_bound = th0_max + (double)p->cfg.num_steps * (double)a.dt * wmax * trmax;
   bool bounded = std::isfinite(theta_bound) && theta_bound < 5.0e4;
   if (p->cfg.math != MPPI_MATH_EXACT) return launch_rollout_t<false, false>(p, d);
   return bounded ? launch_rollout_t<true, true>(p, d) : launch_rollout_t<true, false>(p, d);
@@ -1005,20 +1120,20 @@ static int launch_rollout(mppi_planner* p, const DevParams& d) {
 static int launch_update_local(mppi_planner* p, bool apply_here) {
   const int N = p->n_local, T = p->cfg.num_steps;
   const mppi_params& a = p->params;
-  double* my_packet = p->packets + (size_t)p->cfg.rank * packet_len(T);
+  double* my_packet = p->packets + (size_t)p->cfg.rank * p->B * packet_len(T);
   if (!p->tile_packets_fresh)
     hipLaunchKernelGGL(k_tile_weights, dim3(p->n_tiles), dim3(64), 0, p->stream, p->costs, N, a.lambda_weight,
                        p->w_rel, p->tile_beta);
   p->tile_packets_fresh = false;
-  const size_t lds = sizeof(float) * (size_t)p->n_tiles;
+  const size_t lds = sizeof(float) * (size_t)p->inst_tiles;
   REQUIRE(lds <= 60 * 1024, MPPI_ERR_INVALID, "too many rollouts per GPU for the update kernel (%d)", N);
   if (apply_here)
-    hipLaunchKernelGGL(k_update_rows<true>, dim3(T), dim3(kRowThreads), lds, p->stream, p->w_rel, p->tile_beta, N,
-                       p->n_tiles, p->noise, T, a.lambda_weight, my_packet, p->u, p->u_prev, a.vrange[0],
+    hipLaunchKernelGGL(k_update_rows<true>, dim3(T, p->B), dim3(kRowThreads), lds, p->stream, p->w_rel,
+                       p->tile_beta, p->n_inst, p->inst_tiles, p->noise, T, a.lambda_weight, my_packet, p->u, p->u_prev, a.vrange[0],
                        a.vrange[1], a.wrange[0], a.wrange[1], p->stats);
   else
-    hipLaunchKernelGGL(k_update_rows<false>, dim3(T), dim3(kRowThreads), lds, p->stream, p->w_rel, p->tile_beta, N,
-                       p->n_tiles, p->noise, T, a.lambda_weight, my_packet, p->u, p->u_prev, a.vrange[0],
+    hipLaunchKernelGGL(k_update_rows<false>, dim3(T, p->B), dim3(kRowThreads), lds, p->stream, p->w_rel,
+                       p->tile_beta, p->n_inst, p->inst_tiles, p->noise, T, a.lambda_weight, my_packet, p->u, p->u_prev, a.vrange[0],
                        a.vrange[1], a.wrange[0], a.wrange[1], p->stats);
   HIP_TRY(hipGetLastError());
   return MPPI_OK;
@@ -1026,7 +1141,7 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
 
 static int launch_apply(mppi_planner* p) {
   const mppi_params& a = p->params;
-  hipLaunchKernelGGL(k_apply, dim3(1), dim3(kUpdateThreads), 0, p->stream, p->packets, p->cfg.world_size,
+  hipLaunchKernelGGL(k_apply, dim3(p->B), dim3(kUpdateThreads), 0, p->stream, p->packets, p->cfg.world_size,
                      p->cfg.rank, p->cfg.num_steps, a.lambda_weight, p->u, p->u_prev, a.vrange[0], a.vrange[1],
                      a.wrange[0], a.wrange[1], p->stats);
   HIP_TRY(hipGetLastError());
@@ -1047,9 +1162,9 @@ static int launch_update(mppi_planner* p, bool prof) {
           "world_size %d but no communicator: call mppi_planner_comm_init (or use update_local/update_apply)",
           p->cfg.world_size);
   TRY(launch_update_local(p, false));
-  const int len = packet_len(p->cfg.num_steps);
+  const int len = p->B * packet_len(p->cfg.num_steps);
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[3], p->stream));
-  // one all-gather of (2T+2) doubles per iteration, in place
+  // one all-gather of (2T+2) doubles per problem and iteration, in place
   RCCL_TRY(g_rccl.AllGather(p->packets + (size_t)p->cfg.rank * len, p->packets, (size_t)len, ncclDouble, p->comm,
                             p->stream));
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[4], p->stream));
@@ -1141,9 +1256,10 @@ extern "C" int mppi_planner_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang,
     TRY(tdm_sample_on(ang, alpha, p->stream));
   }
   TRY(run_iterations(p, lin, ang, p->params.num_opt));
-  HIP_TRY(hipMemcpyAsync(u_out, p->u, sizeof(float2) * (size_t)p->cfg.num_steps, hipMemcpyDeviceToHost,
-                         p->stream));
+  const size_t u_bytes = sizeof(float2) * (size_t)p->B * (size_t)p->cfg.num_steps;
+  HIP_TRY(hipMemcpyAsync(p->u_host, p->u, u_bytes, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
+  memcpy(u_out, p->u_host, u_bytes);
   return finish_timing(p);
 }
 
@@ -1229,7 +1345,7 @@ extern "C" int mppi_planner_update(mppi_planner* p) {
 
 extern "C" int mppi_planner_packet_len(mppi_planner* p, int* doubles) {
   REQUIRE(p && doubles, MPPI_ERR_INVALID, "NULL argument");
-  *doubles = packet_len(p->cfg.num_steps);
+  *doubles = p->B * packet_len(p->cfg.num_steps);
   return MPPI_OK;
 }
 
@@ -1238,7 +1354,7 @@ extern "C" int mppi_planner_update_local(mppi_planner* p, double* packet) {
   REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
   HIP_TRY(hipSetDevice(p->cfg.device));
   TRY(launch_update_local(p, false));
-  const int len = packet_len(p->cfg.num_steps);
+  const int len = p->B * packet_len(p->cfg.num_steps);
   HIP_TRY(hipMemcpyAsync(packet, p->packets + (size_t)p->cfg.rank * len, sizeof(double) * (size_t)len,
                          hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
@@ -1249,7 +1365,7 @@ extern "C" int mppi_planner_update_apply(mppi_planner* p, const double* packets,
   REQUIRE(p && packets, MPPI_ERR_INVALID, "NULL argument");
   REQUIRE(count == p->cfg.world_size, MPPI_ERR_INVALID, "expected %d packets, got %d", p->cfg.world_size, count);
   HIP_TRY(hipSetDevice(p->cfg.device));
-  const int len = packet_len(p->cfg.num_steps);
+  const int len = p->B * packet_len(p->cfg.num_steps);
   HIP_TRY(hipMemcpyAsync(p->packets, packets, sizeof(double) * (size_t)len * (size_t)count,
                          hipMemcpyHostToDevice, p->stream));
   TRY(launch_apply(p));
@@ -1261,33 +1377,53 @@ extern "C" int mppi_planner_get_weights(mppi_planner* p, float* weights) {
   REQUIRE(p && weights, MPPI_ERR_INVALID, "NULL argument");
   HIP_TRY(hipSetDevice(p->cfg.device));
   hipLaunchKernelGGL(k_weights_out, dim3(ceil_div(p->n_local, 256)), dim3(256), 0, p->stream, p->costs, p->stats,
-                     p->params.lambda_weight, p->n_local, p->weights_out);
+                     p->params.lambda_weight, p->n_local, p->n_inst, p->weights_out);
   HIP_TRY(hipGetLastError());
   return copy_out(p, weights, p->weights_out, sizeof(float) * (size_t)p->n_local);
 }
 
 extern "C" int mppi_planner_get_state_rollout(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, float* out) {
+  return mppi_planner_get_instance_state_rollout(p, lin, ang, 0, out);
+}
+
+extern "C" int mppi_planner_get_instance_state_rollout(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang,
+                                                       int instance, float* out) {
   REQUIRE(p && out, MPPI_ERR_INVALID, "NULL argument");
   REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
+  REQUIRE(instance >= 0 && instance < p->B, MPPI_ERR_INVALID, "instance %d of %d", instance, p->B);
+  REQUIRE(p->B == 1 || p->inst_set, MPPI_ERR_STATE, "instances not set");
   HIP_TRY(hipSetDevice(p->cfg.device));
   TRY(check_tdms(p, lin, ang));
   TRY(ensure_packed(p, lin, ang));  // uses the already sampled grids (mppi.py:572-573)
   DevParams d = make_dev_params(p, lin, ang);
+  // one problem of a batched handle: its start state, its controls, its slice of the noise
+  struct Rebased {
+    float2 *noise, *u, *u_prev;
+  } view = {p->noise, p->u, p->u_prev};
+  if (p->inst_set) {
+    const BatchInst& I = p->inst_host[(size_t)instance];
+    d.x0 = I.x0; d.y0 = I.y0; d.th0 = I.th0; d.xg = I.xg; d.yg = I.yg;
+    d.inst = nullptr;
+    d.n_local = p->n_inst;
+    view.noise += (size_t)instance * p->inst_tiles * p->cfg.num_steps * 64;
+    view.u += (size_t)instance * p->cfg.num_steps;
+    view.u_prev += (size_t)instance * p->cfg.num_steps;
+  }
   const int V = p->cfg.num_vis_state_rollouts;
   dim3 grid(ceil_div(V, 64)), block(64);
   switch (p->cfg.mode) {
     case MPPI_MODE_TDM:
       REQUIRE(V <= p->cfg.num_grid_samples, MPPI_ERR_INVALID, "V > M");
-      hipLaunchKernelGGL((k_state_rollout<true, false>), grid, block, 0, p->stream, d, p->cells, p->noise,
-                         p->u_prev, p->u, V, p->state_rollout);
+      hipLaunchKernelGGL((k_state_rollout<true, false>), grid, block, 0, p->stream, d, p->cells, view.noise,
+                         view.u_prev, view.u, V, p->state_rollout);
       break;
     case MPPI_MODE_BAREBONE:
-      hipLaunchKernelGGL((k_state_rollout<false, true>), grid, block, 0, p->stream, d, p->cells, p->noise,
-                         p->u_prev, p->u, V, p->state_rollout);
+      hipLaunchKernelGGL((k_state_rollout<false, true>), grid, block, 0, p->stream, d, p->cells, view.noise,
+                         view.u_prev, view.u, V, p->state_rollout);
       break;
     default:
-      hipLaunchKernelGGL((k_state_rollout<false, false>), grid, block, 0, p->stream, d, p->cells, p->noise,
-                         p->u_prev, p->u, V, p->state_rollout);
+      hipLaunchKernelGGL((k_state_rollout<false, false>), grid, block, 0, p->stream, d, p->cells, view.noise,
+                         view.u_prev, view.u, V, p->state_rollout);
   }
   HIP_TRY(hipGetLastError());
   return copy_out(p, out, p->state_rollout, sizeof(float) * (size_t)V * (p->cfg.num_steps + 1) * 3);

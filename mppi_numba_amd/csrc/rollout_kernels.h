@@ -56,7 +56,31 @@ struct DevParams {
   int win_rows, win_cols;  // window size; win_cols is a multiple of 8
   int pitch16;             // row pitch of the global 16-bit cell array (multiple of 8)
   int lin_max_byte, ang_max_byte;  // host-side bounds only (largest traction byte in the grids)
+  // batched multi-query handle: per-problem start / goal / window origin, else nullptr
+  const struct BatchInst* inst;
+  int inst_tiles;  // tiles of 64 rollouts per problem
+  int n_inst;      // rollouts per problem on this GPU
 };
+
+// What differs between the problems of a batched handle (mppi_planner_set_instances).
+struct BatchInst {
+  float x0, y0, th0;
+  float xg, yg;
+  int win_r0, win_c0;  // the LDS window is planned around each start state
+  int pad;
+};
+
+// Problem b of a batched handle: patch the by-value parameters and return its control
+// sequence.  b is uniform over the workgroup, so these are scalar loads; a single-problem
+// handle (inst == nullptr) pays one uniform branch.
+__device__ __forceinline__ const float2* select_instance(DevParams& P, const float2* __restrict__ u, int b) {
+  if (P.inst == nullptr) return u;
+  const BatchInst I = P.inst[b];
+  P.x0 = I.x0; P.y0 = I.y0; P.th0 = I.th0;
+  P.xg = I.xg; P.yg = I.yg;
+  P.win_r0 = I.win_r0; P.win_c0 = I.win_c0;
+  return u + (size_t)b * P.n_steps;
+}
 
 // u[t]/std^2 (float64) for the control-cost term, staged in LDS once per block
 __device__ __forceinline__ void stage_control_ratios(const DevParams& P, const float2* __restrict__ u,
@@ -225,6 +249,8 @@ __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
                               const float2* __restrict__ noise, const float2* __restrict__ u,
                               float* __restrict__ costs) {
   extern __shared__ double2 uos[];
+  // batched handle: the waves of a workgroup belong to one problem (host: blockDim/64 divides inst_tiles)
+  u = select_instance(P, u, P.inst ? (int)(blockIdx.x * (blockDim.x >> 6)) / P.inst_tiles : 0);
   float2* us = reinterpret_cast<float2*>(uos + P.n_steps);  // u[t] staged next to the ratios
   // 16-byte aligned start of the map window
   uint16_t* lds_map = reinterpret_cast<uint16_t*>(uos + P.n_steps + (P.n_steps + 1) / 2);
@@ -337,6 +363,8 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
   // the same SIMDs: win the issue arbitration against them
   __builtin_amdgcn_s_setprio(3);
   const int T = P.n_steps, N = P.n_local;
+  // batched handle: all triples of a workgroup belong to one problem (host: W divides inst_tiles)
+  u = select_instance(P, u, P.inst ? (int)(blockIdx.x * (blockDim.x / 192)) / P.inst_tiles : 0);
   float2* us = reinterpret_cast<float2*>(uos + T);
   uint16_t* lds_map = reinterpret_cast<uint16_t*>(uos + T + (T + 1) / 2);
   char* ring_base = reinterpret_cast<char*>(lds_map) + map_bytes;
@@ -529,6 +557,7 @@ __global__ void k_rollout_tdm(DevParams P, const uint32_t* __restrict__ cellsM,
                               float* __restrict__ costs, float* __restrict__ sample_costs, int m_pow2) {
   extern __shared__ double2 uos[];
   float* sc = reinterpret_cast<float*>(uos + P.n_steps);
+  u = select_instance(P, u, P.inst ? (int)blockIdx.x / P.n_inst : 0);
   stage_control_ratios(P, u, uos);
   const int n = blockIdx.x;
   const int N = P.n_local, T = P.n_steps, M = P.n_grids;
@@ -619,6 +648,7 @@ __global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cel
   double* cc_sh = reinterpret_cast<double*>(qd_sh + T);
   float* sc = reinterpret_cast<float*>(cc_sh + T);
   const int n = blockIdx.x;
+  u = select_instance(P, u, P.inst ? n / P.n_inst : 0);
   const double dt64 = (double)P.dt;
   for (int t = threadIdx.x; t < T; t += blockDim.x) {
     float2 ut = u[t];

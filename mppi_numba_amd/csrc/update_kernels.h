@@ -77,6 +77,8 @@ __global__ __launch_bounds__(64) void k_tile_weights(const float* __restrict__ c
 //   APPLY  (single GPU): u[t] = clip(u[t] + num/den)
 //   !APPLY (one of several GPUs): num -> this rank's packet for the all-gather.
 // stats[0] = beta, stats[1] = den (for the normalised weights the host may ask for).
+// Batched handle: blockIdx.y = problem b, which owns rollouts [b*n, (b+1)*n), tiles
+// [b*n_tiles, (b+1)*n_tiles), u[b], stats[b], packet segment b.
 constexpr int kRowThreads = 1024;
 
 template <bool APPLY>
@@ -91,6 +93,16 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
   __shared__ double red[kRowThreads / 64][3];
   __shared__ float redf[kRowThreads / 64];
   const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  {
+    const int inst = blockIdx.y;
+    w_rel += (size_t)inst * n;
+    tile_beta += (size_t)inst * n_tiles;
+    noise += (size_t)inst * n_tiles * n_steps * 64;  // tile-major: whole tiles per problem
+    rank_packet += (size_t)inst * packet_len(n_steps);
+    u += (size_t)inst * n_steps;
+    u_prev += (size_t)inst * n_steps;
+    stats += 2 * inst;
+  }
   float b = __builtin_inff();
   for (int g = threadIdx.x; g < n_tiles; g += kRowThreads) b = fminf(b, tile_beta[g]);
   b = wave_min_f32(b);
@@ -143,19 +155,24 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
   }
 }
 
-// combine the packets of all ranks (identical on every GPU, fixed g order)
+// combine the packets of all ranks (identical on every GPU, fixed g order).
+// Batched handle: blockIdx.x = problem b; rank g's packet for it is packets[(g*B + b)*len].
 __global__ __launch_bounds__(kUpdateThreads) void k_apply(const double* __restrict__ packets, int world,
                                                           int rank, int n_steps, float lambda,
                                                           float2* __restrict__ u, float2* __restrict__ u_prev,
                                                           float v_lo, float v_hi, float w_lo, float w_hi,
                                                           double* __restrict__ stats) {
   const int len = packet_len(n_steps);
+  const size_t stride = (size_t)gridDim.x * len;  // doubles per rank
+  packets += (size_t)blockIdx.x * len;
+  u += (size_t)blockIdx.x * n_steps;
+  u_prev += (size_t)blockIdx.x * n_steps;
+  stats += 2 * blockIdx.x;
   double beta = packets[0];
-  for (int g = 1; g < world; ++g) beta = fmin(beta, packets[(size_t)g * len]);
+  for (int g = 1; g < world; ++g) beta = fmin(beta, packets[g * stride]);
   const double neg_inv_lambda = -1.0 / (double)lambda;
   double den = 0.0;
-  for (int g = 0; g < world; ++g)
-    den += exp(neg_inv_lambda * (packets[(size_t)g * len] - beta)) * packets[(size_t)g * len + 1];
+  for (int g = 0; g < world; ++g) den += exp(neg_inv_lambda * (packets[g * stride] - beta)) * packets[g * stride + 1];
   if (threadIdx.x == 0) {
     stats[0] = beta;
     stats[1] = den;
@@ -163,9 +180,9 @@ __global__ __launch_bounds__(kUpdateThreads) void k_apply(const double* __restri
   for (int t = threadIdx.x; t < n_steps; t += kUpdateThreads) {
     double nx = 0.0, ny = 0.0;
     for (int g = 0; g < world; ++g) {
-      double sg = exp(neg_inv_lambda * (packets[(size_t)g * len] - beta));
-      nx = fma(sg, packets[(size_t)g * len + 2 + 2 * t], nx);
-      ny = fma(sg, packets[(size_t)g * len + 3 + 2 * t], ny);
+      double sg = exp(neg_inv_lambda * (packets[g * stride] - beta));
+      nx = fma(sg, packets[g * stride + 2 + 2 * t], nx);
+      ny = fma(sg, packets[g * stride + 3 + 2 * t], ny);
     }
     apply_update(u, u_prev, t, nx, ny, den, v_lo, v_hi, w_lo, w_hi);
   }
@@ -174,15 +191,18 @@ __global__ __launch_bounds__(kUpdateThreads) void k_apply(const double* __restri
 // normalised weights for the host (weights_d of the reference), on demand:
 // w_n = exp(-(c_n - beta)/lambda) / den with the global beta and den of the last update
 __global__ void k_weights_out(const float* __restrict__ costs, const double* __restrict__ stats, float lambda,
-                              int n, float* __restrict__ out) {
+                              int n, int n_inst, float* __restrict__ out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (float)(exp(-1.0 / (double)lambda * ((double)costs[i] - stats[0])) / stats[1]);
+  if (i >= n) return;
+  const double* st = stats + 2 * (i / n_inst);  // {beta, den} of the problem this rollout belongs to
+  out[i] = (float)(exp(-1.0 / (double)lambda * ((double)costs[i] - st[0])) / st[1]);
 }
 
 // device-side shift of the control sequence: u[:-k] = u[k:], tail kept (mppi.py:539-541)
 __global__ void k_shift_u(float2* __restrict__ u, int n_steps, int k) {
-  // single block: read everything, barrier, write
+  // one block per problem: read everything, barrier, write
   extern __shared__ float2 tmp[];
+  u += (size_t)blockIdx.x * n_steps;
   for (int t = threadIdx.x; t < n_steps; t += blockDim.x) tmp[t] = u[t];
   __syncthreads();
   for (int t = threadIdx.x; t + k < n_steps; t += blockDim.x) u[t] = tmp[t + k];

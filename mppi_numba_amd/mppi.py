@@ -61,6 +61,8 @@ class MPPI_Numba(object):
         # multi-GPU extension: this object owns rollouts [rank*N/world, (rank+1)*N/world)
         self.rank = int(rank)
         self.world_size = int(world_size)
+        # batched multi-query extension (batch.py): problems solved by this handle
+        self.num_instances = int(getattr(self, "num_instances", 1))
 
         self._handle = None
         self.noise_samples_d = None
@@ -123,18 +125,23 @@ class MPPI_Numba(object):
             num_vis_state_rollouts=int(self.num_vis_state_rollouts),
             rng=_lib.RNG_XOROSHIRO if getattr(self.cfg, "rng", "philox") == "xoroshiro" else _lib.RNG_PHILOX,
             math=_lib.MATH_FAST if getattr(self.cfg, "math", "exact") == "fast" else _lib.MATH_EXACT,
-            rank=self.rank, world_size=self.world_size, seed=int(self.seed))
+            rank=self.rank, world_size=self.world_size, num_instances=self.num_instances,
+            seed=int(self.seed))
         handle = C.c_void_p()
         _lib.call("mppi_planner_create", C.byref(cfg), C.byref(handle))
         self._handle = handle
-        self.num_local_rollouts = self.num_control_rollouts // self.world_size
+        # per-GPU rollouts; a batched handle stacks its problems: (B*n_per_problem, ...)
+        self.num_local_rollouts = self.num_instances * (self.num_control_rollouts // self.world_size)
         n, t, v = self.num_local_rollouts, self.num_steps, self.num_vis_state_rollouts
+        lead = () if self.num_instances == 1 else (self.num_instances,)
+        ushape = lead + (t, 2)
+        cshape = (n,) if self.num_instances == 1 else (self.num_instances, n // self.num_instances)
         self.noise_samples_d = DeviceArray((n, t, 2), np.float32, lambda: self._fetch("mppi_planner_get_noise", (n, t, 2)))
-        self.u_cur_d = DeviceArray((t, 2), np.float32, lambda: self._fetch("mppi_planner_get_u", (t, 2)))
-        self._u_prev_view = DeviceArray((t, 2), np.float32, lambda: self._fetch("mppi_planner_get_u_prev", (t, 2)))
+        self.u_cur_d = DeviceArray(ushape, np.float32, lambda: self._fetch("mppi_planner_get_u", ushape))
+        self._u_prev_view = DeviceArray(ushape, np.float32, lambda: self._fetch("mppi_planner_get_u_prev", ushape))
         self.u_prev_d = self._u_prev_view
-        self.costs_d = DeviceArray((n,), np.float32, lambda: self._fetch("mppi_planner_get_costs", (n,)))
-        self.weights_d = DeviceArray((n,), np.float32, lambda: self._fetch("mppi_planner_get_weights", (n,)))
+        self.costs_d = DeviceArray(cshape, np.float32, lambda: self._fetch("mppi_planner_get_costs", cshape))
+        self.weights_d = DeviceArray(cshape, np.float32, lambda: self._fetch("mppi_planner_get_weights", cshape))
         self.rng_states_d = DeviceArray((self._rng_state_count(), 2), np.uint64, self._fetch_rng_states)
         self.state_rollout_batch_d = DeviceArray((v, t + 1, 3), np.float32, lambda: self._last_state_rollout.copy())
         self._last_state_rollout = np.zeros((v, t + 1, 3), dtype=np.float32)
@@ -261,7 +268,8 @@ class MPPI_Numba(object):
 
     def _solve(self):
         self.move_mppi_task_vars_to_device()
-        useq = np.empty((self.num_steps, 2), dtype=np.float32)
+        lead = () if self.num_instances == 1 else (self.num_instances,)
+        useq = np.empty(lead + (self.num_steps, 2), dtype=np.float32)
         _lib.call("mppi_planner_solve", self._handle, self.lin_tdm._handle, self.ang_tdm._handle,
                   _lib.ptr(useq, C.c_float))
         self.u_prev_d = self._u_prev_view  # the reference aliases u_prev_d to u_cur_d in the loop
@@ -302,7 +310,7 @@ class MPPI_Numba(object):
         _lib.call("mppi_planner_shift_u", self._handle, int(num_shifts))
 
     def set_u(self, u):
-        u = np.ascontiguousarray(u, dtype=np.float32).reshape(self.num_steps, 2)
+        u = np.ascontiguousarray(u, dtype=np.float32).reshape(self.num_instances * self.num_steps, 2)
         _lib.call("mppi_planner_set_u", self._handle, _lib.ptr(u, C.c_float))
 
     def sample_noise(self):

@@ -257,11 +257,14 @@ def custom_world(rows, cols, res, seed):
      ["k_rollout_pipe", "pow2res=0"]),
     ("resolution 0.1: cell borders every few float32 ulps", 200, 200, 0.1, 2048, 80, (7.33, 8.21, -2.0), 3.0,
      ["k_rollout_pipe", "pow2res=0", "cc_lds=1"]),
-    ("four wave triples per workgroup", 256, 256, 0.25, 65536, 40, (20.0, 30.0, 0.3), 5.0,
-     ["k_rollout_pipe", "triples_per_wg=4"]),
-    ("long horizon: whole-map window, fewer triples per workgroup than CUs would like, smallest chunk",
-     256, 256, 0.25, 65536, 120, (30.0, 30.0, 0.3), 5.0,
-     ["k_rollout_pipe", "triples_per_wg=3", "chunk=2", "cc_lds=0", "noise_blocks=0"]),
+    ("two wave triples per workgroup", 256, 256, 0.25, 32768, 40, (20.0, 30.0, 0.3), 5.0,
+     ["k_rollout_pipe", "triples_per_wg=2"]),
+    ("three wave triples per workgroup, ragged last tile", 256, 256, 0.25, 49152 - 37, 40, (20.0, 30.0, 0.3), 5.0,
+     ["k_rollout_pipe", "triples_per_wg=3"]),
+    ("throughput regime: fused kernel on the LDS window, 4 waves per CU", 256, 256, 0.25, 65536, 40,
+     (20.0, 30.0, 0.3), 5.0, ["k_rollout_map det lds_window", "waves_per_wg=4"]),
+    ("throughput regime, long horizon: whole-map window, 8 waves per CU", 256, 256, 0.25, 131072, 120,
+     (30.0, 30.0, 0.3), 5.0, ["k_rollout_map det lds_window", "waves_per_wg=8", "window=260x264"]),
     ("reach window larger than LDS: global 32-bit cell path", 700, 700, 0.05, 2048, 100, (17.0, 18.0, 1.0), 3.0,
      ["k_rollout_map det global_cells"]),
     ("whole-map window, control-cost products in global scratch", 270, 250, 0.25, 2048, 200, (30.0, 33.0, 0.0), 5.0,
