@@ -414,7 +414,11 @@ struct mppi_planner {
   // device buffers
   float2* noise = nullptr;    // tile-major (n_local, T): the buffer the NEXT rollout/update reads
   float2* noise_buf[2] = {nullptr, nullptr};  // double buffer: noise of iteration k+1 is generated
-  int noise_cur = 0;                           // on noise_stream while iteration k runs
+  int noise_cur = 0;                           // while iteration k runs (in-launch or on noise_stream)
+  // throughput regime: no CU is idle during the rollout, but the rollout is issue-bound and the
+  // generator write-bound, so the noise of iteration k+1 runs beside rollout k on a second stream
+  hipStream_t noise_stream = nullptr;
+  hipEvent_t ev_buf_free = nullptr, ev_noise_ready = nullptr;
   std::string last_rollout;        // which rollout kernel variant the last launch used (diagnostic)
   bool next_noise_wanted = false;  // the coming rollout launch should also generate noise_buf[cur^1]
   bool next_noise_done = false;    // ... and it did
@@ -496,6 +500,12 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   if (p->ev_end) (void)hipEventDestroy(p->ev_end);
   for (auto& e : p->ev_stage)
     if (e) (void)hipEventDestroy(e);
+  if (p->noise_stream) {
+    (void)hipStreamSynchronize(p->noise_stream);
+    (void)hipStreamDestroy(p->noise_stream);
+  }
+  if (p->ev_buf_free) (void)hipEventDestroy(p->ev_buf_free);
+  if (p->ev_noise_ready) (void)hipEventDestroy(p->ev_noise_ready);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
   return MPPI_OK;
@@ -505,6 +515,9 @@ static int planner_alloc(mppi_planner* p) {
   const mppi_planner_cfg& c = p->cfg;
   const size_t N = (size_t)p->n_local, T = (size_t)c.num_steps;
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&p->noise_stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&p->ev_buf_free, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&p->ev_noise_ready, hipEventDisableTiming));
   HIP_TRY(hipEventCreate(&p->ev_begin));
   HIP_TRY(hipEventCreate(&p->ev_end));
   for (auto& e : p->ev_stage) HIP_TRY(hipEventCreate(&e));
@@ -824,10 +837,10 @@ static NoiseJob make_noise_job(mppi_planner* p, float2* target) {
   return j;
 }
 
-static int launch_noise(mppi_planner* p, float2* target) {
+static int launch_noise(mppi_planner* p, float2* target, hipStream_t stream = nullptr) {
   long total = (long)noise_items(p->n_local, p->cfg.num_steps, p->cfg.rng == MPPI_RNG_PHILOX);  // one thread per item
   NoiseJob job = make_noise_job(p, target);
-  hipLaunchKernelGGL(k_noise, dim3(ceil_div(total, 256)), dim3(256), 0, p->stream, job);
+  hipLaunchKernelGGL(k_noise, dim3(ceil_div(total, 256)), dim3(256), 0, stream ? stream : p->stream, job);
   HIP_TRY(hipGetLastError());
   return MPPI_OK;
 }
@@ -1180,7 +1193,13 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
   // The noise of iteration k+1 does not depend on iteration k.  When the pipelined rollout
   // kernel runs, its spare workgroups generate it into the other half of the double buffer
   // (same launch, no extra dependency); otherwise it is generated in line.
-  bool have_noise = false;
+  bool have_noise = false, noise_on_side_stream = false;
+  // (below ~4M rollout-steps the generator takes less than the ~12 us a cross-stream dependency costs)
+  static const bool no_side_stream = getenv("MPPI_NO_SIDE_STREAM") != nullptr;  // developer switch
+  // and above 8 rollout waves per CU the register file has no room for the generator's waves: it
+  // then runs in the rollout's tail and collides with the update (measured, profiles/r01_ablation.md)
+  const bool side_stream_pays = (long)p->n_local * p->cfg.num_steps >= 4L * 1000 * 1000 &&
+                                ceil_div(ceil_div(p->n_local, 64), p->num_cus) <= 8 && !no_side_stream;
   for (int k = 0; k < iterations; ++k) {
     // profiled iteration: a steady-state one when there is one (its rollout launch then
     // also carries the noise of the following iteration), else the last
@@ -1188,6 +1207,8 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
     if (prof) HIP_TRY(hipEventRecord(p->ev_stage[0], p->stream));
     if (have_noise) {
       p->noise_cur ^= 1;
+      if (noise_on_side_stream) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_noise_ready, 0));
+      noise_on_side_stream = false;
     } else {
       TRY(launch_noise(p, p->noise_buf[p->noise_cur]));
     }
@@ -1195,8 +1216,16 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
     p->next_noise_wanted = (k + 1 < iterations);
     p->next_noise_done = false;
     if (prof) HIP_TRY(hipEventRecord(p->ev_stage[1], p->stream));
+    // the other noise buffer was last read by the previous update, which is behind us on this stream
+    if (p->next_noise_wanted && side_stream_pays) HIP_TRY(hipEventRecord(p->ev_buf_free, p->stream));
     TRY(launch_rollout(p, d));
     have_noise = p->next_noise_done;
+    if (p->next_noise_wanted && !have_noise && side_stream_pays) {
+      HIP_TRY(hipStreamWaitEvent(p->noise_stream, p->ev_buf_free, 0));
+      TRY(launch_noise(p, p->noise_buf[p->noise_cur ^ 1], p->noise_stream));
+      HIP_TRY(hipEventRecord(p->ev_noise_ready, p->noise_stream));
+      have_noise = noise_on_side_stream = true;
+    }
     p->next_noise_wanted = false;
     if (prof) HIP_TRY(hipEventRecord(p->ev_stage[2], p->stream));
     TRY(launch_update(p, prof));

@@ -307,3 +307,24 @@ def test_det_rollout_variants_vs_oracle(label, rows, cols, res, n, t_steps, x0, 
     planner.update()
     _, u_ref, _ = O.update_useq(params["lambda_weight"], want, noise, params["vrange"], params["wrange"], u_in)
     assert (np.abs(planner.u_cur_d.copy_to_host() - u_ref) / np.array([3.0, np.pi])).max() <= 1e-5, label
+
+
+def test_overlapped_noise_generation_equals_in_line_generation():
+    """In the throughput regime the noise of iteration k+1 is generated on a second stream
+    beside rollout k.  Philox is counter-based: the overlapped loop must produce exactly
+    the controls of the same iterations driven one stage at a time."""
+    n = 65536  # x T=200: 13M rollout-steps, above the side-stream threshold
+    _, _, _, _, fused, _ = build("c4", n)
+    _, _, _, _, staged, _ = build("c4", n)
+    for planner in (fused, staged):
+        assert planner.num_steps == 200
+    fused.solve()
+    fused.iterate_async(4)
+    fused.synchronize()
+    staged.solve()
+    for _ in range(4):
+        staged.sample_noise()
+        staged.rollout()
+        staged.update()
+    assert np.array_equal(fused.u_cur_d.copy_to_host(), staged.u_cur_d.copy_to_host())
+    assert np.array_equal(fused.noise_samples_d.copy_to_host(), staged.noise_samples_d.copy_to_host())
