@@ -1140,14 +1140,18 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
   p->tile_packets_fresh = false;
   const size_t lds = sizeof(float) * (size_t)p->inst_tiles;
   REQUIRE(lds <= 60 * 1024, MPPI_ERR_INVALID, "too many rollouts per GPU for the update kernel (%d)", N);
-  if (apply_here)
-    hipLaunchKernelGGL(k_update_rows<true>, dim3(T, p->B), dim3(kRowThreads), lds, p->stream, p->w_rel,
-                       p->tile_beta, p->n_inst, p->inst_tiles, p->noise, T, a.lambda_weight, my_packet, p->u, p->u_prev, a.vrange[0],
-                       a.vrange[1], a.wrange[0], a.wrange[1], p->stats);
-  else
-    hipLaunchKernelGGL(k_update_rows<false>, dim3(T, p->B), dim3(kRowThreads), lds, p->stream, p->w_rel,
-                       p->tile_beta, p->n_inst, p->inst_tiles, p->noise, T, a.lambda_weight, my_packet, p->u, p->u_prev, a.vrange[0],
-                       a.vrange[1], a.wrange[0], a.wrange[1], p->stats);
+  // rows per workgroup: see k_update_rows
+  const bool many_rows = (long)T * p->B >= 2048;
+  const dim3 grid(many_rows ? ceil_div(T, 4) : T, p->B);
+#define MPPI_LAUNCH_ROWS(APPLY, TC)                                                                             \
+  hipLaunchKernelGGL((k_update_rows<APPLY, TC>), grid, dim3(kRowThreads), lds, p->stream, p->w_rel, p->tile_beta, \
+                     p->n_inst, p->inst_tiles, p->noise, T, a.lambda_weight, my_packet, p->u, p->u_prev,        \
+                     a.vrange[0], a.vrange[1], a.wrange[0], a.wrange[1], p->stats)
+  if (apply_here && many_rows) MPPI_LAUNCH_ROWS(true, 4);
+  else if (apply_here) MPPI_LAUNCH_ROWS(true, 1);
+  else if (many_rows) MPPI_LAUNCH_ROWS(false, 4);
+  else MPPI_LAUNCH_ROWS(false, 1);
+#undef MPPI_LAUNCH_ROWS
   HIP_TRY(hipGetLastError());
   return MPPI_OK;
 }

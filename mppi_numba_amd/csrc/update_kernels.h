@@ -81,7 +81,12 @@ __global__ __launch_bounds__(64) void k_tile_weights(const float* __restrict__ c
 // [b*n_tiles, (b+1)*n_tiles), u[b], stats[b], packet segment b.
 constexpr int kRowThreads = 1024;
 
-template <bool APPLY>
+// TC rows per workgroup: 1 keeps the workgroup count up when there are few rows (one problem,
+// latency matters); 4 amortises the minimum / scale prologue and the reductions when the
+// grid would otherwise be thousands of short-lived workgroups (batched handles).  Each
+// thread sums its strided subset in increasing i whatever TC and UN are, so the result does
+// not depend on them.
+template <bool APPLY, int TC>
 __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __restrict__ w_rel,
                                                              const float* __restrict__ tile_beta, int n, int n_tiles,
                                                              const float2* __restrict__ noise, int n_steps,
@@ -90,9 +95,10 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
                                                              float v_lo, float v_hi, float w_lo, float w_hi,
                                                              double* __restrict__ stats) {
   extern __shared__ float scale_sh[];  // [n_tiles]
-  __shared__ double red[kRowThreads / 64][3];
+  constexpr int kCols = 1 + 2 * TC;    // den, then (x, y) per row
+  __shared__ double red[kRowThreads / 64][kCols];
   __shared__ float redf[kRowThreads / 64];
-  const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = blockIdx.x * TC, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   {
     const int inst = blockIdx.y;
     w_rel += (size_t)inst * n;
@@ -114,43 +120,83 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
   for (int g = threadIdx.x; g < n_tiles; g += kRowThreads)
     scale_sh[g] = (float)exp(neg_inv_lambda * (double)(tile_beta[g] - beta));
   __syncthreads();
-  double den = 0.0, nx = 0.0, ny = 0.0;
-  for (int i = threadIdx.x; i < n; i += kRowThreads) {  // kRowThreads is a multiple of 64: i>>6 is the tile
+  double den = 0.0, nx[TC], ny[TC];
+#pragma unroll
+  for (int j = 0; j < TC; ++j) nx[j] = ny[j] = 0.0;
+  // rows past the horizon (last workgroup) are clamped for the loads and never written
+  size_t row_off[TC];
+#pragma unroll
+  for (int j = 0; j < TC; ++j) row_off[j] = (size_t)min(t0 + j, n_steps - 1) * 64;
+  constexpr int UN = TC == 1 ? 8 : 2;  // independent loads in flight per thread: UN * (TC + 1)
+  int i = threadIdx.x;                 // kRowThreads is a multiple of 64: i>>6 is the tile, i&63 the lane
+  for (; i + (UN - 1) * kRowThreads < n; i += UN * kRowThreads) {
+    float wr[UN];
+    float2 e[UN][TC];
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      const int idx = i + k * kRowThreads;
+      wr[k] = w_rel[idx];
+      const float2* tile = noise + (size_t)(idx >> 6) * n_steps * 64 + (idx & 63);
+#pragma unroll
+      for (int j = 0; j < TC; ++j) e[k][j] = tile[row_off[j]];
+    }
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      double w = (double)scale_sh[(i + k * kRowThreads) >> 6] * (double)wr[k];
+      den += w;
+#pragma unroll
+      for (int j = 0; j < TC; ++j) {
+        nx[j] = fma(w, (double)e[k][j].x, nx[j]);
+        ny[j] = fma(w, (double)e[k][j].y, ny[j]);
+      }
+    }
+  }
+  for (; i < n; i += kRowThreads) {
     double w = (double)scale_sh[i >> 6] * (double)w_rel[i];
-    float2 e = noise[tile_index(t, i, n_steps)];
+    const float2* tile = noise + (size_t)(i >> 6) * n_steps * 64 + (i & 63);
     den += w;
-    nx = fma(w, (double)e.x, nx);
-    ny = fma(w, (double)e.y, ny);
+#pragma unroll
+    for (int j = 0; j < TC; ++j) {
+      float2 e = tile[row_off[j]];
+      nx[j] = fma(w, (double)e.x, nx[j]);
+      ny[j] = fma(w, (double)e.y, ny[j]);
+    }
   }
   den = wave_sum_f64(den);
-  nx = wave_sum_f64(nx);
-  ny = wave_sum_f64(ny);
+#pragma unroll
+  for (int j = 0; j < TC; ++j) {
+    nx[j] = wave_sum_f64(nx[j]);
+    ny[j] = wave_sum_f64(ny[j]);
+  }
   if (lane == 0) {
     red[wave][0] = den;
-    red[wave][1] = nx;
-    red[wave][2] = ny;
+#pragma unroll
+    for (int j = 0; j < TC; ++j) {
+      red[wave][1 + 2 * j] = nx[j];
+      red[wave][2 + 2 * j] = ny[j];
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int k = 1; k < kRowThreads / 64; ++k) {
-      red[0][0] += red[k][0];
-      red[0][1] += red[k][1];
-      red[0][2] += red[k][2];
-    }
-    den = red[0][0];
-    nx = red[0][1];
-    ny = red[0][2];
+  if (threadIdx.x < kCols) {  // fixed wave order: ((w0 + w1) + w2) + ...
+    double acc = red[0][threadIdx.x];
+    for (int k = 1; k < kRowThreads / 64; ++k) acc += red[k][threadIdx.x];
+    red[0][threadIdx.x] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < TC && t0 + (int)threadIdx.x < n_steps) {
+    const int j = threadIdx.x, t = t0 + j;
+    const double d = red[0][0], sx = red[0][1 + 2 * j], sy = red[0][2 + 2 * j];
     if (APPLY) {
-      apply_update(u, u_prev, t, nx, ny, den, v_lo, v_hi, w_lo, w_hi);
+      apply_update(u, u_prev, t, sx, sy, d, v_lo, v_hi, w_lo, w_hi);
     } else {
-      rank_packet[2 + 2 * t] = nx;
-      rank_packet[3 + 2 * t] = ny;
+      rank_packet[2 + 2 * t] = sx;
+      rank_packet[3 + 2 * t] = sy;
     }
     if (t == 0) {
       rank_packet[0] = (double)beta;
-      rank_packet[1] = den;
+      rank_packet[1] = d;
       stats[0] = (double)beta;
-      stats[1] = den;
+      stats[1] = d;
     }
   }
 }
