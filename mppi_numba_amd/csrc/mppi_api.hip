@@ -932,13 +932,20 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
       bool have_window = plan_lds_window(p, d, &lds_win);
       TRY(upload_instances(p));
       static const bool no_pipe = getenv("MPPI_NO_PIPE") != nullptr;  // developer switch (ablation)
-      if (have_window && EXACT && BOUNDED && !no_pipe) {
-        // pipelined kernel: needs the whole map in LDS, a heading increment small enough for
-        // the incremental trig (|dt*w*traction| <= 0.36 rad) and a horizon short enough for it
+      // incremental trig: needs a heading increment |dt*w*traction| <= 0.36 rad and T <= 2000
+      bool rot_ok = false, pow2res = false;
+      {
         const mppi_params& a = p->params;
         double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
         double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
         double dmax = (double)a.dt * wmax * trmax;
+        rot_ok = EXACT && BOUNDED && std::isfinite(dmax) && dmax <= 0.36 && T <= 2000;
+        int res_exp = 0;
+        pow2res = std::frexp((double)a.res, &res_exp) == 0.5;  // res == 2^k exactly
+      }
+      if (have_window && rot_ok && !no_pipe) {
+        // pipelined kernel: the map window in LDS + the incremental trig
+        const mppi_params& a = p->params;
         const size_t map_bytes = lds_win - sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);
         int pairs = ceil_div(ceil_div(N, 64), p->num_cus);  // wave triples per workgroup
         if (pairs < 1) pairs = 1;
@@ -962,7 +969,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         // 53 vs 79 us, 2 triples 76 vs 83 us, 4 triples a tie, two rounds 162 vs 88 us at T=200).
         // Beyond that the fused kernel below, 4..16 waves per CU, has the better throughput.
         const bool latency_regime = pairs <= 3 && ceil_div(ceil_div(N, 64), pairs) <= p->num_cus;
-        if (std::isfinite(dmax) && dmax <= 0.36 && T <= 2000 && chunk > 0 && latency_regime) {
+        if (chunk > 0 && latency_regime) {
           // control-cost products in LDS when there is room, else in a global scratch array
           const size_t cc_bytes = (size_t)pairs * T * 64 * sizeof(double);
           const bool cc_lds = lds_win + ring_bytes(chunk) + cc_bytes <= budget;
@@ -980,8 +987,6 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
             p->next_noise_done = true;
           }
           if (!cc_lds && !p->cc_scratch) TRY(dev_alloc(&p->cc_scratch, (size_t)ceil_div(N, 64) * 64 * T));
-          int res_exp = 0;
-          const bool pow2res = std::frexp((double)a.res, &res_exp) == 0.5;  // res == 2^k exactly
 #define MPPI_LAUNCH_PIPE(CH, P2, CL)                                                                  \
   do {                                                                                                \
     auto kern = k_rollout_pipe<CH, P2, CL>;                                                           \
@@ -1027,6 +1032,21 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         // batched handle: a workgroup stays inside one problem
         if (p->inst_set) while (p->inst_tiles % waves != 0) --waves;
         int block = 64 * waves;
+        static const bool no_fused = getenv("MPPI_NO_FUSED") != nullptr;  // developer switch (ablation)
+        if (rot_ok && !no_fused) {
+          auto fused = pow2res ? k_rollout_fused<true> : k_rollout_fused<false>;
+          if (lds_win > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fused),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
+          hipLaunchKernelGGL(fused, dim3(ceil_div(N, block)), dim3(block), lds_win, p->stream, d, p->cells16,
+                             p->noise, p->u, p->costs, p->w_rel, p->tile_beta);
+          char buf[200];
+          snprintf(buf, sizeof(buf), "k_rollout_fused pow2res=%d waves_per_wg=%d window=%dx%d problems=%d",
+                   (int)pow2res, waves, d.win_rows, d.win_cols, p->inst_set ? p->B : 0);
+          p->last_rollout = buf;
+          p->tile_packets_fresh = true;
+          break;
+        }
         auto kern = k_rollout_map<MAP_DET, EXACT, BOUNDED, true>;
         if (lds_win > 64 * 1024)
           HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -306,6 +306,116 @@ __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
 }
 
 // -------------------------------------------------------------------------
+// Throughput variant of the deterministic rollout (MPPI_MODE_DET, exact math, LDS
+// window, bounded heading increment): one wave per 64 rollouts, 4..16 waves per CU.
+// When there are more tiles than a single round of the pipelined kernel below can
+// take, latency no longer matters and the SIMDs are bound by instruction issue; this
+// kernel is k_rollout_map<DET, true, true, true> with the per-step instruction count
+// cut from ~190 to ~120 by the same exact rewrites the pipelined kernel uses:
+//   * (cos, sin) rotated by the exact increment of the float32-rounded heading instead
+//     of a full sincos (|increment| <= 0.36 rad, T <= 2000: host-checked),
+//   * branch-free Newton sqrt, 24-bit window index, floor instead of the exact floor
+//     division when the resolution is a power of two.
+// Rounding points are those of the reference (mppi.py:977-1009): float64 products,
+// float32 stores of x, y, theta and of the running cost.  After the goal is reached the
+// state keeps integrating (harmless: only the cost is frozen), as in the pipelined kernel.
+// LDS: [T] double2 control ratios | [T] float2 u | window of 16-bit cells.
+// -------------------------------------------------------------------------
+template <bool POW2RES>
+__global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells16,
+                                const float2* __restrict__ noise, const float2* __restrict__ u,
+                                float* __restrict__ costs, float* __restrict__ w_rel,
+                                float* __restrict__ tile_beta) {
+  extern __shared__ double2 uos[];
+  // batched handle: the waves of a workgroup belong to one problem (host: blockDim/64 divides inst_tiles)
+  u = select_instance(P, u, P.inst ? (int)(blockIdx.x * (blockDim.x >> 6)) / P.inst_tiles : 0);
+  const int T = P.n_steps, N = P.n_local;
+  float2* us = reinterpret_cast<float2*>(uos + T);
+  uint16_t* lds_map = reinterpret_cast<uint16_t*>(uos + T + (T + 1) / 2);
+  copy_window_to_lds(P, cells16, lds_map, 0, (int)blockDim.x);
+  for (int t = threadIdx.x; t < T; t += blockDim.x) us[t] = u[t];
+  stage_control_ratios(P, u, uos);  // ends with a barrier
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = n < N;
+  const int nn = live ? n : N - 1;
+  const float2* col = noise + tile_index(0, nn, T);  // this lane's column; rows are 64 apart
+
+  float x = P.x0, y = P.y0, th = P.th0, cost = 0.0f;
+  double x64 = (double)x, y64 = (double)y, th64 = (double)th, d2 = 1e9;
+  double s, c;
+  sincos_f64<false>(th64, s, c);
+  bool done = false, reached = false;
+  const double dt64 = (double)P.dt, gt2 = (double)P.gt2;
+
+  auto step = [&](float2 ut, float2 e) {
+    int xi, yi;
+    if (POW2RES) {  // res is a power of two: the float32 quotient is exact
+      xi = (int)floorf((x - P.xlo) * P.inv_res);
+      yi = (int)floorf((y - P.ylo) * P.inv_res);
+    } else {
+      xi = floordiv_to_int(x - P.xlo, P.res, P.inv_res);
+      yi = floordiv_to_int(y - P.ylo, P.res, P.inv_res);
+    }
+    xi = clamp_index(xi - P.win_c0, P.win_cols);
+    yi = clamp_index(yi - P.win_r0, P.win_rows);
+    const uint32_t c16 = lds_map[__mul24(yi, P.win_cols) + xi];
+    const double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), P.lin_lo);
+    const double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), P.ang_lo);
+    const double qv = dt64 * (double)clip_f32(ut.x + e.x, P.v_lo, P.v_hi);  // exact: float32 factors
+    const double qw = dt64 * (double)clip_f32(ut.y + e.y, P.w_lo, P.w_hi);
+    x = (float)fma(vtr, qv * c, x64);
+    y = (float)fma(vtr, qv * s, y64);
+    th = (float)fma(wtr, qw, th64);
+    x64 = (double)x;
+    y64 = (double)y;
+    const double th_new = (double)th;
+    rotate_sincos_f64(th_new - th64, s, c);  // exact increment of the ROUNDED heading
+    th64 = th_new;
+    const double dx = (double)(P.xg - x), dy = (double)(P.yg - y);
+    const double nd2 = fma(dx, dx, dy * dy);
+    float c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(nd2), dt64));
+    c1 = c1 + ((c16 & 0x4000u) ? P.obs_cost : 0.0f);  // cell the step STARTED in (mppi.py:971-998)
+    c1 = c1 + ((c16 & 0x8000u) ? P.unk_cost : 0.0f);
+    const bool hit = nd2 <= gt2, act = !done;
+    cost = act ? c1 : cost;
+    d2 = act ? nd2 : d2;
+    reached = reached || (act && hit);
+    done = done || hit;
+  };
+
+  float2 e_cur[kNoiseBatch], e_nxt[kNoiseBatch];
+#pragma unroll
+  for (int j = 0; j < kNoiseBatch; ++j) e_cur[j] = col[(size_t)min(j, T - 1) * 64];
+  int t0 = 0;
+  for (; t0 + kNoiseBatch <= T; t0 += kNoiseBatch) {
+#pragma unroll
+    for (int j = 0; j < kNoiseBatch; ++j) e_nxt[j] = col[(size_t)min(t0 + kNoiseBatch + j, T - 1) * 64];
+#pragma unroll
+    for (int j = 0; j < kNoiseBatch; ++j) step(us[t0 + j], e_cur[j]);
+#pragma unroll
+    for (int j = 0; j < kNoiseBatch; ++j) e_cur[j] = e_nxt[j];
+    if (__all(done)) break;
+  }
+  if (!__all(done))
+    for (int t = t0; t < T; ++t) step(us[t], e_cur[t - t0]);
+
+  // terminal cost, then the control cost of all T steps (mppi.py:1005-1009): the float32-rounded
+  // accumulation is sequential, loads and products are batched
+  cost = (float)((double)cost + (reached ? 0.0 : 1.0) * sqrt(d2) / P.v_post_den);
+  for (t0 = 0; t0 + kNoiseBatch <= T; t0 += kNoiseBatch) {
+    double cc[kNoiseBatch];
+#pragma unroll
+    for (int j = 0; j < kNoiseBatch; ++j) cc[j] = control_cost(P, uos[t0 + j], col[(size_t)(t0 + j) * 64]);
+#pragma unroll
+    for (int j = 0; j < kNoiseBatch; ++j) cost = (float)((double)cost + cc[j]);
+  }
+  for (int t = t0; t < T; ++t) cost = (float)((double)cost + control_cost(P, uos[t], col[(size_t)t * 64]));
+  if (live) costs[n] = cost;
+  // first half of the control update (update_kernels.h): weights relative to the tile's minimum
+  if ((n & ~63) < N) emit_tile_weights(cost, live, P.lambda, n, n >> 6, w_rel, tile_beta);
+}
+
+// -------------------------------------------------------------------------
 // Pipelined deterministic rollout (MPPI_MODE_DET, exact math, LDS map).
 //
 // At N = 8192 a GPU has 8x more SIMDs than there are waves, and a lone wave

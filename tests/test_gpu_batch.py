@@ -57,7 +57,7 @@ def single_problem(cfg, lin, ang, params, x0, goal):
 @pytest.mark.parametrize("workload,n,t_steps,m,count,token", [
     ("c2", 1024, 60, 1, 5, "k_rollout_pipe"),           # deterministic traction, LDS reach windows
     ("c2", 256, 250, 1, 3, "k_rollout_"),               # long horizon: whole map or global cells
-    ("c2", 4096, 30, 1, 12, "k_rollout_map det lds_window"),  # throughput regime: fused kernel, LDS windows
+    ("c2", 4096, 30, 1, 12, "k_rollout_fused"),  # throughput regime: fused kernel, LDS windows
     ("c3", 128, 40, 64, 3, "k_rollout_tdm"),            # CVaR over M sampled maps
 ])
 def test_batch_matches_single_problem_handles_and_oracle(workload, n, t_steps, m, count, token):

@@ -262,9 +262,9 @@ def custom_world(rows, cols, res, seed):
     ("three wave triples per workgroup, ragged last tile", 256, 256, 0.25, 49152 - 37, 40, (20.0, 30.0, 0.3), 5.0,
      ["k_rollout_pipe", "triples_per_wg=3"]),
     ("throughput regime: fused kernel on the LDS window, 4 waves per CU", 256, 256, 0.25, 65536, 40,
-     (20.0, 30.0, 0.3), 5.0, ["k_rollout_map det lds_window", "waves_per_wg=4"]),
+     (20.0, 30.0, 0.3), 5.0, ["k_rollout_fused", "waves_per_wg=4"]),
     ("throughput regime, long horizon: whole-map window, 8 waves per CU", 256, 256, 0.25, 131072, 120,
-     (30.0, 30.0, 0.3), 5.0, ["k_rollout_map det lds_window", "waves_per_wg=8", "window=260x264"]),
+     (30.0, 30.0, 0.3), 5.0, ["k_rollout_fused", "waves_per_wg=8", "window=260x264"]),
     ("reach window larger than LDS: global 32-bit cell path", 700, 700, 0.05, 2048, 100, (17.0, 18.0, 1.0), 3.0,
      ["k_rollout_map det global_cells"]),
     ("whole-map window, control-cost products in global scratch", 270, 250, 0.25, 2048, 200, (30.0, 33.0, 0.0), 5.0,
@@ -328,3 +328,33 @@ def test_overlapped_noise_generation_equals_in_line_generation():
         staged.update()
     assert np.array_equal(fused.u_cur_d.copy_to_host(), staged.u_cur_d.copy_to_host())
     assert np.array_equal(fused.noise_samples_d.copy_to_host(), staged.noise_samples_d.copy_to_host())
+
+
+@pytest.mark.parametrize("n,expect", [(4096, "k_rollout_map det lds_window"), (65536, "k_rollout_map det lds_window")])
+def test_large_heading_increments_use_the_full_sincos_kernel(n, expect):
+    """|dt * w * traction| up to 0.63 rad: outside the range of the incremental trig, so
+    neither the pipelined nor the throughput kernel may be chosen; same parity bar."""
+    from mppi_numba_amd.config import Config
+    from mppi_numba_amd.mppi import MPPI_Numba
+    from mppi_numba_amd.terrain import TDM_Numba
+    pmf, obstacle, unknown, td = custom_world(128, 128, 0.25, seed=77)
+    cfg = Config(T=5.0, dt=0.1, num_grid_samples=1, num_control_rollouts=n, max_speed_padding=5.0,
+                 num_vis_state_rollouts=1, max_map_dim=(132, 132), seed=3, enforce_recommended_limits=False,
+                 use_det_dynamics=True)
+    lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
+    lin.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)
+    ang.set_TDM_from_PMF_grid(pmf[:, ::-1].copy(), td, obstacle, unknown)
+    planner = MPPI_Numba(cfg)
+    params = bench.make_params("c2")
+    params.update(x0=np.array([15.0, 16.0, -1.0]), xgoal=np.array([19.0, 12.0]), lambda_weight=5.0,
+                  wrange=np.array([-2 * np.pi, 2 * np.pi]), u_std=np.array([2.0, 6.0]))
+    planner.setup(params, lin, ang)
+    planner.solve()
+    planner.sample_noise()
+    noise, u_in = planner.noise_samples_d.copy_to_host(), planner.u_cur_d.copy_to_host()
+    planner.rollout()
+    assert expect in planner.last_rollout_kernel(), planner.last_rollout_kernel()
+    got = planner.costs_d.copy_to_host()
+    want = oracle_costs(dict(m=1), params, lin, ang, noise, u_in)
+    ulps = ulp_diff_f32(got, want)
+    assert (ulps == 0).mean() >= 0.999, "exact fraction %.5f, max ulp %d" % ((ulps == 0).mean(), ulps.max())
