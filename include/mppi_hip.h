@@ -115,6 +115,28 @@ int mppi_tdm_set_maps(mppi_tdm* tdm, const int8_t* pmf, int bins, int rows, int 
                       const int8_t* bin_to_int8, double traction_lo, double traction_ratio,
                       const int8_t* obstacle, const int8_t* unknown, const int8_t* risk);
 
+/* Map preprocessing on the device (replaces the numpy code of
+ * terrain.py:408-495 and the padding of terrain.py:511-583): the RAW PMF grid
+ * (bins, src_rows, src_cols) and masks (src_rows, src_cols; NULL = zeros) in, on the
+ * device: crop to (valid_rows, valid_cols) from the origin, ring of pad_cells
+ * zero-traction cells, and per kind
+ *   MPPI_PREP_TDM    the PMF itself                             (use_tdm)
+ *   MPPI_PREP_DET    one-hot PMF at the CVaR_alpha bin          (use_det_dynamics)
+ *   MPPI_PREP_SPEED  nominal PMF + int8 risk traction map       (use_nom_dynamics_with_speed_map)
+ * bin_values / bounds are the float32 copies the reference holds (terrain.py:393-394);
+ * the remaining arguments are those of mppi_tdm_set_maps.  *bad_columns (may be NULL)
+ * receives the number of raw PMF columns that do not sum to 100.  Bit-identical to the
+ * host path. */
+typedef enum mppi_prep_kind { MPPI_PREP_TDM = 0, MPPI_PREP_DET = 1, MPPI_PREP_SPEED = 2 } mppi_prep_kind;
+int mppi_tdm_set_maps_from_pmf(mppi_tdm* tdm, int kind, const int8_t* pmf, int bins, int src_rows,
+                               int src_cols, int valid_rows, int valid_cols, int pad_cells,
+                               const float* bin_values, const float bounds[2], double alpha,
+                               const int8_t* bin_to_int8, double traction_lo, double traction_ratio,
+                               const int8_t* obstacle, const int8_t* unknown, int* bad_columns);
+/* the maps as held on the device; any pointer may be NULL.  pmf (bins, rows, cols),
+ * obstacle / unknown / risk (rows, cols) with rows, cols the PADDED size */
+int mppi_tdm_get_maps(mppi_tdm* tdm, int8_t* pmf, int8_t* obstacle, int8_t* unknown, int8_t* risk);
+
 /* terrain.py:610-622 sample_grids (kernel terrain.py:633-695) */
 int mppi_tdm_sample_grids(mppi_tdm* tdm, double alpha_dyn);
 

@@ -17,6 +17,7 @@ MODE_DET, MODE_SPEED_MAP, MODE_TDM, MODE_BAREBONE = 0, 1, 2, 3
 RNG_PHILOX, RNG_XOROSHIRO = 0, 1
 MATH_EXACT, MATH_FAST = 0, 1
 COMM_ID_BYTES = 128
+PREP_TDM, PREP_DET, PREP_SPEED = 0, 1, 2
 ABI_VERSION = 1
 
 
@@ -80,6 +81,10 @@ SIGNATURES = {
     "mppi_tdm_destroy": [_vp],
     "mppi_tdm_set_maps": [_vp, _i8p, C.c_int, C.c_int, C.c_int, _i8p, C.c_double, C.c_double,
                           _i8p, _i8p, _i8p],
+    "mppi_tdm_set_maps_from_pmf": [_vp, C.c_int, _i8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   _f32p, _f32p, C.c_double, _i8p, C.c_double, C.c_double, _i8p, _i8p,
+                                   C.POINTER(C.c_int)],
+    "mppi_tdm_get_maps": [_vp, _i8p, _i8p, _i8p, _i8p],
     "mppi_tdm_sample_grids": [_vp, C.c_double],
     "mppi_tdm_set_sampled_grids": [_vp, _i8p, C.c_int, C.c_int],
     "mppi_tdm_get_sampled_grids": [_vp, _i8p],

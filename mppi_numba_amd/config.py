@@ -63,6 +63,7 @@ class Config:
                  rng="philox",  # "philox" (rocRAND) | "xoroshiro" (numba-compatible streams)
                  math="exact",  # "exact" (reference CPU-path roundings) | "fast" (float32 trig)
                  device=0,
+                 map_preprocessing="device",  # "device" (HIP kernel, csrc/map_kernels.h) | "host" (numpy, as the reference)
                  ):
 
         self.seed = seed
@@ -90,6 +91,8 @@ class Config:
         self.rng = rng
         self.math = math
         self.device = device
+        assert map_preprocessing in ("host", "device")
+        self.map_preprocessing = map_preprocessing
 
         if num_grid_samples > max_threads_per_block:
             print("WARNING: slow-down expected since each thread needs to handle multiple grid samples due to num_grid_samples({})>max_threads_per_block({})".format(

@@ -18,6 +18,7 @@
 
 #include "rng_kernels.h"
 #include "rollout_kernels.h"
+#include "map_kernels.h"
 #include "update_kernels.h"
 
 using namespace mppi;
@@ -128,6 +129,12 @@ struct mppi_tdm {
   int8_t* unk = nullptr;
   int8_t* risk = nullptr;
   size_t map_capacity = 0;
+  // staging of the raw inputs of mppi_tdm_set_maps_from_pmf (device-side preprocessing)
+  int8_t* raw = nullptr;  // raw PMF | raw obstacle | raw unknown
+  size_t raw_capacity = 0;
+  float* bin_values = nullptr;
+  int bin_values_capacity = 0;
+  int* prep_flags = nullptr;
   uint64_t* states = nullptr;  // xoroshiro-compatible generator only
   long n_states = 0;
   int bins = 0, rows = 0, cols = 0;
@@ -153,6 +160,9 @@ extern "C" int mppi_tdm_destroy(mppi_tdm* t) {
   dev_free(t->obs);
   dev_free(t->unk);
   dev_free(t->risk);
+  dev_free(t->raw);
+  dev_free(t->bin_values);
+  dev_free(t->prep_flags);
   dev_free(t->states);
   if (t->stream) (void)hipStreamDestroy(t->stream);
   delete t;
@@ -270,6 +280,127 @@ extern "C" int mppi_tdm_set_maps(mppi_tdm* t, const int8_t* pmf, int bins, int r
   t->ratio = traction_ratio;
   t->maps_set = true;
   ++t->maps_version;
+  return MPPI_OK;
+}
+
+// (re)size the per-map device buffers
+static int tdm_reserve(mppi_tdm* t, int bins, size_t plane) {
+  size_t vol = plane * (size_t)bins;
+  if (vol > t->pmf_capacity) {
+    dev_free(t->pmf);
+    TRY(dev_alloc(&t->pmf, vol));
+    t->pmf_capacity = vol;
+  }
+  if (bins > t->table_capacity) {
+    dev_free(t->table);
+    TRY(dev_alloc(&t->table, (size_t)bins));
+    t->table_capacity = bins;
+  }
+  if (plane > t->map_capacity) {
+    dev_free(t->obs);
+    dev_free(t->unk);
+    dev_free(t->risk);
+    TRY(dev_alloc(&t->obs, plane));
+    TRY(dev_alloc(&t->unk, plane));
+    TRY(dev_alloc(&t->risk, plane));
+    t->map_capacity = plane;
+  }
+  return MPPI_OK;
+}
+
+// terrain.py:408-495 + 511-583 on the device: raw PMF (and masks) in, the padded maps the
+// planner mode needs out.  See map_kernels.h.
+extern "C" int mppi_tdm_set_maps_from_pmf(mppi_tdm* t, int kind, const int8_t* pmf, int bins, int src_rows,
+                                          int src_cols, int valid_rows, int valid_cols, int pad_cells,
+                                          const float* bin_values, const float bounds[2], double alpha,
+                                          const int8_t* bin_to_int8, double traction_lo, double traction_ratio,
+                                          const int8_t* obstacle, const int8_t* unknown, int* bad_columns) {
+  REQUIRE(t && pmf && bin_values && bounds && bin_to_int8, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(kind >= PREP_TDM && kind <= PREP_SPEED, MPPI_ERR_INVALID, "bad preprocessing kind %d", kind);
+  REQUIRE(bins >= 1 && src_rows >= 1 && src_cols >= 1, MPPI_ERR_INVALID, "bad map dims");
+  REQUIRE(valid_rows >= 1 && valid_rows <= src_rows && valid_cols >= 1 && valid_cols <= src_cols && pad_cells >= 0,
+          MPPI_ERR_INVALID, "bad crop %dx%d of %dx%d (pad %d)", valid_rows, valid_cols, src_rows, src_cols,
+          pad_cells);
+  REQUIRE(alpha > 0.0 && alpha <= 1.0, MPPI_ERR_INVALID, "alpha must be in (0, 1]");
+  const int rows = valid_rows + 2 * pad_cells, cols = valid_cols + 2 * pad_cells;
+  REQUIRE(rows <= t->cfg.max_rows && cols <= t->cfg.max_cols, MPPI_ERR_INVALID,
+          "padded map %dx%d exceeds max_map_dim %dx%d", rows, cols, t->cfg.max_rows, t->cfg.max_cols);
+  HIP_TRY(hipSetDevice(t->cfg.device));
+  const size_t plane = (size_t)rows * cols, src_plane = (size_t)src_rows * src_cols;
+  TRY(tdm_reserve(t, bins, plane));
+  const size_t raw_need = src_plane * ((size_t)bins + 2);
+  if (raw_need > t->raw_capacity) {
+    dev_free(t->raw);
+    TRY(dev_alloc(&t->raw, raw_need));
+    t->raw_capacity = raw_need;
+  }
+  if (bins > t->bin_values_capacity) {
+    dev_free(t->bin_values);
+    TRY(dev_alloc(&t->bin_values, (size_t)bins));
+    t->bin_values_capacity = bins;
+  }
+  if (!t->prep_flags) TRY(dev_alloc(&t->prep_flags, (size_t)4));
+  int8_t* raw_obs = t->raw + src_plane * bins;
+  int8_t* raw_unk = raw_obs + src_plane;
+  HIP_TRY(hipMemcpyAsync(t->raw, pmf, src_plane * bins, hipMemcpyHostToDevice, t->stream));
+  if (obstacle) HIP_TRY(hipMemcpyAsync(raw_obs, obstacle, src_plane, hipMemcpyHostToDevice, t->stream));
+  if (unknown) HIP_TRY(hipMemcpyAsync(raw_unk, unknown, src_plane, hipMemcpyHostToDevice, t->stream));
+  HIP_TRY(hipMemcpyAsync(t->bin_values, bin_values, sizeof(float) * (size_t)bins, hipMemcpyHostToDevice, t->stream));
+  HIP_TRY(hipMemcpyAsync(t->table, bin_to_int8, (size_t)bins, hipMemcpyHostToDevice, t->stream));
+  HIP_TRY(hipMemsetAsync(t->prep_flags, 0, 4 * sizeof(int), t->stream));
+  PrepJob j;
+  j.raw_pmf = t->raw;
+  j.raw_obs = obstacle ? raw_obs : nullptr;
+  j.raw_unk = unknown ? raw_unk : nullptr;
+  j.bin_values = t->bin_values;
+  j.bins = bins; j.src_rows = src_rows; j.src_cols = src_cols;
+  j.valid_rows = valid_rows; j.valid_cols = valid_cols; j.pad = pad_cells;
+  j.lo = bounds[0];
+  j.span = bounds[1] - bounds[0];  // float32 subtraction, as numpy does on the float32 bounds
+  j.alpha = alpha;
+  j.kind = kind;
+  j.pmf = t->pmf; j.obs = t->obs; j.unk = t->unk; j.risk = t->risk;
+  j.flags = t->prep_flags;
+  hipLaunchKernelGGL(k_prepare_maps, dim3(ceil_div((long)plane, 256)), dim3(256), 0, t->stream, j);
+  HIP_TRY(hipGetLastError());
+  int flags[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(flags, t->prep_flags, sizeof(flags), hipMemcpyDeviceToHost, t->stream));
+  HIP_TRY(hipStreamSynchronize(t->stream));
+  if (bad_columns) *bad_columns = flags[0];
+  bool compact = flags[2] == 0;
+  t->table_max = -128;
+  for (int b = 0; b < bins; ++b) {
+    compact = compact && bin_to_int8[b] >= 0;
+    t->table_max = std::max(t->table_max, (int)bin_to_int8[b]);
+  }
+  t->compact_ok = compact;
+  t->one_hot = (kind != PREP_TDM) || flags[1] == 0;
+  t->bins = bins;
+  t->rows = rows;
+  t->cols = cols;
+  t->has_risk = kind == PREP_SPEED;
+  t->lo = traction_lo;
+  t->ratio = traction_ratio;
+  t->maps_set = true;
+  ++t->maps_version;
+  return MPPI_OK;
+}
+
+// the maps as they are on the device (any pointer may be NULL): pmf (bins, rows, cols),
+// obstacle / unknown / risk (rows, cols)
+extern "C" int mppi_tdm_get_maps(mppi_tdm* t, int8_t* pmf, int8_t* obstacle, int8_t* unknown, int8_t* risk) {
+  REQUIRE(t, MPPI_ERR_INVALID, "NULL tdm");
+  REQUIRE(t->maps_set, MPPI_ERR_STATE, "TDM maps not set");
+  HIP_TRY(hipSetDevice(t->cfg.device));
+  const size_t plane = (size_t)t->rows * t->cols;
+  if (pmf) HIP_TRY(hipMemcpyAsync(pmf, t->pmf, plane * t->bins, hipMemcpyDeviceToHost, t->stream));
+  if (obstacle) HIP_TRY(hipMemcpyAsync(obstacle, t->obs, plane, hipMemcpyDeviceToHost, t->stream));
+  if (unknown) HIP_TRY(hipMemcpyAsync(unknown, t->unk, plane, hipMemcpyDeviceToHost, t->stream));
+  if (risk) {
+    REQUIRE(t->has_risk, MPPI_ERR_STATE, "this TDM holds no risk traction map");
+    HIP_TRY(hipMemcpyAsync(risk, t->risk, plane, hipMemcpyDeviceToHost, t->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(t->stream));
   return MPPI_OK;
 }
 

@@ -273,6 +273,10 @@ class TDM_Numba(object):
         assert self.bin_values[0] == 0, "Assume minimum bin value is 0 for now"
         assert self.bin_values_bounds[0] == 0, "Assume minimum traction is 0 for now"
 
+        if getattr(self.cfg, "map_preprocessing", "host") == "device":
+            return self._set_TDM_from_PMF_grid_on_device(pmf_grid, alpha, obstacle_map, unknown_map,
+                                                         num_rows, num_cols, res)
+
         risk_padded = None
         if self.use_det_dynamics or self.use_nom_dynamics_with_speed_map:
             col_sums = np.sum(pmf_grid, axis=0)
@@ -303,6 +307,78 @@ class TDM_Numba(object):
         # this entry point holds float32 copies on the device (terrain.py:401-406)
         self._upload(padded_pmf_grid, self.bin_values, self.bin_values_bounds,
                      obstacle_map, unknown_map, num_rows, num_cols, res, risk_padded)
+        self.pmf_grid_initialized = True
+
+    @property
+    def pmf_grid(self):
+        """Processed, unpadded PMF grid (bins, rows, cols) int8.  With device-side map
+        preprocessing it lives on the GPU and is copied back on first access."""
+        if self._pmf_grid is None and self._pmf_grid_fetch is not None:
+            self._pmf_grid = self._pmf_grid_fetch()
+        return self._pmf_grid
+
+    @pmf_grid.setter
+    def pmf_grid(self, value):
+        self._pmf_grid = value
+        self._pmf_grid_fetch = None
+
+    def _set_TDM_from_PMF_grid_on_device(self, pmf_grid, alpha, obstacle_map, unknown_map,
+                                         num_rows, num_cols, res):
+        """Config(map_preprocessing="device"): CVaR bin / risk map / cropping / padding by
+        one HIP kernel (csrc/map_kernels.h) instead of numpy; the host only ships the raw
+        int8 PMF and masks.  Same results bit for bit (tests/test_gpu_maps.py); the host-side
+        attributes (pmf_grid, *_d mirrors) are fetched from the device on demand."""
+        vr, vc, pad = self.get_padding_info(pmf_grid.shape, self.max_speed_padding, self.dt, res)
+        self.pad_cells = pad
+        self.padded_xlimits, self.padded_ylimits = tdm_host.padded_limits(self.xlimits, self.ylimits, vr, vc, pad, res)
+        kind = (_lib.PREP_DET if self.use_det_dynamics else
+                _lib.PREP_SPEED if self.use_nom_dynamics_with_speed_map else _lib.PREP_TDM)
+        raw = np.ascontiguousarray(pmf_grid, dtype=np.int8)
+        masks = []
+        for name, m in (("obstacle_map", obstacle_map), ("unknown_map", unknown_map)):
+            if m is not None:
+                assert m.shape == (num_rows, num_cols), "%s does not have the same XY dim as pmf grid." % name
+                m = np.ascontiguousarray(np.asarray(m).astype(np.int8).reshape(num_rows, num_cols))
+                setattr(self, name, m)
+            else:
+                setattr(self, name, np.zeros((num_rows, num_cols), dtype=np.int8))
+            masks.append(m)
+        bv = tdm_host.as_device_float(self.bin_values)
+        bd = tdm_host.as_device_float(self.bin_values_bounds)
+        table = tdm_host.bin_table(bv, bd)
+        lo, ratio = tdm_host.traction_scale(bd)
+        bv32 = np.ascontiguousarray(self.bin_values, dtype=np.float32)
+        bd32 = np.ascontiguousarray(self.bin_values_bounds, dtype=np.float32)
+        bad = C.c_int(0)
+        _lib.call("mppi_tdm_set_maps_from_pmf", self._handle, kind, _lib.ptr(raw, C.c_int8), self.num_pmf_bins,
+                  num_rows, num_cols, vr, vc, pad, _lib.ptr(bv32, C.c_float), _lib.ptr(bd32, C.c_float),
+                  float(alpha), _lib.ptr(table, C.c_int8), lo, ratio,
+                  None if masks[0] is None else _lib.ptr(masks[0], C.c_int8),
+                  None if masks[1] is None else _lib.ptr(masks[1], C.c_int8), C.byref(bad))
+        if bad.value:
+            print("WARNING: the provided PMF has {} columns that don't sum up to 100".format(bad.value))
+        bins, rows_p, cols_p = self.num_pmf_bins, vr + 2 * pad, vc + 2 * pad
+        handle = self._handle
+
+        def fetch(which):
+            out = np.empty((bins, rows_p, cols_p) if which == 0 else (rows_p, cols_p), dtype=np.int8)
+            args = [None, None, None, None]
+            args[which] = _lib.ptr(out, C.c_int8)
+            _lib.call("mppi_tdm_get_maps", handle, *args)
+            return out
+
+        self.pmf_grid_d = DeviceArray((bins, rows_p, cols_p), np.int8, lambda: fetch(0))
+        self.obstacle_map_d = DeviceArray((rows_p, cols_p), np.int8, lambda: fetch(1))
+        self.unknown_map_d = DeviceArray((rows_p, cols_p), np.int8, lambda: fetch(2))
+        if kind == _lib.PREP_SPEED:
+            self.risk_traction_map_d = DeviceArray((1, rows_p, cols_p), np.int8, lambda: fetch(3))
+        # unpadded processed PMF, which the reference keeps on the host: fetched if anyone asks
+        self.pmf_grid = None
+        self._pmf_grid_fetch = lambda: fetch(0)[:, pad:pad + vr, pad:pad + vc].copy()
+        self.bin_values_d = HostMirror(bv)
+        self.bin_values_bounds_d = HostMirror(bd)
+        self.bin_to_int8 = table
+        self.traction_lo, self.traction_ratio = lo, ratio
         self.pmf_grid_initialized = True
 
     def _upload(self, padded_pmf_grid, bin_values_dev, bounds_dev, obstacle_map, unknown_map,
