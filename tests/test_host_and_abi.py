@@ -68,6 +68,15 @@ def test_errors_are_reported_not_swallowed():
     from mppi_numba_amd.mppi import MPPI_Numba
     with pytest.raises(_lib.MppiError):
         MPPI_Numba(Config(use_det_dynamics=True))
+    from mppi_numba_amd.batch import MPPI_Batch
+    with pytest.raises(_lib.MppiError):
+        MPPI_Batch(Config(use_det_dynamics=True, num_control_rollouts=128), 4)
+    # argument checks come before the device probe
+    bad = _lib.PlannerCfg(device=0, mode=0, num_control_rollouts=64, num_steps=10, num_grid_samples=1,
+                          num_vis_state_rollouts=1, rng=0, math=0, rank=0, world_size=1, num_instances=-2, seed=1)
+    with pytest.raises(_lib.MppiError) as err:
+        _lib.call("mppi_planner_create", C.byref(bad), C.byref(handle))
+    assert err.value.code in (-1, -4)
 
 
 def test_config_mirrors_reference_clamps(capsys):
@@ -84,6 +93,9 @@ def test_config_mirrors_reference_clamps(capsys):
         Config(use_tdm=True, use_det_dynamics=True)
     with pytest.raises(AssertionError):
         Config()
+    with pytest.raises(AssertionError):
+        Config(use_tdm=True, map_preprocessing="somewhere")
+    assert Config(use_tdm=True).map_preprocessing == "device"
     import copy
     import pickle
     c2 = pickle.loads(pickle.dumps(copy.deepcopy(c)))
