@@ -66,74 +66,77 @@ class Config:
                  map_preprocessing="device",  # "device" (HIP kernel, csrc/map_kernels.h) | "host" (numpy, as the reference)
                  ):
 
+        # planner variant: exactly one, and the costmap interface does not exist upstream either
+        variants = dict(use_tdm=use_tdm, use_det_dynamics=use_det_dynamics,
+                        use_nom_dynamics_with_speed_map=use_nom_dynamics_with_speed_map, use_costmap=use_costmap)
+        for name, flag in variants.items():
+            setattr(self, name, flag)
+        assert T > 0 and dt > 0 and T > dt
+        assert sum(bool(v) for v in variants.values()) == 1, \
+            "MPPI Config Error: Only one of the {} can be true.".format(", ".join(variants))
+        assert not use_costmap, "Interface with costmap2d is not yet implemented."
+
         self.seed = seed
-        self.use_tdm = use_tdm
-        self.use_det_dynamics = use_det_dynamics
-        self.use_nom_dynamics_with_speed_map = use_nom_dynamics_with_speed_map
-        self.use_costmap = use_costmap
-        modes_on = sum([use_tdm, use_det_dynamics, use_nom_dynamics_with_speed_map, use_costmap])
-
-        assert T > 0
-        assert dt > 0
-        assert T > dt
-        assert modes_on == 1, "MPPI Config Error: Only one of the use_tdm, use_det_dynamics, use_nom_dynamics_with_speed_map, use_costmap can be true."
-        assert not self.use_costmap, "Interface with costmap2d is not yet implemented."
-
-        self.T = T
-        self.dt = dt
+        self.T, self.dt = T, dt
         self.num_steps = int(T / dt)
         assert self.num_steps > 0
-
-        self.max_threads_per_block = max_threads_per_block
-        self.enforce_recommended_limits = enforce_recommended_limits
-        assert rng in ("philox", "xoroshiro")
-        assert math in ("exact", "fast")
-        self.rng = rng
-        self.math = math
-        self.device = device
-        assert map_preprocessing in ("host", "device")
-        self.map_preprocessing = map_preprocessing
-
-        if num_grid_samples > max_threads_per_block:
-            print("WARNING: slow-down expected since each thread needs to handle multiple grid samples due to num_grid_samples({})>max_threads_per_block({})".format(
-                num_grid_samples, max_threads_per_block))
-
-        self.num_grid_samples = num_grid_samples
-        if self.num_grid_samples > max_rec_blocks and enforce_recommended_limits:
-            self.num_grid_samples = max_rec_blocks
-            print("MPPI Config: Limit num_grid_samples by recommended max block number (<={}). But this can be overwritten if needed.".format(max_rec_blocks))
-        elif self.num_grid_samples < 1:
-            self.num_grid_samples = 1
-            print("MPPI Config: Set num_grid_samples from {} -> 1. Need at least 1 map to work with".format(num_grid_samples))
-
-        self.num_control_rollouts = num_control_rollouts
-        if enforce_recommended_limits:
-            if self.num_control_rollouts > rec_max_control_rollouts:
-                self.num_control_rollouts = rec_max_control_rollouts
-                print("MPPI Config: Clip num_control_rollouts to be recommended max number of {}. (Max={})".format(
-                    rec_max_control_rollouts, max_blocks))
-            elif self.num_control_rollouts < rec_min_control_rollouts:
-                self.num_control_rollouts = rec_min_control_rollouts
-                print("MPPI Config: Clip num_control_rollouts to be recommended min number of {}. (Recommended max={})".format(
-                    rec_min_control_rollouts, rec_max_control_rollouts))
-        assert self.num_control_rollouts >= 1
-
         self.max_speed_padding = max_speed_padding
-
-        self.tdm_sample_thread_dim = tuple(tdm_sample_thread_dim)
-        assert len(self.tdm_sample_thread_dim) == 2
-        assert self.tdm_sample_thread_dim[0] > 0
-        assert self.tdm_sample_thread_dim[1] > 0
-        requested = self.tdm_sample_thread_dim[0] * self.tdm_sample_thread_dim[1]
-        if requested >= max_threads_per_block:
-            self.tdm_sample_thread_dim = max_square_block_dim
-            print("MPPI Config: Requested {} threads per block (more than max {}) for sampling tdm. Change tdm_sample_thread_dim to {}".format(
-                requested, max_threads_per_block, max_square_block_dim))
-
-        # For visualizing state rollouts
-        self.num_vis_state_rollouts = min([num_vis_state_rollouts,
-                                           self.num_control_rollouts,
-                                           self.num_grid_samples])
-        self.num_vis_state_rollouts = max([1, self.num_vis_state_rollouts])
-
         self.max_map_dim = max_map_dim
+        self.max_threads_per_block = max_threads_per_block
+
+        # extensions
+        assert rng in ("philox", "xoroshiro") and math in ("exact", "fast") and map_preprocessing in ("host", "device")
+        self.enforce_recommended_limits = enforce_recommended_limits
+        self.rng, self.math, self.device, self.map_preprocessing = rng, math, device, map_preprocessing
+
+        self.num_grid_samples = self._grid_samples(num_grid_samples, enforce_recommended_limits)
+        self.num_control_rollouts = self._control_rollouts(num_control_rollouts, enforce_recommended_limits)
+        self.tdm_sample_thread_dim = self._sampler_block(tdm_sample_thread_dim)
+        # rollouts kept for plotting: no more than there are control samples or sampled maps
+        self.num_vis_state_rollouts = max(1, min(num_vis_state_rollouts, self.num_control_rollouts,
+                                                 self.num_grid_samples))
+
+    @staticmethod
+    def _say(text, *values):
+        print("MPPI Config: " + text.format(*values))
+
+    @classmethod
+    def _grid_samples(cls, wanted, clamp):
+        """M: at least one map; the reference caps it at its recommended block count."""
+        if wanted > max_threads_per_block:
+            print("WARNING: slow-down expected since each thread needs to handle multiple grid samples due to "
+                  "num_grid_samples({})>max_threads_per_block({})".format(wanted, max_threads_per_block))
+        if clamp and wanted > max_rec_blocks:
+            cls._say("Limit num_grid_samples by recommended max block number (<={}). But this can be overwritten if needed.",
+                     max_rec_blocks)
+            return max_rec_blocks
+        if wanted < 1:
+            cls._say("Set num_grid_samples from {} -> 1. Need at least 1 map to work with", wanted)
+            return 1
+        return wanted
+
+    @classmethod
+    def _control_rollouts(cls, wanted, clamp):
+        """N: clipped to the reference's recommended [100, 15000] unless the clamp is lifted."""
+        if clamp and wanted > rec_max_control_rollouts:
+            cls._say("Clip num_control_rollouts to be recommended max number of {}. (Max={})",
+                     rec_max_control_rollouts, max_blocks)
+            wanted = rec_max_control_rollouts
+        elif clamp and wanted < rec_min_control_rollouts:
+            cls._say("Clip num_control_rollouts to be recommended min number of {}. (Recommended max={})",
+                     rec_min_control_rollouts, rec_max_control_rollouts)
+            wanted = rec_min_control_rollouts
+        assert wanted >= 1
+        return wanted
+
+    @classmethod
+    def _sampler_block(cls, shape):
+        """2-D block of the grid sampler (only shapes the xoroshiro-compatible sampler here)."""
+        shape = tuple(shape)
+        assert len(shape) == 2 and shape[0] > 0 and shape[1] > 0
+        threads = shape[0] * shape[1]
+        if threads >= max_threads_per_block:
+            cls._say("Requested {} threads per block (more than max {}) for sampling tdm. Change tdm_sample_thread_dim to {}",
+                     threads, max_threads_per_block, max_square_block_dim)
+            return max_square_block_dim
+        return shape
