@@ -92,20 +92,35 @@ __device__ __forceinline__ void sincos_f64(double x, double& s_out, double& c_ou
 // linearly with the number of steps (no renormalisation): ~1e-13 after 1000
 // steps, against the 3e-12 that would be needed to move a float32 rounding of
 // x + dt*v*tr*cos(theta) with probability 1e-6.
+// d = a*b + c as the three-operand v_fma_f64.  For a Horner step acc = z*acc + K the compiler
+// prefers the two-operand v_fmac_f64 (accumulator tied to the addend) and then has to copy the
+// constant K into the accumulator first: one v_mov_b64 per step, 11 per rotation on the
+// critical wave.  Same IEEE operation, no copy.
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+// FMA3: use fma3 for the Horner steps.  Measured per kernel (profiles/r01_ablation.md): the CVaR
+// kernel gains 10 %; the pipelined and the throughput kernel lose 2-8 % (the opaque asm costs
+// the scheduler more than the copies cost those loops), so they keep the compiler's choice.
+template <bool FMA3 = false>
 __device__ __forceinline__ void rotate_sincos_f64(double delta, double& s, double& c) {
+  auto step = [](double a, double b, double k) { return FMA3 ? fma3(a, b, k) : fma(a, b, k); };
   double z = delta * delta;
-  double ps = fma(z, 1.6059043836821613e-10, -2.5052108385441720e-08);   // 1/13!, -1/11!
-  ps = fma(z, ps, 2.7557319223985893e-06);                                // 1/9!
-  ps = fma(z, ps, -1.9841269841269841e-04);                               // -1/7!
-  ps = fma(z, ps, 8.3333333333333332e-03);                                // 1/5!
-  ps = fma(z, ps, -1.6666666666666666e-01);                               // -1/3!
+  double ps = step(z, 1.6059043836821613e-10, -2.5052108385441720e-08);  // 1/13!, -1/11!
+  ps = step(z, ps, 2.7557319223985893e-06);                               // 1/9!
+  ps = step(z, ps, -1.9841269841269841e-04);                              // -1/7!
+  ps = step(z, ps, 8.3333333333333332e-03);                               // 1/5!
+  ps = step(z, ps, -1.6666666666666666e-01);                              // -1/3!
   double sd = fma(delta * z, ps, delta);
-  double pc = fma(z, 2.0876756987868100e-09, -2.7557319223985888e-07);    // 1/12!, -1/10!
-  pc = fma(z, pc, 2.4801587301587302e-05);                                // 1/8!
-  pc = fma(z, pc, -1.3888888888888889e-03);                               // -1/6!
-  pc = fma(z, pc, 4.1666666666666664e-02);                                // 1/4!
-  pc = fma(z, pc, -0.5);
-  double cd = fma(z, pc, 1.0);
+  double pc = step(z, 2.0876756987868100e-09, -2.7557319223985888e-07);   // 1/12!, -1/10!
+  pc = step(z, pc, 2.4801587301587302e-05);                               // 1/8!
+  pc = step(z, pc, -1.3888888888888889e-03);                              // -1/6!
+  pc = step(z, pc, 4.1666666666666664e-02);                               // 1/4!
+  pc = step(z, pc, -0.5);
+  double cd = step(z, pc, 1.0);
   double c2 = fma(c, cd, -(s * sd));
   double s2 = fma(s, cd, c * sd);
   c = c2;

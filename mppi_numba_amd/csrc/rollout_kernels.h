@@ -809,7 +809,7 @@ __global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cel
       x = nx; y = ny; th = nth;
       x64 = (double)nx; y64 = (double)ny;
       double th_new = (double)nth;
-      rotate_sincos_f64(th_new - th64, s, c);
+      rotate_sincos_f64<true>(th_new - th64, s, c);
       th64 = th_new;
       cost = act ? c1 : cost;
       d2 = act ? nd2 : d2;
