@@ -780,7 +780,7 @@ __global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cel
     double s, c;
     sincos_f64<false>(th64, s, c);
     bool done = false, reached = false;
-    for (int t = 0; t < T; ++t) {
+    auto step = [&](int t) {
       double2 qd = qd_sh[t];
       int xi, yi;
       if (POW2RES) {
@@ -815,8 +815,19 @@ __global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cel
       d2 = act ? nd2 : d2;
       reached = reached || (act && hit);
       done = done || hit;
+    };
+    // straight-line groups of four steps; the early exit (every lane of the wave has reached
+    // the goal) is tested once per group: it only ever skips work whose results are frozen
+    int t = 0;
+    for (; t + 4 <= T; t += 4) {
+      step(t);
+      step(t + 1);
+      step(t + 2);
+      step(t + 3);
       if (__all(done)) break;
     }
+    if (!__all(done))
+      for (; t < T; ++t) step(t);
     // control cost of all T steps, then the terminal cost (mppi.py:706-713)
     for (int t = 0; t < T; ++t) cost = (float)((double)cost + cc_sh[t]);
     double term = (reached ? 0.0 : 1.0) * sqrt(d2) / P.v_post_den;
