@@ -85,6 +85,19 @@ __device__ __forceinline__ void sincos_f64(double x, double& s_out, double& c_ou
   c_out = c;
 }
 
+// Cell coordinate along one axis when the resolution is a power of two, relative to a window
+// that starts `origin` cells into the map and clamped to [0, last]:
+//   clamp(floor((pos - lo) / res) - origin, 0, last)
+// in four instructions (sub, fma, med3, cvt) instead of seven.  Exactness: d = fl(pos - lo) is
+// the reference's float32 difference; d * inv_res is exact (power of two); subtracting the
+// integer `origin` from it is exact as well (a multiple of ulp(q) no larger than q), so the fma
+// returns q - origin exactly and floor(q) - origin == floor(q - origin).  After the clamp the
+// value is >= 0, where the truncating conversion is the floor.
+__device__ __forceinline__ int cell_coord_pow2(float pos, float lo, float inv_res, float origin, float last) {
+  float q = fmaf(pos - lo, inv_res, -origin);
+  return (int)__builtin_amdgcn_fmed3f(q, 0.0f, last);
+}
+
 // (cos, sin) of theta+delta from (cos, sin) of theta, |delta| <= 0.36 rad (the host
 // proves the bound from dt*max|w|*max traction).  Taylor kernels: the first
 // omitted terms are delta^15/15! < 2e-19 and delta^14/14! < 8e-18; with the

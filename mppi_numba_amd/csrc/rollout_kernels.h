@@ -346,19 +346,21 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
   sincos_f64<false>(th64, s, c);
   bool done = false, reached = false;
   const double dt64 = (double)P.dt, gt2 = (double)P.gt2;
+  const float win_c0f = (float)P.win_c0, win_r0f = (float)P.win_r0;
+  const float win_last_col = (float)(P.win_cols - 1), win_last_row = (float)(P.win_rows - 1);
+  const int win_pitch_bytes = 2 * P.win_cols;
+  const char* lds_bytes = reinterpret_cast<const char*>(lds_map);
 
   auto step = [&](float2 ut, float2 e) {
     int xi, yi;
-    if (POW2RES) {  // res is a power of two: the float32 quotient is exact
-      xi = (int)floorf((x - P.xlo) * P.inv_res);
-      yi = (int)floorf((y - P.ylo) * P.inv_res);
+    if (POW2RES) {  // res is a power of two: see cell_coord_pow2
+      xi = cell_coord_pow2(x, P.xlo, P.inv_res, win_c0f, win_last_col);
+      yi = cell_coord_pow2(y, P.ylo, P.inv_res, win_r0f, win_last_row);
     } else {
-      xi = floordiv_to_int(x - P.xlo, P.res, P.inv_res);
-      yi = floordiv_to_int(y - P.ylo, P.res, P.inv_res);
+      xi = clamp_index(floordiv_to_int(x - P.xlo, P.res, P.inv_res) - P.win_c0, P.win_cols);
+      yi = clamp_index(floordiv_to_int(y - P.ylo, P.res, P.inv_res) - P.win_r0, P.win_rows);
     }
-    xi = clamp_index(xi - P.win_c0, P.win_cols);
-    yi = clamp_index(yi - P.win_r0, P.win_rows);
-    const uint32_t c16 = lds_map[__mul24(yi, P.win_cols) + xi];
+    const uint32_t c16 = *reinterpret_cast<const uint16_t*>(lds_bytes + (__mul24(yi, win_pitch_bytes) + (xi << 1)));
     const double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), P.lin_lo);
     const double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), P.ang_lo);
     const double qv = dt64 * (double)clip_f32(ut.x + e.x, P.v_lo, P.v_hi);  // exact: float32 factors
@@ -508,7 +510,10 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
     double x64 = (double)x, y64 = (double)y, th64 = (double)th;
     double s, c;
     sincos_f64<false>(th64, s, c);
-    const double dt64 = (double)P.dt;
+    const float win_c0f = (float)P.win_c0, win_r0f = (float)P.win_r0;
+    const float win_last_col = (float)(P.win_cols - 1), win_last_row = (float)(P.win_rows - 1);
+    const int win_pitch_bytes = 2 * P.win_cols;
+    const char* lds_bytes = reinterpret_cast<const char*>(lds_map);
     __syncthreads();  // controls of chunk 0 are in the ring
     for (int k = 0; k <= K; ++k) {
       if (k < K) {
@@ -518,19 +523,18 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
 #pragma unroll
         for (int j = 0; j < C; ++j) {
           double2 qd = in_qd[j * 64 + lane];  // {dt*v, dt*w}: exact products of float32 factors
-          int xi, yi;
-          if (POW2RES) {  // res is a power of two: the float32 quotient is exact
-            xi = (int)floorf((x - P.xlo) * P.inv_res);
-            yi = (int)floorf((y - P.ylo) * P.inv_res);
-          } else {
-            xi = floordiv_to_int(x - P.xlo, P.res, P.inv_res);
-            yi = floordiv_to_int(y - P.ylo, P.res, P.inv_res);
-          }
           // the window holds every cell reachable within the horizon (host-proved); the
           // clamp is for memory safety only
-          xi = clamp_index(xi - P.win_c0, P.win_cols);
-          yi = clamp_index(yi - P.win_r0, P.win_rows);
-          uint32_t c16 = lds_map[__mul24(yi, P.win_cols) + xi];  // 24-bit multiply: full rate
+          int xi, yi;
+          if (POW2RES) {  // res is a power of two: see cell_coord_pow2
+            xi = cell_coord_pow2(x, P.xlo, P.inv_res, win_c0f, win_last_col);
+            yi = cell_coord_pow2(y, P.ylo, P.inv_res, win_r0f, win_last_row);
+          } else {
+            xi = clamp_index(floordiv_to_int(x - P.xlo, P.res, P.inv_res) - P.win_c0, P.win_cols);
+            yi = clamp_index(floordiv_to_int(y - P.ylo, P.res, P.inv_res) - P.win_r0, P.win_rows);
+          }
+          // 24-bit multiply-add (full rate) straight to the byte offset
+          uint32_t c16 = *reinterpret_cast<const uint16_t*>(lds_bytes + (__mul24(yi, win_pitch_bytes) + (xi << 1)));
           double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), P.lin_lo);
           double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), P.ang_lo);
           x = (float)fma(vtr, qd.x * c, x64);
