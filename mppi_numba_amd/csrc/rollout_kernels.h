@@ -774,6 +774,7 @@ __global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cel
   }
   __syncthreads();
   const double gt2 = (double)P.gt2;
+  const float last_col = (float)(P.cols - 1), last_row = (float)(P.rows - 1);
   for (int m = threadIdx.x; m < m_pow2; m += blockDim.x) {
     if (m >= M) {
       sc[m] = -__builtin_inff();  // padding sorts to the tail
@@ -787,15 +788,13 @@ __global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cel
     auto step = [&](int t) {
       double2 qd = qd_sh[t];
       int xi, yi;
-      if (POW2RES) {
-        xi = (int)floorf((x - P.xlo) * P.inv_res);
-        yi = (int)floorf((y - P.ylo) * P.inv_res);
+      if (POW2RES) {  // see cell_coord_pow2 (window = the whole map)
+        xi = cell_coord_pow2(x, P.xlo, P.inv_res, 0.0f, last_col);
+        yi = cell_coord_pow2(y, P.ylo, P.inv_res, 0.0f, last_row);
       } else {
-        xi = floordiv_to_int(x - P.xlo, P.res, P.inv_res);
-        yi = floordiv_to_int(y - P.ylo, P.res, P.inv_res);
+        xi = clamp_index(floordiv_to_int(x - P.xlo, P.res, P.inv_res), P.cols);
+        yi = clamp_index(floordiv_to_int(y - P.ylo, P.res, P.inv_res), P.rows);
       }
-      xi = clamp_index(xi, P.cols);
-      yi = clamp_index(yi, P.rows);
       uint32_t cell = cellsM[(size_t)(yi * P.cols + xi) * M + m];
       double vtr = fma(P.lin_ratio, (double)(int)(int8_t)(cell & 0xff), P.lin_lo);
       double wtr = fma(P.ang_ratio, (double)(int)(int8_t)((cell >> 8) & 0xff), P.ang_lo);
