@@ -98,14 +98,15 @@ def batch_problems(count, rng):
     return x0s, goals
 
 
-def algorithmic_bytes(w, n, rp, cp):
+def algorithmic_bytes(w, n, rp, cp, rollout_writes_noise=True):
     """SURVEY.md section 8d.  Returns (bytes per iteration, bytes per rollout-kernel launch).
-    The pipelined rollout launch (det mode) also writes the noise of the following iteration:
-    8 (noise read) + 4 (map bytes) + 8 (noise write) per rollout-step."""
+    Rollout launch, det mode: 8 (noise read) + 4 (map bytes) per rollout-step, + 8 (noise
+    write) when it is the pipelined kernel, whose spare workgroups also produce the noise of
+    the following iteration."""
     t, m = w["t"], w["m"]
     if m == 1:
         it = n * t * 28 + n * 16 + 32 * t + 4 * rp * cp
-        roll = n * t * (8 + 4 + 8) + n * 4 + 8 * t + 4 * rp * cp
+        roll = n * t * (8 + 4 + (8 if rollout_writes_noise else 0)) + n * 4 + 8 * t + 4 * rp * cp
     else:
         it = 4 * n * m * t + 24 * n * t + 16 * n + 2 * m * rp * cp
         roll = 4 * n * m * t + 8 * n * t + 4 * n + 2 * m * rp * cp
@@ -289,7 +290,9 @@ def main():
         barrier()
         return
 
-    bytes_iter, bytes_roll = algorithmic_bytes(w, n_local * max(1, problems), rp, cp)
+    kernel_name = planner.last_rollout_kernel().split(" ")[0]
+    bytes_iter, bytes_roll = algorithmic_bytes(w, n_local * max(1, problems), rp, cp,
+                                               rollout_writes_noise=(kernel_name == "k_rollout_pipe"))
     traffic = None
     try:  # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
@@ -314,7 +317,8 @@ def main():
                                "control samples over ranks, 1 all-gather of (2T+2) f64 per step"},
         "gpu_ms_per_step_events": gpu_ms / args.steps,
         "kernel_ms": stage,
-        "roofline": {"bound": "hbm", "kernel": "k_rollout_pipe (rollout + next iteration's noise)" if m == 1 else "k_rollout_tdm",
+        "roofline": {"bound": "hbm",
+                     "kernel": kernel_name + (" (rollout + next iteration's noise)" if kernel_name == "k_rollout_pipe" else ""),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_roll,
