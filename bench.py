@@ -228,10 +228,31 @@ def main():
             planner.setup(params, lin, ang)
     rp, cp = lin.pmf_grid_d.shape[1:]
 
+    exchange_note = None
     if world > 1 and args.exchange == "rccl" and not problems:
-        ids = [comm_unique_id() if rank == 0 else None]
+        import torch
+        err = ""
+        try:
+            ids = [comm_unique_id() if rank == 0 else None]
+        except Exception as e:  # rank 0 could not even load RCCL
+            ids, err = [None], str(e)
         dist.broadcast_object_list(ids, src=0)
-        planner.comm_init(ids[0])
+        if ids[0] is not None:
+            try:
+                planner.comm_init(ids[0])
+            except Exception as e:
+                err = str(e)
+        failed = torch.tensor([1 if (err or ids[0] is None) else 0])
+        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+        if int(failed.item()):
+            # keep the run alive and say so: same kernels, packets staged through the host
+            args.exchange = "host"
+            exchange_note = "RCCL communicator unavailable (%s): packets exchanged over gloo" % (err or "on another rank")
+            print("bench.py rank %d: %s" % (rank, exchange_note), file=sys.stderr)
+            if err == "" and ids[0] is not None:
+                # this rank did create a communicator the others lack: never use it
+                planner = MPPI_Numba(cfg, rank=rank, world_size=world)
+                planner.setup(params, lin, ang)
 
     if world > 1 and args.exchange == "host" and not problems:
         import torch
@@ -314,7 +335,10 @@ def main():
                    "problems_per_gpu": problems or 1,
                    "rollout_kernel": planner.last_rollout_kernel(),
                    "sharding": "independent problems over ranks, no exchange" if problems else
-                               "control samples over ranks, 1 all-gather of (2T+2) f64 per step"},
+                               "control samples over ranks, 1 all-gather of (2T+2) f64 per step",
+                   "exchange": "none" if (world == 1 or problems) else
+                               ("RCCL all-gather on the planner's stream" if args.exchange == "rccl" else
+                                (exchange_note or "host-staged over gloo (--exchange host)"))},
         "gpu_ms_per_step_events": gpu_ms / args.steps,
         "kernel_ms": stage,
         "roofline": {"bound": "hbm",
