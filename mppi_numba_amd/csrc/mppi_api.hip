@@ -219,6 +219,8 @@ extern "C" int mppi_tdm_create(const mppi_tdm_cfg* cfg, mppi_tdm** out) {
   return MPPI_OK;
 }
 
+static int tdm_reserve(mppi_tdm* t, int bins, size_t plane);
+
 extern "C" int mppi_tdm_set_maps(mppi_tdm* t, const int8_t* pmf, int bins, int rows, int cols,
                                  const int8_t* bin_to_int8, double traction_lo, double traction_ratio,
                                  const int8_t* obstacle, const int8_t* unknown, const int8_t* risk) {
@@ -228,25 +230,7 @@ extern "C" int mppi_tdm_set_maps(mppi_tdm* t, const int8_t* pmf, int bins, int r
           "padded map %dx%d exceeds max_map_dim %dx%d", rows, cols, t->cfg.max_rows, t->cfg.max_cols);
   HIP_TRY(hipSetDevice(t->cfg.device));
   size_t plane = (size_t)rows * cols, vol = plane * bins;
-  if (vol > t->pmf_capacity) {
-    dev_free(t->pmf);
-    TRY(dev_alloc(&t->pmf, vol));
-    t->pmf_capacity = vol;
-  }
-  if (bins > t->table_capacity) {
-    dev_free(t->table);
-    TRY(dev_alloc(&t->table, (size_t)bins));
-    t->table_capacity = bins;
-  }
-  if (plane > t->map_capacity) {
-    dev_free(t->obs);
-    dev_free(t->unk);
-    dev_free(t->risk);
-    TRY(dev_alloc(&t->obs, plane));
-    TRY(dev_alloc(&t->unk, plane));
-    TRY(dev_alloc(&t->risk, plane));
-    t->map_capacity = plane;
-  }
+  TRY(tdm_reserve(t, bins, plane));
   HIP_TRY(hipMemcpyAsync(t->pmf, pmf, vol, hipMemcpyHostToDevice, t->stream));
   HIP_TRY(hipMemcpyAsync(t->table, bin_to_int8, (size_t)bins, hipMemcpyHostToDevice, t->stream));
   HIP_TRY(hipMemcpyAsync(t->obs, obstacle, plane, hipMemcpyHostToDevice, t->stream));
@@ -288,11 +272,13 @@ static int tdm_reserve(mppi_tdm* t, int bins, size_t plane) {
   size_t vol = plane * (size_t)bins;
   if (vol > t->pmf_capacity) {
     dev_free(t->pmf);
+    t->pmf_capacity = 0;  // (stays 0 if the allocation below fails)
     TRY(dev_alloc(&t->pmf, vol));
     t->pmf_capacity = vol;
   }
   if (bins > t->table_capacity) {
     dev_free(t->table);
+    t->table_capacity = 0;  // (stays 0 if the allocation below fails)
     TRY(dev_alloc(&t->table, (size_t)bins));
     t->table_capacity = bins;
   }
@@ -300,6 +286,7 @@ static int tdm_reserve(mppi_tdm* t, int bins, size_t plane) {
     dev_free(t->obs);
     dev_free(t->unk);
     dev_free(t->risk);
+    t->map_capacity = 0;  // (stays 0 if an allocation below fails)
     TRY(dev_alloc(&t->obs, plane));
     TRY(dev_alloc(&t->unk, plane));
     TRY(dev_alloc(&t->risk, plane));
@@ -331,11 +318,13 @@ extern "C" int mppi_tdm_set_maps_from_pmf(mppi_tdm* t, int kind, const int8_t* p
   const size_t raw_need = src_plane * ((size_t)bins + 2);
   if (raw_need > t->raw_capacity) {
     dev_free(t->raw);
+    t->raw_capacity = 0;  // (stays 0 if the allocation below fails)
     TRY(dev_alloc(&t->raw, raw_need));
     t->raw_capacity = raw_need;
   }
   if (bins > t->bin_values_capacity) {
     dev_free(t->bin_values);
+    t->bin_values_capacity = 0;  // (stays 0 if the allocation below fails)
     TRY(dev_alloc(&t->bin_values, (size_t)bins));
     t->bin_values_capacity = bins;
   }
@@ -911,6 +900,7 @@ static int ensure_packed(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang) {
   if (need > p->cells_capacity) {
     HIP_TRY(hipStreamSynchronize(p->stream));
     dev_free(p->cells);
+    p->cells_capacity = 0;  // (stays 0 if the allocation below fails)
     TRY(dev_alloc(&p->cells, need));
     p->cells_capacity = need;
   }
@@ -928,6 +918,7 @@ static int ensure_packed(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang) {
       if (need16 > p->cells16_capacity) {
         HIP_TRY(hipStreamSynchronize(p->stream));
         dev_free(p->cells16);
+        p->cells16_capacity = 0;  // (stays 0 if the allocation below fails)
         TRY(dev_alloc(&p->cells16, need16));
         p->cells16_capacity = need16;
       }

@@ -24,21 +24,6 @@ constexpr int kUpdateThreads = 256;
 // packet layout (doubles): [0] beta_g  [1] den_g  [2 + 2t + c] num_g[t][c]
 __host__ __device__ inline int packet_len(int n_steps) { return 2 + 2 * n_steps; }
 
-__global__ __launch_bounds__(kUpdateThreads) void k_block_min_from_costs(const float* __restrict__ costs, int n,
-                                                                         float* __restrict__ block_min) {
-  __shared__ float red[kUpdateThreads / 64];
-  int i = blockIdx.x * kUpdateThreads + threadIdx.x;
-  float v = (i < n) ? costs[i] : __builtin_inff();
-  v = wave_min_f32(v);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float m = red[0];
-    for (int k = 1; k < kUpdateThreads / 64; ++k) m = fminf(m, red[k]);
-    block_min[blockIdx.x] = m;
-  }
-}
-
 // u[t] = clip(u[t] + num[t]/den); u_prev mirrors it (the reference aliases
 // u_prev_d to u_cur_d before the update, mppi.py:362)
 __device__ __forceinline__ void apply_update(float2* u, float2* u_prev, int t, double nx, double ny, double den,
