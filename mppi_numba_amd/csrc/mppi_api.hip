@@ -530,7 +530,10 @@ struct mppi_planner {
   std::vector<BatchInst> inst_host;
   BatchInst* inst_dev = nullptr;
   bool inst_set = false, inst_dirty = false;
-  float2* u_host = nullptr;  // pinned (B,T) landing buffer of solve(): no pageable D2H on the hot path
+  // pinned, device-mapped (B,T) mirror of u: the update kernels write it (u_host_dev is the device
+  // view of the same memory), solve() reads it after the stream has drained -- no copy on the hot path
+  float2* u_host = nullptr;
+  float2* u_host_dev = nullptr;
   // device buffers
   float2* noise = nullptr;    // tile-major (n_local, T): the buffer the NEXT rollout/update reads
   float2* noise_buf[2] = {nullptr, nullptr};  // double buffer: noise of iteration k+1 is generated
@@ -652,7 +655,9 @@ static int planner_alloc(mppi_planner* p) {
   TRY(dev_alloc(&p->u, B * T));
   TRY(dev_alloc(&p->u_prev, B * T));
   TRY(dev_alloc(&p->inst_dev, B));
-  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->u_host), B * T * sizeof(float2), hipHostMallocDefault));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->u_host), B * T * sizeof(float2), hipHostMallocMapped));
+  HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->u_host_dev), p->u_host, 0));
+  memset(p->u_host, 0, B * T * sizeof(float2));
   p->inst_host.assign(B, BatchInst{});
   TRY(dev_alloc(&p->costs, N));
   TRY(dev_alloc(&p->weights_out, N));
@@ -1288,7 +1293,7 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
 #define MPPI_LAUNCH_ROWS(APPLY, TC)                                                                             \
   hipLaunchKernelGGL((k_update_rows<APPLY, TC>), grid, dim3(kRowThreads), lds, p->stream, p->w_rel, p->tile_beta, \
                      p->n_inst, p->inst_tiles, p->noise, T, a.lambda_weight, my_packet, p->u, p->u_prev,        \
-                     a.vrange[0], a.vrange[1], a.wrange[0], a.wrange[1], p->stats)
+                     p->u_host_dev, a.vrange[0], a.vrange[1], a.wrange[0], a.wrange[1], p->stats)
   if (apply_here && many_rows) MPPI_LAUNCH_ROWS(true, 4);
   else if (apply_here) MPPI_LAUNCH_ROWS(true, 1);
   else if (many_rows) MPPI_LAUNCH_ROWS(false, 4);
@@ -1301,8 +1306,8 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
 static int launch_apply(mppi_planner* p) {
   const mppi_params& a = p->params;
   hipLaunchKernelGGL(k_apply, dim3(p->B), dim3(kUpdateThreads), 0, p->stream, p->packets, p->cfg.world_size,
-                     p->cfg.rank, p->cfg.num_steps, a.lambda_weight, p->u, p->u_prev, a.vrange[0], a.vrange[1],
-                     a.wrange[0], a.wrange[1], p->stats);
+                     p->cfg.rank, p->cfg.num_steps, a.lambda_weight, p->u, p->u_prev, p->u_host_dev, a.vrange[0],
+                     a.vrange[1], a.wrange[0], a.wrange[1], p->stats);
   HIP_TRY(hipGetLastError());
   return MPPI_OK;
 }
@@ -1432,7 +1437,8 @@ extern "C" int mppi_planner_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang,
   }
   TRY(run_iterations(p, lin, ang, p->params.num_opt));
   const size_t u_bytes = sizeof(float2) * (size_t)p->B * (size_t)p->cfg.num_steps;
-  HIP_TRY(hipMemcpyAsync(p->u_host, p->u, u_bytes, hipMemcpyDeviceToHost, p->stream));
+  // with at least one iteration the last update kernel has written the host-mapped mirror
+  if (p->params.num_opt < 1) HIP_TRY(hipMemcpyAsync(p->u_host, p->u, u_bytes, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   memcpy(u_out, p->u_host, u_bytes);
   return finish_timing(p);

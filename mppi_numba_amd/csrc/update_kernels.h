@@ -26,13 +26,17 @@ __host__ __device__ inline int packet_len(int n_steps) { return 2 + 2 * n_steps;
 
 // u[t] = clip(u[t] + num[t]/den); u_prev mirrors it (the reference aliases
 // u_prev_d to u_cur_d before the update, mppi.py:362)
-__device__ __forceinline__ void apply_update(float2* u, float2* u_prev, int t, double nx, double ny, double den,
-                                             float v_lo, float v_hi, float w_lo, float w_hi) {
+// u_mirror: the same sequence in host-mapped pinned memory (posted PCIe writes), so that solve()
+// only has to wait for the stream instead of queueing a device-to-host copy behind it
+__device__ __forceinline__ void apply_update(float2* u, float2* u_prev, float2* u_mirror, int t, double nx,
+                                             double ny, double den, float v_lo, float v_hi, float w_lo,
+                                             float w_hi) {
   float2 ut = u[t];
   ut.x = clip_f32(ut.x + (float)(nx / den), v_lo, v_hi);
   ut.y = clip_f32(ut.y + (float)(ny / den), w_lo, w_hi);
   u[t] = ut;
   u_prev[t] = ut;
+  u_mirror[t] = ut;
 }
 
 // ---- stage 1: weights relative to the minimum of each tile of 64 rollouts ----------
@@ -77,8 +81,8 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
                                                              const float2* __restrict__ noise, int n_steps,
                                                              float lambda, double* __restrict__ rank_packet,
                                                              float2* __restrict__ u, float2* __restrict__ u_prev,
-                                                             float v_lo, float v_hi, float w_lo, float w_hi,
-                                                             double* __restrict__ stats) {
+                                                             float2* __restrict__ u_mirror, float v_lo, float v_hi,
+                                                             float w_lo, float w_hi, double* __restrict__ stats) {
   extern __shared__ float scale_sh[];  // [n_tiles]
   constexpr int kCols = 1 + 2 * TC;    // den, then (x, y) per row
   __shared__ double red[kRowThreads / 64][kCols];
@@ -92,6 +96,7 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
     rank_packet += (size_t)inst * packet_len(n_steps);
     u += (size_t)inst * n_steps;
     u_prev += (size_t)inst * n_steps;
+    u_mirror += (size_t)inst * n_steps;
     stats += 2 * inst;
   }
   float b = __builtin_inff();
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
     const int j = threadIdx.x, t = t0 + j;
     const double d = red[0][0], sx = red[0][1 + 2 * j], sy = red[0][2 + 2 * j];
     if (APPLY) {
-      apply_update(u, u_prev, t, sx, sy, d, v_lo, v_hi, w_lo, w_hi);
+      apply_update(u, u_prev, u_mirror, t, sx, sy, d, v_lo, v_hi, w_lo, w_hi);
     } else {
       rank_packet[2 + 2 * t] = sx;
       rank_packet[3 + 2 * t] = sy;
@@ -191,13 +196,14 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
 __global__ __launch_bounds__(kUpdateThreads) void k_apply(const double* __restrict__ packets, int world,
                                                           int rank, int n_steps, float lambda,
                                                           float2* __restrict__ u, float2* __restrict__ u_prev,
-                                                          float v_lo, float v_hi, float w_lo, float w_hi,
-                                                          double* __restrict__ stats) {
+                                                          float2* __restrict__ u_mirror, float v_lo, float v_hi,
+                                                          float w_lo, float w_hi, double* __restrict__ stats) {
   const int len = packet_len(n_steps);
   const size_t stride = (size_t)gridDim.x * len;  // doubles per rank
   packets += (size_t)blockIdx.x * len;
   u += (size_t)blockIdx.x * n_steps;
   u_prev += (size_t)blockIdx.x * n_steps;
+  u_mirror += (size_t)blockIdx.x * n_steps;
   stats += 2 * blockIdx.x;
   double beta = packets[0];
   for (int g = 1; g < world; ++g) beta = fmin(beta, packets[g * stride]);
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(kUpdateThreads) void k_apply(const double* __restri
       nx = fma(sg, packets[g * stride + 2 + 2 * t], nx);
       ny = fma(sg, packets[g * stride + 3 + 2 * t], ny);
     }
-    apply_update(u, u_prev, t, nx, ny, den, v_lo, v_hi, w_lo, w_hi);
+    apply_update(u, u_prev, u_mirror, t, nx, ny, den, v_lo, v_hi, w_lo, w_hi);
   }
 }
 
