@@ -563,6 +563,7 @@ struct mppi_planner {
   size_t cells16_capacity = 0;
   int pitch16 = 0;
   bool cells16_valid = false;
+  bool cells16_with_risk = false;  // cells16 holds 32-bit cells with the risk byte (speed-map mode)
   int num_cus = 256;
   int lds_per_cu = 160 * 1024;
   int8_t* risk_ref = nullptr;
@@ -919,7 +920,9 @@ static int ensure_packed(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang) {
     };
     if (lin->compact_ok && grid_7bit(lin) && grid_7bit(ang)) {
       p->pitch16 = ceil_div(lin->cols, 8) * 8;
-      size_t need16 = (size_t)lin->rows * p->pitch16;
+      // speed-map mode: 32-bit cells (16 bits + risk byte) in the same buffer, twice the 16-bit units
+      const bool with_risk = p->cfg.mode == MPPI_MODE_SPEED_MAP && lin->has_risk;
+      size_t need16 = (size_t)lin->rows * p->pitch16 * (with_risk ? 2 : 1);
       if (need16 > p->cells16_capacity) {
         HIP_TRY(hipStreamSynchronize(p->stream));
         dev_free(p->cells16);
@@ -927,10 +930,16 @@ static int ensure_packed(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang) {
         TRY(dev_alloc(&p->cells16, need16));
         p->cells16_capacity = need16;
       }
-      hipLaunchKernelGGL(k_pack_cells16, dim3(ceil_div((long)need16, 256)), dim3(256), 0, p->stream, lin->grid,
-                         ang->grid, lin->cfg.max_cols, lin->obs, lin->unk, lin->rows, lin->cols, p->pitch16,
-                         p->cells16);
+      if (with_risk)
+        hipLaunchKernelGGL(k_pack_cells32_risk, dim3(ceil_div((long)lin->rows * p->pitch16, 256)), dim3(256), 0,
+                           p->stream, lin->grid, ang->grid, lin->cfg.max_cols, lin->obs, lin->unk, lin->risk,
+                           lin->rows, lin->cols, p->pitch16, reinterpret_cast<uint32_t*>(p->cells16));
+      else
+        hipLaunchKernelGGL(k_pack_cells16, dim3(ceil_div((long)need16, 256)), dim3(256), 0, p->stream, lin->grid,
+                           ang->grid, lin->cfg.max_cols, lin->obs, lin->unk, lin->rows, lin->cols, p->pitch16,
+                           p->cells16);
       p->cells16_valid = true;
+      p->cells16_with_risk = with_risk;
     }
   } else {
     dim3 grid((unsigned)(lin->rows * ceil_div(lin->cols, 64)), (unsigned)ceil_div(M, 64));
@@ -979,10 +988,12 @@ static bool plan_lds_window(mppi_planner* p, DevParams& d, size_t* lds_bytes) {
   const int T = p->cfg.num_steps;
   const size_t head = sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);
   const size_t budget = (size_t)p->lds_per_cu - 1024;  // leave room for the runtime's own use
-  if (!p->cells16_valid || p->cfg.mode != MPPI_MODE_DET) return false;
+  if (!p->cells16_valid) return false;
+  if (p->cfg.mode == MPPI_MODE_SPEED_MAP ? !p->cells16_with_risk : p->cfg.mode != MPPI_MODE_DET) return false;
+  const size_t cell_bytes = p->cells16_with_risk ? sizeof(uint32_t) : sizeof(uint16_t);
   const mppi_params& a = p->params;
   d.pitch16 = p->pitch16;
-  const size_t whole = (size_t)d.rows * p->pitch16 * sizeof(uint16_t);
+  const size_t whole = (size_t)d.rows * p->pitch16 * cell_bytes;
   // cells reachable from x0 within the horizon (plus a margin), columns in multiples of 8
   double vmax = std::fmax(std::fabs((double)a.vrange[0]), std::fabs((double)a.vrange[1]));
   double trmax = std::fmax(std::fabs(d.lin_lo), std::fabs(d.lin_lo + (double)d.lin_max_byte * d.lin_ratio));
@@ -997,7 +1008,7 @@ static bool plan_lds_window(mppi_planner* p, DevParams& d, size_t* lds_bytes) {
       long reach = (long)std::ceil(reach_m / (double)a.res) + 2;
       long wr = std::min((long)d.rows, 2 * reach + 1);
       long wc = std::min((long)p->pitch16, (2 * reach + 1 + 7) / 8 * 8 + 8);
-      size_t wbytes = (size_t)wr * (size_t)wc * sizeof(uint16_t);
+      size_t wbytes = (size_t)wr * (size_t)wc * cell_bytes;
       if (wbytes < whole) {
         if (head + wbytes > budget) return false;
         for (BatchInst& I : p->inst_host) {
@@ -1024,7 +1035,7 @@ static bool plan_lds_window(mppi_planner* p, DevParams& d, size_t* lds_bytes) {
     r1 = std::min((long)d.rows, yi0 + reach + 1);
     c0 = std::max(0L, xi0 - reach) / 8 * 8;
     c1 = std::min((long)p->pitch16, (std::min((long)d.cols, xi0 + reach + 1) + 7) / 8 * 8);
-    if (r1 > r0 && c1 > c0) bytes = (size_t)(r1 - r0) * (size_t)(c1 - c0) * sizeof(uint16_t);
+    if (r1 > r0 && c1 > c0) bytes = (size_t)(r1 - r0) * (size_t)(c1 - c0) * cell_bytes;
   }
   if (bytes < whole) {  // the reach window is smaller: less to copy, more LDS left
     if (head + bytes > budget) return false;
@@ -1194,14 +1205,41 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
       }
       break;
     }
-    case MPPI_MODE_SPEED_MAP:
+    case MPPI_MODE_SPEED_MAP: {
       p->tile_packets_fresh = false;
+      size_t lds_win = 0;
+      const bool have_window = plan_lds_window(p, d, &lds_win);  // 32-bit cells: 16 bits + risk byte
       TRY(upload_instances(p));
+      const mppi_params& a = p->params;
+      double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
+      double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
+      double dmax = (double)a.dt * wmax * trmax;
+      static const bool no_fused = getenv("MPPI_NO_FUSED") != nullptr;  // developer switch (ablation)
+      if (have_window && EXACT && BOUNDED && std::isfinite(dmax) && dmax <= 0.36 && T <= 2000 && !no_fused) {
+        int waves = ceil_div(ceil_div(N, 64), p->num_cus);
+        waves = waves < 4 ? 4 : (waves > 16 ? 16 : waves);
+        if (p->inst_set) while (p->inst_tiles % waves != 0) --waves;
+        int res_exp = 0;
+        const bool pow2res = std::frexp((double)a.res, &res_exp) == 0.5;
+        auto fused = pow2res ? k_rollout_fused<true, true> : k_rollout_fused<false, true>;
+        if (lds_win > 64 * 1024)
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fused),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
+        hipLaunchKernelGGL(fused, dim3(ceil_div(N, 64 * waves)), dim3(64 * waves), lds_win, p->stream, d, p->cells16,
+                           p->noise, p->u, p->costs, p->w_rel, p->tile_beta);
+        char buf[200];
+        snprintf(buf, sizeof(buf), "k_rollout_fused speed_map pow2res=%d waves_per_wg=%d window=%dx%d problems=%d",
+                 (int)pow2res, waves, d.win_rows, d.win_cols, p->inst_set ? p->B : 0);
+        p->last_rollout = buf;
+        p->tile_packets_fresh = true;
+        break;
+      }
       hipLaunchKernelGGL((k_rollout_map<MAP_SPEED, EXACT, BOUNDED, false>), dim3(ceil_div(N, 64)), dim3(64),
                          lds_map, p->stream, d, p->cells, (const uint16_t*)nullptr, (const int8_t*)p->risk_ref,
                          p->noise, p->u, p->costs);
       p->last_rollout = "k_rollout_map speed_map global_cells exact=" + std::to_string((int)EXACT);
       break;
+    }
     case MPPI_MODE_TDM: {
       int mp2 = next_pow2(M);
       int threads = ceil_div(M, 64) * 64;

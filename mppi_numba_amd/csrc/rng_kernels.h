@@ -287,6 +287,24 @@ __global__ void k_pack_cells16(const int8_t* __restrict__ lin, const int8_t* __r
   cells16[i] = (uint16_t)v;
 }
 
+// speed-map mode: the same 16 bits plus the risk traction byte in bits 16..23 (32-bit cells,
+// same pitch in cells), for the LDS window of k_rollout_fused<.., SPEED>
+__global__ void k_pack_cells32_risk(const int8_t* __restrict__ lin, const int8_t* __restrict__ ang, int grid_stride,
+                                    const int8_t* __restrict__ obs, const int8_t* __restrict__ unk,
+                                    const int8_t* __restrict__ risk, int rows, int cols, int pitch,
+                                    uint32_t* __restrict__ cells32) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * pitch) return;
+  int r = i / pitch, c = i % pitch;
+  uint32_t v = 0;
+  if (c < cols) {
+    uint32_t l = (uint8_t)lin[(size_t)r * grid_stride + c] & 127u, a = (uint8_t)ang[(size_t)r * grid_stride + c] & 127u;
+    uint32_t o = (uint8_t)obs[(size_t)r * cols + c] & 1u, k = (uint8_t)unk[(size_t)r * cols + c] & 1u;
+    v = l | (a << 7) | (o << 14) | (k << 15) | ((uint32_t)(uint8_t)risk[(size_t)r * cols + c] << 16);
+  }
+  cells32[i] = v;
+}
+
 // cellsM[(r*cols+c)*M + m]: transpose (M,R,C) -> (R,C,M) through an LDS tile
 // of 64 samples x 64 cells so that both the byte reads (along c) and the word
 // writes (along m) are contiguous.

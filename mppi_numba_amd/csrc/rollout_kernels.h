@@ -216,14 +216,17 @@ __device__ __forceinline__ void map_step(const DevParams& P, const uint32_t* __r
 // of the workgroup.  Window columns [win_c0, win_c0 + win_cols) are multiples of 8 cells =
 // 16-byte vectors.  Batches of eight loads per lane, no branch inside a batch: indices past
 // the end are clamped to the last vector, which is then simply written again.
+// (CELL_BYTES = 4: the 32-bit cells of the speed-map mode, same geometry in cells)
+template <int CELL_BYTES = 2>
 __device__ __forceinline__ void copy_window_to_lds(const DevParams& P, const uint16_t* __restrict__ cells16,
                                                    uint16_t* lds_map, int first_thread, int n_threads) {
   const int tid = (int)threadIdx.x - first_thread;
   if (tid < 0 || tid >= n_threads) return;
-  const int vec_per_row = P.win_cols / 8;
+  constexpr int kPerVec = 16 / CELL_BYTES;  // cells per 16-byte vector
+  const int vec_per_row = P.win_cols / kPerVec;
   const int total = P.win_rows * vec_per_row;
-  const int src_pitch = P.pitch16 / 8;
-  const uint4* src = reinterpret_cast<const uint4*>(cells16) + ((size_t)P.win_r0 * P.pitch16 + P.win_c0) / 8;
+  const int src_pitch = P.pitch16 / kPerVec;
+  const uint4* src = reinterpret_cast<const uint4*>(cells16) + ((size_t)P.win_r0 * P.pitch16 + P.win_c0) / kPerVec;
   uint4* dst = reinterpret_cast<uint4*>(lds_map);
   const bool flat = (vec_per_row == src_pitch);  // full-width window: one contiguous run
   const int step = 8 * n_threads;
@@ -321,7 +324,7 @@ __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
 // state keeps integrating (harmless: only the cost is frozen), as in the pipelined kernel.
 // LDS: [T] double2 control ratios | [T] float2 u | window of 16-bit cells.
 // -------------------------------------------------------------------------
-template <bool POW2RES>
+template <bool POW2RES, bool SPEED = false>
 __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells16,
                                 const float2* __restrict__ noise, const float2* __restrict__ u,
                                 float* __restrict__ costs, float* __restrict__ w_rel,
@@ -332,7 +335,7 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
   const int T = P.n_steps, N = P.n_local;
   float2* us = reinterpret_cast<float2*>(uos + T);
   uint16_t* lds_map = reinterpret_cast<uint16_t*>(uos + T + (T + 1) / 2);
-  copy_window_to_lds(P, cells16, lds_map, 0, (int)blockDim.x);
+  copy_window_to_lds<SPEED ? 4 : 2>(P, cells16, lds_map, 0, (int)blockDim.x);
   for (int t = threadIdx.x; t < T; t += blockDim.x) us[t] = u[t];
   stage_control_ratios(P, u, uos);  // ends with a barrier
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -348,7 +351,7 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
   const double dt64 = (double)P.dt, gt2 = (double)P.gt2;
   const float win_c0f = (float)P.win_c0, win_r0f = (float)P.win_r0;
   const float win_last_col = (float)(P.win_cols - 1), win_last_row = (float)(P.win_rows - 1);
-  const int win_pitch_bytes = 2 * P.win_cols;
+  const int win_pitch_bytes = (SPEED ? 4 : 2) * P.win_cols;
   const char* lds_bytes = reinterpret_cast<const char*>(lds_map);
 
   auto step = [&](float2 ut, float2 e) {
@@ -360,7 +363,17 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
       xi = clamp_index(floordiv_to_int(x - P.xlo, P.res, P.inv_res) - P.win_c0, P.win_cols);
       yi = clamp_index(floordiv_to_int(y - P.ylo, P.res, P.inv_res) - P.win_r0, P.win_rows);
     }
-    const uint32_t c16 = *reinterpret_cast<const uint16_t*>(lds_bytes + (__mul24(yi, win_pitch_bytes) + (xi << 1)));
+    uint32_t c16;
+    double step_time = dt64;
+    if (SPEED) {
+      // 32-bit cell: the 16 bits below + the risk traction byte; time per step = dt over the
+      // risk-aware effective speed (mppi.py:1095-1096)
+      c16 = *reinterpret_cast<const uint32_t*>(lds_bytes + (__mul24(yi, win_pitch_bytes) + (xi << 2)));
+      const double eff = fma(P.lin_ratio, (double)(int)(int8_t)(c16 >> 16), P.lin_lo);
+      step_time = dt64 / (eff + 1e-6);
+    } else {
+      c16 = *reinterpret_cast<const uint16_t*>(lds_bytes + (__mul24(yi, win_pitch_bytes) + (xi << 1)));
+    }
     const double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), P.lin_lo);
     const double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), P.ang_lo);
     const double qv = dt64 * (double)clip_f32(ut.x + e.x, P.v_lo, P.v_hi);  // exact: float32 factors
@@ -375,7 +388,7 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
     th64 = th_new;
     const double dx = (double)(P.xg - x), dy = (double)(P.yg - y);
     const double nd2 = fma(dx, dx, dy * dy);
-    float c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(nd2), dt64));
+    float c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(nd2), step_time));
     c1 = c1 + ((c16 & 0x4000u) ? P.obs_cost : 0.0f);  // cell the step STARTED in (mppi.py:971-998)
     c1 = c1 + ((c16 & 0x8000u) ? P.unk_cost : 0.0f);
     const bool hit = nd2 <= gt2, act = !done;

@@ -83,3 +83,48 @@ def test_speed_map_edge_sizes(n, t_steps):
                          lin.obstacle_map_d.copy_to_host(), lin.unknown_map_d.copy_to_host(), noise, u_in,
                          risk=lin.risk_traction_map_d.copy_to_host())
     assert np.array_equal(got, want)
+    assert "k_rollout_fused speed_map" in planner.last_rollout_kernel()
+
+
+def test_speed_map_large_reach_uses_global_cells_and_matches_oracle():
+    """Reach window of 32-bit cells (traction bits + risk byte) larger than LDS: the general
+    kernel on the global cell array; same costs."""
+    from mppi_numba_amd.config import Config
+    from mppi_numba_amd.mppi import MPPI_Numba
+    from mppi_numba_amd.terrain import TDM_Numba
+    pmf, obstacle, unknown, td = bench.synthetic_world("c3", np.random.default_rng(0))
+    cfg = Config(T=10.0, dt=0.1, num_grid_samples=1, num_control_rollouts=2048, max_speed_padding=5.0,
+                 num_vis_state_rollouts=1, max_map_dim=(260, 260), seed=2, enforce_recommended_limits=False,
+                 use_nom_dynamics_with_speed_map=True)
+    lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
+    lin.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)
+    ang.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)
+    planner = MPPI_Numba(cfg)
+    params = bench.make_params("c2")
+    params.update(x0=np.array([32.0, 32.0, 0.5]), xgoal=np.array([50.0, 40.0]))
+    planner.setup(params, lin, ang)
+    planner.solve()
+    planner.sample_noise()
+    noise, u_in = planner.noise_samples_d.copy_to_host(), planner.u_cur_d.copy_to_host()
+    planner.rollout()
+    assert "k_rollout_map speed_map global_cells" in planner.last_rollout_kernel()
+    p = O.make_params(params, lin.res, lin.padded_xlimits, lin.padded_ylimits,
+                      lin.bin_values_bounds_d.copy_to_host(), ang.bin_values_bounds_d.copy_to_host())
+    want = O.rollout_det(p, lin.sample_grid_batch_d.copy_to_host(), ang.sample_grid_batch_d.copy_to_host(),
+                         lin.obstacle_map_d.copy_to_host(), lin.unknown_map_d.copy_to_host(), noise, u_in,
+                         risk=lin.risk_traction_map_d.copy_to_host())
+    got = planner.costs_d.copy_to_host()
+    ulps = ulp_diff_f32(got, want)
+    assert (ulps == 0).mean() >= 0.999
+    # the same problem from the map corner: the window fits, the fused kernel runs, same bar
+    params.update(x0=np.array([4.0, 4.0, 0.5]))
+    planner.set_params(params)
+    planner.rollout()
+    assert "k_rollout_fused speed_map" in planner.last_rollout_kernel()
+    p = O.make_params(params, lin.res, lin.padded_xlimits, lin.padded_ylimits,
+                      lin.bin_values_bounds_d.copy_to_host(), ang.bin_values_bounds_d.copy_to_host())
+    want = O.rollout_det(p, lin.sample_grid_batch_d.copy_to_host(), ang.sample_grid_batch_d.copy_to_host(),
+                         lin.obstacle_map_d.copy_to_host(), lin.unknown_map_d.copy_to_host(), noise, u_in,
+                         risk=lin.risk_traction_map_d.copy_to_host())
+    ulps = ulp_diff_f32(planner.costs_d.copy_to_host(), want)
+    assert (ulps == 0).mean() >= 0.999
