@@ -538,8 +538,8 @@ struct mppi_planner {
   float2* noise = nullptr;    // tile-major (n_local, T): the buffer the NEXT rollout/update reads
   float2* noise_buf[2] = {nullptr, nullptr};  // double buffer: noise of iteration k+1 is generated
   int noise_cur = 0;                           // while iteration k runs (in-launch or on noise_stream)
-  // throughput regime: no CU is idle during the rollout, but the rollout is issue-bound and the
-  // generator write-bound, so the noise of iteration k+1 runs beside rollout k on a second stream
+  // throughput regime (no idle CU for in-launch generation): the noise of iteration k+1 runs beside
+  // rollout k on a second stream while the rollout leaves wave slots free (run_iterations)
   hipStream_t noise_stream = nullptr;
   hipEvent_t ev_buf_free = nullptr, ev_noise_ready = nullptr;
   std::string last_rollout;        // which rollout kernel variant the last launch used (diagnostic)
