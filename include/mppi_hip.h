@@ -265,6 +265,11 @@ int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity)
 /* diagnostic: compares the library's single-block Philox4x32-10 with rocRAND's engine on
  * 65536 (seed, subsequence, offset) triples; *mismatches must come back 0 */
 int mppi_selftest_philox(int device, int* mismatches);
+/* developer measurement: wall microseconds per iteration of `iterations` (even) x {noise,
+ * rollout, update}, launched directly vs replayed from a captured hipGraph, `replays`
+ * times each.  Replays reuse the captured arguments: a measurement, not a way to plan. */
+int mppi_planner_graph_probe(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int iterations, int replays,
+                             float* us_direct, float* us_graph);
 
 /* ---- multi-GPU: N sharded over ranks, one RCCL all-gather of (2T+2) floats
  *      per iteration (not in the reference) ------------------------------------ */

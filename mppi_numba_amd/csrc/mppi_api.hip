@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -1673,6 +1674,59 @@ extern "C" int mppi_planner_last_elapsed_ms(mppi_planner* p, float* ms) {
   REQUIRE(p && ms, MPPI_ERR_INVALID, "NULL argument");
   TRY(finish_timing(p));
   *ms = p->last_elapsed_ms;
+  return MPPI_OK;
+}
+
+// Developer measurement (profiles/r01_ablation.md): `iterations` x {noise,
+// rollout, update} launched directly versus replayed from a hipGraph captured off the planner's
+// stream, `replays` times each, wall clock per iteration in microseconds.  A measurement only: a
+// replay reuses the captured by-value arguments (Philox epoch, start state, noise buffer parity),
+// so it is not a way to run the planner.
+extern "C" int mppi_planner_graph_probe(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int iterations, int replays,
+                                        float* us_direct, float* us_graph) {
+  REQUIRE(p && us_direct && us_graph, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(iterations >= 2 && iterations % 2 == 0 && replays >= 1, MPPI_ERR_INVALID,
+          "iterations must be even (noise double buffer) and replays >= 1");
+  REQUIRE(p->cfg.world_size == 1 && !p->comm, MPPI_ERR_INVALID, "single-GPU measurement");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  const bool profile = p->profile_stages;
+  p->profile_stages = false;
+  auto now_us = [] {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return 1e6 * (double)ts.tv_sec + 1e-3 * (double)ts.tv_nsec;
+  };
+  // warm: buffers packed, instances uploaded, kernel attributes set
+  TRY(run_iterations(p, lin, ang, iterations));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  TRY(finish_timing(p));
+  double t0 = now_us();
+  for (int r = 0; r < replays; ++r) TRY(run_iterations(p, lin, ang, iterations));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  *us_direct = (float)((now_us() - t0) / ((double)replays * iterations));
+  TRY(finish_timing(p));
+
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+  int rc = run_iterations(p, lin, ang, iterations);
+  hipError_t end = hipStreamEndCapture(p->stream, &graph);
+  p->elapsed_pending = false;  // the events were captured, not recorded
+  if (rc != MPPI_OK) {
+    if (graph) (void)hipGraphDestroy(graph);
+    return rc;
+  }
+  HIP_TRY(end);
+  HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  HIP_TRY(hipGraphLaunch(exec, p->stream));  // first launch uploads the executable graph
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  t0 = now_us();
+  for (int r = 0; r < replays; ++r) HIP_TRY(hipGraphLaunch(exec, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  *us_graph = (float)((now_us() - t0) / ((double)replays * iterations));
+  (void)hipGraphExecDestroy(exec);
+  (void)hipGraphDestroy(graph);
+  p->profile_stages = profile;
   return MPPI_OK;
 }
 
