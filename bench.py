@@ -171,6 +171,9 @@ def main():
     ap.add_argument("--problems", type=int, default=None, help="c5: problems per GPU (default 64)")
     ap.add_argument("--math", default="exact", choices=["exact", "fast"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=0, metavar="ITERATIONS",
+                    help="hipGraph replay of the iteration loop, that many (even) iterations per graph; "
+                         "0 = direct launches (single GPU; same results)")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "host"],
                     help="multi-GPU packet exchange: RCCL all-gather on the stream (default) or, for debugging "
                          "on a box where several ranks must share one GPU, host-staged over gloo")
@@ -272,6 +275,9 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    if args.graph and world == 1:
+        planner.set_graph_replay(True, args.graph)
+
     # warm start: one full solve (samples the grids) + 10 iterations
     planner.solve()
     planner.iterate_async(10)
@@ -333,6 +339,7 @@ def main():
                    "horizon_steps": t_steps, "traction_samples": m, "padded_grid": [int(rp), int(cp)],
                    "rng": "rocRAND philox4x32-10", "math": args.math,
                    "problems_per_gpu": problems or 1,
+                   "graph_replay_iterations": args.graph if world == 1 else 0,
                    "rollout_kernel": planner.last_rollout_kernel(),
                    "sharding": "independent problems over ranks, no exchange" if problems else
                                "control samples over ranks, 1 all-gather of (2T+2) f64 per step",

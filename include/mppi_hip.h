@@ -265,6 +265,18 @@ int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity)
 /* diagnostic: compares the library's single-block Philox4x32-10 with rocRAND's engine on
  * 65536 (seed, subsequence, offset) triples; *mismatches must come back 0 */
 int mppi_selftest_philox(int device, int* mismatches);
+/* hipGraph replay of the iteration loop (off by default; single GPU).
+ * iterations_per_graph: 0 = off, else an even number (the noise double buffer must come
+ * back to where it was).  When on, every iteration also produces the noise of its
+ * successor, that many iterations are captured into a graph the first time and replayed
+ * for as long as nothing a kernel argument carries has changed (parameters, maps, start
+ * state of a single-problem handle ...); the Philox call epoch then lives in device
+ * memory.  Results are identical to the direct loop.  Worth it for loops of many
+ * iterations (params.num_opt, iterate_async); a handle whose start state changes every
+ * call re-captures every call unless it is a batched handle (set_instances), whose
+ * start / goal live in device memory. */
+int mppi_planner_set_graph_replay(mppi_planner* p, int iterations_per_graph);
+int mppi_planner_graph_stats(mppi_planner* p, long* captures, long* replays);
 /* developer measurement: wall microseconds per iteration of `iterations` (even) x {noise,
  * rollout, update}, launched directly vs replayed from a captured hipGraph, `replays`
  * times each.  Replays reuse the captured arguments: a measurement, not a way to plan. */

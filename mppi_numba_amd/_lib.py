@@ -119,6 +119,8 @@ SIGNATURES = {
     "mppi_planner_describe_last_rollout": [_vp, C.c_char_p, C.c_int],
     "mppi_selftest_philox": [C.c_int, C.POINTER(C.c_int)],
     "mppi_planner_graph_probe": [_vp, _vp, _vp, C.c_int, C.c_int, _f32p, _f32p],
+    "mppi_planner_set_graph_replay": [_vp, C.c_int],
+    "mppi_planner_graph_stats": [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)],
     "mppi_comm_unique_id": [C.c_char_p],
     "mppi_planner_comm_init": [_vp, C.c_char_p],
     "mppi_planner_packet_len": [_vp, C.POINTER(C.c_int)],

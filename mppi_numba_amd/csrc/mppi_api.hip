@@ -543,9 +543,25 @@ struct mppi_planner {
   // rollout k on a second stream while the rollout leaves wave slots free (run_iterations)
   hipStream_t noise_stream = nullptr;
   hipEvent_t ev_buf_free = nullptr, ev_noise_ready = nullptr;
+  // hipGraph replay of the iteration loop (mppi_planner_set_graph_replay): two iterations
+  // (one round of the noise double buffer) captured once, replayed while nothing a kernel
+  // argument carries has changed.  See run_iterations.
+  bool graph_on = false;
+  int graph_chunk = 2;                    // iterations per captured graph
+  unsigned long long* gen_dev = nullptr;  // device: update kernels executed since graph mode was enabled
+  uint64_t bumps_launched = 0;            // host mirror of *gen_dev once the stream has drained
+  bool primed = false;                    // noise_buf[noise_cur ^ 1] already holds the NEXT iteration's noise
+  bool graph_warm = false;                // one direct iteration has run since graph mode was enabled
+  // one cached graph per parity of the noise double buffer (a call with an odd number of
+  // iterations leaves the other parity behind)
+  hipGraph_t graph[2] = {nullptr, nullptr};
+  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+  std::vector<unsigned char> graph_sig[2];  // everything the captured launches took by value
+  long graph_replays = 0, graph_captures = 0;
   std::string last_rollout;        // which rollout kernel variant the last launch used (diagnostic)
   bool next_noise_wanted = false;  // the coming rollout launch should also generate noise_buf[cur^1]
   bool next_noise_done = false;    // ... and it did
+  bool noise_on_side_stream = false;  // the noise produced ahead is still in flight on noise_stream
   float2* staging = nullptr;  // (n_local,T) host-layout staging for set/get_noise
   float2* u = nullptr;        // [T]
   float2* u_prev = nullptr;   // [T]
@@ -595,6 +611,16 @@ struct mppi_planner {
   ncclComm_t comm = nullptr;
 };
 
+static void drop_graphs(mppi_planner* p) {
+  for (int i = 0; i < 2; ++i) {
+    if (p->graph_exec[i]) (void)hipGraphExecDestroy(p->graph_exec[i]);
+    if (p->graph[i]) (void)hipGraphDestroy(p->graph[i]);
+    p->graph_exec[i] = nullptr;
+    p->graph[i] = nullptr;
+    p->graph_sig[i].clear();
+  }
+}
+
 extern "C" int mppi_planner_destroy(mppi_planner* p) {
   if (!p) return MPPI_OK;
   (void)hipSetDevice(p->cfg.device);
@@ -625,6 +651,8 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   if (p->ev_end) (void)hipEventDestroy(p->ev_end);
   for (auto& e : p->ev_stage)
     if (e) (void)hipEventDestroy(e);
+  drop_graphs(p);
+  dev_free(p->gen_dev);
   if (p->noise_stream) {
     (void)hipStreamSynchronize(p->noise_stream);
     (void)hipStreamDestroy(p->noise_stream);
@@ -748,12 +776,23 @@ extern "C" int mppi_planner_create(const mppi_planner_cfg* cfg, mppi_planner** o
   return MPPI_OK;
 }
 
+// Graph mode keeps the noise of the next iteration ready.  Dropping it gives its Philox epoch
+// back, so that the sequence of noise blocks the iterations consume stays the one of the direct
+// loop (the xoroshiro-compatible generator cannot rewind: it simply moves on).
+static void discard_noise_ahead(mppi_planner* p) {
+  if (p->primed && p->cfg.rng == MPPI_RNG_PHILOX) --p->noise_epoch;
+  p->primed = false;
+  p->noise_on_side_stream = false;
+}
+
 extern "C" int mppi_planner_set_params(mppi_planner* p, const mppi_params* params) {
   REQUIRE(p && params, MPPI_ERR_INVALID, "NULL argument");
   REQUIRE(params->lambda_weight > 0.0f, MPPI_ERR_INVALID, "lambda_weight must be > 0");
   REQUIRE(params->num_opt >= 0, MPPI_ERR_INVALID, "num_opt must be >= 0");
   REQUIRE(p->cfg.mode == MPPI_MODE_BAREBONE || params->res > 0.0f, MPPI_ERR_INVALID, "res must be > 0");
   REQUIRE(params->u_std[0] > 0.0f && params->u_std[1] > 0.0f, MPPI_ERR_INVALID, "u_std must be > 0");
+  if (p->params_set && (p->params.u_std[0] != params->u_std[0] || p->params.u_std[1] != params->u_std[1]))
+    discard_noise_ahead(p);  // it was scaled with the old standard deviations
   p->params = *params;
   p->params_set = true;
   p->inst_dirty = true;  // the per-problem window origins depend on the reach
@@ -964,7 +1003,11 @@ static NoiseJob make_noise_job(mppi_planner* p, float2* target) {
   j.out = target;
   j.states = (p->cfg.rng == MPPI_RNG_XOROSHIRO) ? p->states : nullptr;
   j.seed = p->cfg.seed;
-  j.epoch = p->noise_epoch;
+  // graph mode: the epoch is split into a by-value part that stays the same from one replay to
+  // the next and the device-side count of executed updates (bumps_launched mirrors it: every
+  // earlier update is ahead of this generator in stream order)
+  j.gen_counter = p->graph_on ? (const uint64_t*)p->gen_dev : nullptr;
+  j.epoch = p->graph_on ? p->noise_epoch - p->bumps_launched : p->noise_epoch;
   j.n_local = p->n_local;
   j.n_offset = p->n_offset;
   j.n_steps = p->cfg.num_steps;
@@ -1332,12 +1375,14 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
 #define MPPI_LAUNCH_ROWS(APPLY, TC)                                                                             \
   hipLaunchKernelGGL((k_update_rows<APPLY, TC>), grid, dim3(kRowThreads), lds, p->stream, p->w_rel, p->tile_beta, \
                      p->n_inst, p->inst_tiles, p->noise, T, a.lambda_weight, my_packet, p->u, p->u_prev,        \
-                     p->u_host_dev, a.vrange[0], a.vrange[1], a.wrange[0], a.wrange[1], p->stats)
+                     p->u_host_dev, a.vrange[0], a.vrange[1], a.wrange[0], a.wrange[1], p->stats,                \
+                     p->graph_on ? p->gen_dev : (unsigned long long*)nullptr)
   if (apply_here && many_rows) MPPI_LAUNCH_ROWS(true, 4);
   else if (apply_here) MPPI_LAUNCH_ROWS(true, 1);
   else if (many_rows) MPPI_LAUNCH_ROWS(false, 4);
   else MPPI_LAUNCH_ROWS(false, 1);
 #undef MPPI_LAUNCH_ROWS
+  if (p->graph_on) ++p->bumps_launched;
   HIP_TRY(hipGetLastError());
   return MPPI_OK;
 }
@@ -1374,6 +1419,78 @@ static int launch_update(mppi_planner* p, bool prof) {
   return launch_apply(p);
 }
 
+// One iteration: {noise unless it was produced ahead, rollout (+ the next iteration's noise when
+// `want_next`), update}.  `have_noise`: noise_buf[noise_cur ^ 1] already holds this iteration's
+// noise; on return it says the same for the following iteration.
+static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_noise, bool want_next, bool prof) {
+  // (below ~4M rollout-steps the generator takes less than the ~12 us a cross-stream dependency costs)
+  static const bool no_side_stream = getenv("MPPI_NO_SIDE_STREAM") != nullptr;  // developer switch
+  // and above 8 rollout waves per CU the register file has no room for the generator's waves: it
+  // then runs in the rollout's tail and collides with the update (measured, profiles/r01_ablation.md)
+  const bool side_stream_pays = (long)p->n_local * p->cfg.num_steps >= 4L * 1000 * 1000 &&
+                                ceil_div(ceil_div(p->n_local, 64), p->num_cus) <= 8 && !no_side_stream;
+  if (prof) HIP_TRY(hipEventRecord(p->ev_stage[0], p->stream));
+  if (have_noise) {
+    p->noise_cur ^= 1;
+    if (p->noise_on_side_stream) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_noise_ready, 0));
+    p->noise_on_side_stream = false;
+  } else {
+    TRY(launch_noise(p, p->noise_buf[p->noise_cur]));
+  }
+  p->noise = p->noise_buf[p->noise_cur];
+  p->next_noise_wanted = want_next;
+  p->next_noise_done = false;
+  if (prof) HIP_TRY(hipEventRecord(p->ev_stage[1], p->stream));
+  // the other noise buffer was last read by the previous update, which is behind us on this stream
+  if (want_next && side_stream_pays) HIP_TRY(hipEventRecord(p->ev_buf_free, p->stream));
+  TRY(launch_rollout(p, d));
+  have_noise = p->next_noise_done;
+  if (want_next && !have_noise && side_stream_pays) {
+    HIP_TRY(hipStreamWaitEvent(p->noise_stream, p->ev_buf_free, 0));
+    TRY(launch_noise(p, p->noise_buf[p->noise_cur ^ 1], p->noise_stream));
+    HIP_TRY(hipEventRecord(p->ev_noise_ready, p->noise_stream));
+    have_noise = p->noise_on_side_stream = true;
+    if (p->graph_on) {
+      // graph mode: join before the update, which advances the epoch counter the generator reads
+      // (and a captured iteration must not leave a fork open)
+      HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_noise_ready, 0));
+      p->noise_on_side_stream = false;
+    }
+  }
+  p->next_noise_wanted = false;
+  if (prof) HIP_TRY(hipEventRecord(p->ev_stage[2], p->stream));
+  TRY(launch_update(p, prof));
+  if (prof) HIP_TRY(hipEventRecord(p->ev_stage[5], p->stream));
+  return MPPI_OK;
+}
+
+// Everything the launches of an iteration take by value or derive on the host: a captured graph
+// may be replayed only while none of it has changed.
+static void graph_signature(const mppi_planner* p, const DevParams& d, const mppi_tdm* lin, const mppi_tdm* ang,
+                            std::vector<unsigned char>& out) {
+  struct Sig {
+    DevParams d;
+    mppi_params params;
+    const void *lin, *ang, *cells, *cells16, *cc, *sample_costs;
+    uint64_t lin_grid, ang_grid, lin_maps, epoch_bias;
+    int noise_cur, inst_set, want_sample_costs, pad;
+  } sig;
+  memset(&sig, 0, sizeof(sig));
+  sig.d = d;
+  sig.params = p->params;
+  if (p->inst_set) {  // batched handle: start and goal are read from device memory, not from arguments
+    sig.d.x0 = sig.d.y0 = sig.d.th0 = sig.d.xg = sig.d.yg = 0.0f;
+    memset(sig.params.x0, 0, sizeof(sig.params.x0));
+    memset(sig.params.xgoal, 0, sizeof(sig.params.xgoal));
+  }
+  sig.lin = lin; sig.ang = ang; sig.cells = p->cells; sig.cells16 = p->cells16; sig.cc = p->cc_scratch;
+  sig.sample_costs = p->sample_costs;
+  sig.lin_grid = p->packed_lin_grid; sig.ang_grid = p->packed_ang_grid; sig.lin_maps = p->packed_lin_maps;
+  sig.epoch_bias = p->noise_epoch - p->bumps_launched;
+  sig.noise_cur = p->noise_cur; sig.inst_set = p->inst_set; sig.want_sample_costs = p->want_sample_costs;
+  out.assign(reinterpret_cast<unsigned char*>(&sig), reinterpret_cast<unsigned char*>(&sig) + sizeof(sig));
+}
+
 static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int iterations) {
   REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
   TRY(check_tdms(p, lin, ang));
@@ -1383,43 +1500,68 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
   // The noise of iteration k+1 does not depend on iteration k.  When the pipelined rollout
   // kernel runs, its spare workgroups generate it into the other half of the double buffer
   // (same launch, no extra dependency); otherwise it is generated in line.
-  bool have_noise = false, noise_on_side_stream = false;
-  // (below ~4M rollout-steps the generator takes less than the ~12 us a cross-stream dependency costs)
-  static const bool no_side_stream = getenv("MPPI_NO_SIDE_STREAM") != nullptr;  // developer switch
-  // and above 8 rollout waves per CU the register file has no room for the generator's waves: it
-  // then runs in the rollout's tail and collides with the update (measured, profiles/r01_ablation.md)
-  const bool side_stream_pays = (long)p->n_local * p->cfg.num_steps >= 4L * 1000 * 1000 &&
-                                ceil_div(ceil_div(p->n_local, 64), p->num_cus) <= 8 && !no_side_stream;
-  for (int k = 0; k < iterations; ++k) {
-    // profiled iteration: a steady-state one when there is one (its rollout launch then
-    // also carries the noise of the following iteration), else the last
-    bool prof = p->profile_stages && k == (iterations >= 3 ? iterations - 2 : iterations - 1);
-    if (prof) HIP_TRY(hipEventRecord(p->ev_stage[0], p->stream));
-    if (have_noise) {
-      p->noise_cur ^= 1;
-      if (noise_on_side_stream) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_noise_ready, 0));
-      noise_on_side_stream = false;
-    } else {
-      TRY(launch_noise(p, p->noise_buf[p->noise_cur]));
+  const bool use_graph = p->graph_on && !p->profile_stages && p->cfg.world_size == 1 && !p->comm;
+  if (!use_graph) {
+    bool have_noise = p->graph_on && p->primed;
+    p->primed = false;
+    for (int k = 0; k < iterations; ++k) {
+      // profiled iteration: a steady-state one when there is one (its rollout launch then
+      // also carries the noise of the following iteration), else the last
+      bool prof = p->profile_stages && k == (iterations >= 3 ? iterations - 2 : iterations - 1);
+      TRY(launch_iteration(p, d, have_noise, k + 1 < iterations, prof));
     }
-    p->noise = p->noise_buf[p->noise_cur];
-    p->next_noise_wanted = (k + 1 < iterations);
-    p->next_noise_done = false;
-    if (prof) HIP_TRY(hipEventRecord(p->ev_stage[1], p->stream));
-    // the other noise buffer was last read by the previous update, which is behind us on this stream
-    if (p->next_noise_wanted && side_stream_pays) HIP_TRY(hipEventRecord(p->ev_buf_free, p->stream));
-    TRY(launch_rollout(p, d));
-    have_noise = p->next_noise_done;
-    if (p->next_noise_wanted && !have_noise && side_stream_pays) {
-      HIP_TRY(hipStreamWaitEvent(p->noise_stream, p->ev_buf_free, 0));
-      TRY(launch_noise(p, p->noise_buf[p->noise_cur ^ 1], p->noise_stream));
-      HIP_TRY(hipEventRecord(p->ev_noise_ready, p->noise_stream));
-      have_noise = noise_on_side_stream = true;
+  } else {
+    // Graph mode.  Every iteration also asks for the noise of its successor (`primed`; kernels that
+    // cannot produce it ahead generate in line instead), so that all iterations look alike; two of
+    // them bring the noise double buffer back to where it was and are what gets captured.
+    // Host-side effects of a launch (which kernel, window plan, instance upload, lazy allocations)
+    // happen in the direct iteration that precedes any capture.
+    bool have_noise = p->primed;
+    int k = 0;
+    if (p->inst_set && p->inst_dirty) {  // batched handle: new start states -> window origins, upload
+      size_t unused = 0;
+      DevParams plan = d;
+      (void)plan_lds_window(p, plan, &unused);
+      TRY(upload_instances(p));
     }
-    p->next_noise_wanted = false;
-    if (prof) HIP_TRY(hipEventRecord(p->ev_stage[2], p->stream));
-    TRY(launch_update(p, prof));
-    if (prof) HIP_TRY(hipEventRecord(p->ev_stage[5], p->stream));
+    if ((!have_noise || !p->graph_warm) && k < iterations) {
+      TRY(launch_iteration(p, d, have_noise, true, false));
+      p->graph_warm = true;
+      ++k;
+    }
+    const int chunk = p->graph_chunk;  // iterations per graph: even (noise double buffer)
+    while (iterations - k >= chunk) {
+      std::vector<unsigned char> sig;
+      graph_signature(p, d, lin, ang, sig);
+      sig.push_back(have_noise ? 1 : 0);
+      const int slot = p->noise_cur & 1;
+      if (!p->graph_exec[slot] || sig != p->graph_sig[slot]) {
+        if (p->graph_exec[slot]) { (void)hipGraphExecDestroy(p->graph_exec[slot]); p->graph_exec[slot] = nullptr; }
+        if (p->graph[slot]) { (void)hipGraphDestroy(p->graph[slot]); p->graph[slot] = nullptr; }
+        p->graph_sig[slot].clear();
+        const bool primed_before = have_noise;
+        HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+        int rc = MPPI_OK;
+        for (int j = 0; j < chunk && rc == MPPI_OK; ++j) rc = launch_iteration(p, d, have_noise, true, false);
+        hipError_t end = hipStreamEndCapture(p->stream, &p->graph[slot]);
+        if (rc != MPPI_OK) return rc;
+        HIP_TRY(end);
+        REQUIRE(have_noise == primed_before, MPPI_ERR_STATE, "graph capture: the iterations are not alike");
+        HIP_TRY(hipGraphInstantiate(&p->graph_exec[slot], p->graph[slot], nullptr, nullptr, 0));
+        p->graph_sig[slot] = sig;
+        ++p->graph_captures;
+        // (capturing ran the host side of two iterations; the launch below runs their device side)
+      } else {
+        // the host-side counters a direct launch of the two iterations would have advanced
+        if (p->cfg.rng == MPPI_RNG_PHILOX) p->noise_epoch += (uint64_t)chunk;
+        p->bumps_launched += (uint64_t)chunk;
+      }
+      HIP_TRY(hipGraphLaunch(p->graph_exec[slot], p->stream));
+      ++p->graph_replays;
+      k += chunk;
+    }
+    for (; k < iterations; ++k) TRY(launch_iteration(p, d, have_noise, true, false));
+    p->primed = have_noise;
   }
   HIP_TRY(hipEventRecord(p->ev_end, p->stream));
   p->elapsed_pending = true;
@@ -1727,6 +1869,35 @@ extern "C" int mppi_planner_graph_probe(mppi_planner* p, mppi_tdm* lin, mppi_tdm
   (void)hipGraphExecDestroy(exec);
   (void)hipGraphDestroy(graph);
   p->profile_stages = profile;
+  return MPPI_OK;
+}
+
+// hipGraph replay of the iteration loop (off by default).  See run_iterations.
+extern "C" int mppi_planner_set_graph_replay(mppi_planner* p, int iterations_per_graph) {
+  REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
+  const int enabled = iterations_per_graph != 0;
+  REQUIRE(!enabled || (iterations_per_graph >= 2 && iterations_per_graph % 2 == 0 && iterations_per_graph <= 256),
+          MPPI_ERR_INVALID, "iterations_per_graph must be 0 (off) or even in [2, 256], got %d",
+          iterations_per_graph);
+  REQUIRE(!enabled || (p->cfg.world_size == 1 && !p->comm), MPPI_ERR_INVALID,
+          "graph replay is a single-GPU feature (the exchange is not captured)");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  drop_graphs(p);
+  discard_noise_ahead(p);
+  if (enabled && !p->gen_dev) TRY(dev_alloc(&p->gen_dev, (size_t)1));
+  if (enabled) HIP_TRY(hipMemset(p->gen_dev, 0, sizeof(unsigned long long)));
+  p->bumps_launched = 0;
+  p->graph_warm = false;
+  p->graph_on = enabled != 0;
+  if (enabled) p->graph_chunk = iterations_per_graph;
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_graph_stats(mppi_planner* p, long* captures, long* replays) {
+  REQUIRE(p && captures && replays, MPPI_ERR_INVALID, "NULL argument");
+  *captures = p->graph_captures;
+  *replays = p->graph_replays;
   return MPPI_OK;
 }
 

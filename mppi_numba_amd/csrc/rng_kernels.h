@@ -117,6 +117,10 @@ struct NoiseJob {
   float2* out;        // tile-major target buffer (nullptr: nothing to do)
   uint64_t* states;   // xoroshiro states or nullptr (Philox)
   uint64_t seed, epoch;
+  // graph replay: kernel arguments are frozen in a captured graph, so the Philox call epoch is
+  // epoch + *gen_counter, where the counter lives on the device and every update kernel
+  // increments it (nullptr: epoch alone, passed by value per launch)
+  const uint64_t* gen_counter;
   int n_local, n_offset, n_steps;
   float std0, std1;
 };
@@ -130,7 +134,8 @@ __device__ __forceinline__ void noise_row(const NoiseJob& j, unsigned int row, i
     const int n = (int)tile * 64 + lane;
     if (n >= j.n_local) return;
     uint64_t sub = (uint64_t)(j.n_offset + n) * (uint64_t)pairs + (uint64_t)tp;
-    uint4 r = philox4x32_10(make_uint4((unsigned int)j.epoch, (unsigned int)(j.epoch >> 32), (unsigned int)sub,
+    const uint64_t epoch = j.epoch + (j.gen_counter ? *j.gen_counter : 0ull);  // uniform: a scalar load
+    uint4 r = philox4x32_10(make_uint4((unsigned int)epoch, (unsigned int)(epoch >> 32), (unsigned int)sub,
                                        (unsigned int)(sub >> 32)),
                             make_uint2((unsigned int)j.seed, (unsigned int)(j.seed >> 32)));
     float2 a = box_muller_fast(r.x, r.y), b = box_muller_fast(r.z, r.w);

@@ -82,8 +82,12 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
                                                              float lambda, double* __restrict__ rank_packet,
                                                              float2* __restrict__ u, float2* __restrict__ u_prev,
                                                              float2* __restrict__ u_mirror, float v_lo, float v_hi,
-                                                             float w_lo, float w_hi, double* __restrict__ stats) {
+                                                             float w_lo, float w_hi, double* __restrict__ stats,
+                                                             unsigned long long* __restrict__ gen_counter) {
   extern __shared__ float scale_sh[];  // [n_tiles]
+  // graph replay: one more generation of noise has been consumed (rng_kernels.h NoiseJob); no
+  // generator runs while an update does
+  if (gen_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *gen_counter += 1ull;
   constexpr int kCols = 1 + 2 * TC;    // den, then (x, y) per row
   __shared__ double red[kRowThreads / 64][kCols];
   __shared__ float redf[kRowThreads / 64];

@@ -359,6 +359,15 @@ class MPPI_Numba(object):
         _lib.call("mppi_planner_describe_last_rollout", self._handle, buf, 512)
         return buf.value.decode()
 
+    def set_graph_replay(self, enabled=True, iterations_per_graph=2):
+        """hipGraph replay of the iteration loop (include/mppi_hip.h); same results."""
+        _lib.call("mppi_planner_set_graph_replay", self._handle, int(iterations_per_graph) if enabled else 0)
+
+    def graph_stats(self):
+        captures, replays = C.c_long(0), C.c_long(0)
+        _lib.call("mppi_planner_graph_stats", self._handle, C.byref(captures), C.byref(replays))
+        return dict(captures=int(captures.value), replays=int(replays.value))
+
     def set_profiling(self, enabled):
         _lib.call("mppi_planner_set_profiling", self._handle, int(bool(enabled)))
 
