@@ -63,7 +63,9 @@ typedef enum mppi_rng_kind {
 typedef enum mppi_math_kind {
   MPPI_MATH_EXACT = 0, /* float64 trig/sqrt where the reference's CPU path has
                           float64: costs bit-identical to it (default)          */
-  MPPI_MATH_FAST = 1   /* float32 sincosf/sqrtf: ~1 ulp cost differences        */
+  MPPI_MATH_FAST = 1   /* float32 sincosf/sqrtf in the general kernel: ~1 ulp cost
+                          differences.  For numerical comparison; NOT faster -- the
+                          pipelined / fused kernels exist for the exact path only */
 } mppi_math_kind;
 
 const char* mppi_last_error(void);
