@@ -270,11 +270,14 @@ def gen_rng():
 
 
 def _det_like(mode_kw, n_rollouts=48, seed_world=3, alpha=0.4, num_opt=2,
-              goal=(2.8, 4.2), n_solves=2, extra_params=None):
+              goal=(2.8, 4.2), n_solves=2, extra_params=None, res=0.5, dt=0.1, horizon=2.0,
+              x0=(1.6, 2.1, 0.3), bounds=None):
     rng = np.random.default_rng(seed_world)
-    pmf, obstacle, unknown, tdm_dict = _world(rng)
+    pmf, obstacle, unknown, tdm_dict = _world(rng, res=res)
     tdm_dict["det_dynamics_cvar_alpha"] = alpha
-    cfg = _make_cfg(n_rollouts, T=2.0, dt=0.1, num_grid_samples=8,
+    if bounds is not None:
+        tdm_dict["bin_values_bounds"] = bounds
+    cfg = _make_cfg(n_rollouts, T=horizon, dt=dt, num_grid_samples=8,
                     max_speed_padding=3.0, tdm_sample_thread_dim=(4, 4),
                     num_vis_state_rollouts=5, max_map_dim=(30, 32), seed=1, **mode_kw)
     lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
@@ -282,7 +285,7 @@ def _det_like(mode_kw, n_rollouts=48, seed_world=3, alpha=0.4, num_opt=2,
     ang_pmf = _random_pmf(rng, pmf.shape[0], pmf.shape[1], pmf.shape[2])
     ang.set_TDM_from_PMF_grid(ang_pmf, tdm_dict, obstacle, unknown)
     planner = MPPI_Numba(cfg)
-    params = _params(x0=(1.6, 2.1, 0.3), xgoal=goal, dt=cfg.dt, num_opt=num_opt,
+    params = _params(x0=x0, xgoal=goal, dt=cfg.dt, num_opt=num_opt,
                      dist_weight=1.5, obs_penalty=1e5, unknown_penalty=1e2)
     if extra_params:
         params.update(extra_params)
@@ -323,20 +326,42 @@ def gen_speedmap_mean():
                      num_opt=1, n_solves=1, seed_world=8)
 
 
+# Units and ranges away from the notebooks' defaults: a resolution that is not a power of two
+# (cell borders are not exact in float32), dt = 0.05, reverse driving, a heading of several
+# turns, traction bounds above 1, small penalties and tolerances.
+ODD = dict(res=0.3, dt=0.05, horizon=0.65, x0=(1.31, 1.97, 37.3), goal=(1.9, 2.6), bounds=(0.0, 1.2),
+           extra_params=dict(vrange=np.array([-1.0, 2.5]), wrange=np.array([-2.0, 2.0]),
+                             u_std=np.array([1.5, 2.5]), goal_tolerance=0.2, v_post_rollout=0.3,
+                             dist_weight=0.3, obs_penalty=37.5, unknown_penalty=3.25, lambda_weight=4.0))
+
+
+def gen_det_odd_units():
+    return _det_like(dict(use_det_dynamics=True), n_rollouts=40, seed_world=31, alpha=0.7, num_opt=1,
+                     n_solves=2, **ODD)
+
+
+def gen_speedmap_odd_units():
+    return _det_like(dict(use_nom_dynamics_with_speed_map=True), n_rollouts=40, seed_world=32, alpha=0.25,
+                     num_opt=1, n_solves=1, **ODD)
+
+
 def _tdm_like(n_rollouts, m_samples, cvar_alpha, alpha_dyn, num_opt=1, n_solves=2,
               seed_world=11, force_oversized=False, thread_dim=(4, 4), lambda_weight=1.0,
-              goal=(2.6, 3.4), wall_ahead=False):
+              goal=(2.6, 3.4), wall_ahead=False, res=0.5, dt=0.1, horizon=1.5, x0=(1.4, 1.7, 0.5),
+              bounds=None, extra_params=None):
     saved = ref_config.max_threads_per_block
     if force_oversized:
         ref_config.max_threads_per_block = 4
     try:
         rng = np.random.default_rng(seed_world)
-        pmf, obstacle, unknown, tdm_dict = _world(rng, bins=5, rows=10, cols=12)
+        pmf, obstacle, unknown, tdm_dict = _world(rng, bins=5, rows=10, cols=12, res=res)
+        if bounds is not None:
+            tdm_dict["bin_values_bounds"] = bounds
         if wall_ahead:
             # obstacle / unknown cells right in front of x0 = (1.4, 1.7, 0.5)
             obstacle[4, 4:6] = 1
             unknown[3, 4:6] = 1
-        cfg = _make_cfg(n_rollouts, T=1.5, dt=0.1, num_grid_samples=m_samples,
+        cfg = _make_cfg(n_rollouts, T=horizon, dt=dt, num_grid_samples=m_samples,
                         max_speed_padding=3.0, tdm_sample_thread_dim=thread_dim,
                         num_vis_state_rollouts=4, max_map_dim=(24, 26), seed=1,
                         use_tdm=True)
@@ -345,9 +370,11 @@ def _tdm_like(n_rollouts, m_samples, cvar_alpha, alpha_dyn, num_opt=1, n_solves=
         ang_pmf = _random_pmf(rng, pmf.shape[0], pmf.shape[1], pmf.shape[2])
         ang.set_TDM_from_PMF_grid(ang_pmf, tdm_dict, obstacle, unknown)
         planner = MPPI_Numba(cfg)
-        params = _params(x0=(1.4, 1.7, 0.5), xgoal=goal, dt=cfg.dt,
+        params = _params(x0=x0, xgoal=goal, dt=cfg.dt,
                          num_opt=num_opt, cvar_alpha=cvar_alpha, alpha_dyn=alpha_dyn,
                          dist_weight=1.0, lambda_weight=lambda_weight)
+        if extra_params:
+            params.update(extra_params)
         planner.setup(params, lin, ang)
         rec = _UpdateRecorder(planner, MPPI_Numba.update_useq_numba)
         planner.update_useq_numba = rec
@@ -364,6 +391,11 @@ def _tdm_like(n_rollouts, m_samples, cvar_alpha, alpha_dyn, num_opt=1, n_solves=
         return out
     finally:
         ref_config.max_threads_per_block = saved
+
+
+def gen_tdm_odd_units():
+    odd = dict(ODD, x0=(1.11, 1.37, -21.9), goal=(1.6, 1.9))
+    return _tdm_like(20, 6, cvar_alpha=0.34, alpha_dyn=0.8, num_opt=1, n_solves=2, seed_world=33, **odd)
 
 
 def gen_tdm_cvar():
@@ -481,7 +513,10 @@ FIXTURES = {
     "det_mean": gen_det_mean,
     "speedmap_cvar": gen_speedmap,
     "speedmap_mean": gen_speedmap_mean,
+    "det_odd_units": gen_det_odd_units,
+    "speedmap_odd_units": gen_speedmap_odd_units,
     "tdm_cvar": gen_tdm_cvar,
+    "tdm_odd_units": gen_tdm_odd_units,
     "tdm_mean_alpha_dyn": gen_tdm_mean_alpha_dyn,
     "tdm_cvar_odd": gen_tdm_cvar_odd,
     "tdm_oversized_mean": gen_tdm_oversized_mean,

@@ -104,7 +104,7 @@ def test_config_mirrors_reference_clamps(capsys):
 
 
 MODES = {"det_cvar": "det", "det_mean": "det", "speedmap_cvar": "speed", "speedmap_mean": "speed",
-         "tdm_cvar": "tdm"}
+         "tdm_cvar": "tdm", "det_odd_units": "det", "speedmap_odd_units": "speed", "tdm_odd_units": "tdm"}
 
 
 @pytest.mark.parametrize("name", sorted(MODES))
