@@ -38,8 +38,6 @@ struct PrepJob {
                // [2] mask values outside {0, 1}
 };
 
-constexpr int kMaxPrepBins = 64;  // per-thread column buffer (PREP_TDM copies through it)
-
 __global__ __launch_bounds__(256) void k_prepare_maps(PrepJob J) {
   const int rp = J.valid_rows + 2 * J.pad, cp = J.valid_cols + 2 * J.pad;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
