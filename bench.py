@@ -268,8 +268,12 @@ def main():
                 gathered = [torch.zeros_like(mine) for _ in range(world)]
                 dist.all_gather(gathered, mine)
                 planner.update_apply(np.stack([g.numpy() for g in gathered]))
+        def solve_staged():  # solve() = sample the traction grids once, then iterate
+            lin.sample_grids(params.get("alpha_dyn", 1.0) if w["m"] > 1 else 1.0)
+            ang.sample_grids(params.get("alpha_dyn", 1.0) if w["m"] > 1 else 1.0)
+            iterate(1)
         planner.iterate_async = iterate
-        planner.solve = lambda: iterate(1)
+        planner.solve = solve_staged
 
     def barrier():
         if dist is not None:

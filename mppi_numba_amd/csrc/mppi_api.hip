@@ -938,6 +938,9 @@ static DevParams make_dev_params(const mppi_planner* p, const mppi_tdm* lin, con
 // (re)build the packed cell words when the sampled grids or the masks changed
 static int ensure_packed(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang) {
   if (p->cfg.mode == MPPI_MODE_BAREBONE) return MPPI_OK;
+  // solve() samples the traction grids itself; the stage-level entry points use what is there
+  REQUIRE(lin->grid_version > 0 && ang->grid_version > 0, MPPI_ERR_STATE,
+          "traction grids have never been sampled: call mppi_tdm_sample_grids (or mppi_planner_solve) first");
   if (p->packed_lin == lin && p->packed_ang == ang && p->packed_lin_grid == lin->grid_version &&
       p->packed_ang_grid == ang->grid_version && p->packed_lin_maps == lin->maps_version)
     return MPPI_OK;

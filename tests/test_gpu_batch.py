@@ -114,6 +114,8 @@ def test_one_problem_through_the_instance_path_equals_the_classic_path():
     batch = MPPI_Batch(cfg, 1)
     batch.setup(params, lin, ang, x0, goal)
     classic, _ = single_problem(cfg, lin, ang, params, x0[0], goal[0])
+    lin.sample_grids()
+    ang.sample_grids()
     batch.sample_noise()
     noise = batch.noise_samples_d.copy_to_host()
     classic.set_noise(noise)
@@ -213,6 +215,8 @@ def test_batch_sharded_over_two_handles_matches_one():
     x0s, goals = problems(lin, count, rng)
     whole = MPPI_Batch(cfg, count)
     whole.setup(params, lin, ang, x0s, goals)
+    lin.sample_grids()
+    ang.sample_grids()
     whole.sample_noise()
     noise = whole.noise_samples_d.copy_to_host().reshape(count, 1024, 40, 2)
     whole.rollout()

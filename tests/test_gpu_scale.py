@@ -358,3 +358,45 @@ def test_large_heading_increments_use_the_full_sincos_kernel(n, expect):
     want = oracle_costs(dict(m=1), params, lin, ang, noise, u_in)
     ulps = ulp_diff_f32(got, want)
     assert (ulps == 0).mean() >= 0.999, "exact fraction %.5f, max ulp %d" % ((ulps == 0).mean(), ulps.max())
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_iterations_track_the_single_gpu_loop(world):
+    """`world` shards of one problem on one GPU, packets exchanged by hand exactly as the
+    all-gather would: several full iterations (each shard generates its own slice of the
+    Philox noise, rolls it out, reduces it) stay on the unsharded trajectory of u."""
+    n = 8192
+    _, _, _, _, full, _ = build("c2", n)
+    shards = [build("c2", n // world, rank=r, world=world)[4] for r in range(world)]
+    full.solve()
+    u0 = full.u_cur_d.copy_to_host()
+    packets = None
+    for step in range(4):
+        if step == 0:
+            for s in shards:
+                s.set_u(np.zeros_like(u0))
+                s.lin_tdm.sample_grids()  # (solve() does this; the stage-level calls do not)
+                s.ang_tdm.sample_grids()
+        # one iteration on the unsharded handle ...
+        if step > 0:
+            full.iterate_async(1)
+            full.synchronize()
+        # ... and on the shards
+        packets = []
+        for s in shards:
+            s.sample_noise()
+            s.rollout()
+            packets.append(s.update_local())
+        packets = np.stack(packets)
+        assert packets.shape == (world, 2 * 100 + 2)
+        for s in shards:
+            s.update_apply(packets)
+        want = full.u_cur_d.copy_to_host()
+        for s in shards:
+            got = s.u_cur_d.copy_to_host()
+            assert np.abs(got - want).max() <= 5e-6, (step, np.abs(got - want).max())
+        assert all(np.array_equal(shards[0].u_cur_d.copy_to_host(), s.u_cur_d.copy_to_host()) for s in shards[1:])
+    # the union of the shards' costs is the unsharded cost vector of the last iteration
+    costs = np.concatenate([s.costs_d.copy_to_host() for s in shards])
+    rel = np.abs(costs - full.costs_d.copy_to_host()) / np.abs(full.costs_d.copy_to_host())
+    assert np.quantile(rel, 0.99) < 1e-4  # u differs by float64 rounding of the partial sums -> costs by ulps
