@@ -1130,7 +1130,6 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
       }
       if (have_window && rot_ok && !no_pipe) {
         // pipelined kernel: the map window in LDS + the incremental trig
-        const mppi_params& a = p->params;
         const size_t map_bytes = lds_win - sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);
         int pairs = ceil_div(ceil_div(N, 64), p->num_cus);  // wave triples per workgroup
         if (pairs < 1) pairs = 1;

@@ -265,7 +265,7 @@ __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = n < P.n_local;
   const int nn = live ? n : P.n_local - 1;
-  const int N = P.n_local, T = P.n_steps;
+  const int T = P.n_steps;
   const float2* col = noise + tile_index(0, nn, T);  // this lane's column; rows are 64 apart
 
   RolloutState st = {P.x0, P.y0, P.th0, 0.0f, 1e9, false, false};
@@ -688,7 +688,7 @@ __global__ void k_rollout_tdm(DevParams P, const uint32_t* __restrict__ cellsM,
   u = select_instance(P, u, P.inst ? (int)blockIdx.x / P.n_inst : 0);
   stage_control_ratios(P, u, uos);
   const int n = blockIdx.x;
-  const int N = P.n_local, T = P.n_steps, M = P.n_grids;
+  const int T = P.n_steps, M = P.n_grids;
 
   for (int m = threadIdx.x; m < m_pow2; m += blockDim.x) {
     if (m >= M) {
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(64) void k_rollout_barebone(DevParams P, const floa
   const int n = blockIdx.x * 64 + threadIdx.x;
   const bool live = n < P.n_local;
   const int nn = live ? n : P.n_local - 1;
-  const int N = P.n_local, T = P.n_steps;
+  const int T = P.n_steps;
   float x = P.x0, y = P.y0, th = P.th0;
   float cost = 0.0f;
   double d2 = 1e9;
@@ -954,7 +954,7 @@ __global__ void k_state_rollout(DevParams P, const uint32_t* __restrict__ cells,
                                 const float2* __restrict__ u_cur, int n_vis, float* __restrict__ out) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_vis) return;
-  const int T = P.n_steps, N = P.n_local;
+  const int T = P.n_steps;
   const int M = ACROSS_ENVS ? P.n_grids : 1;
   const int m = ACROSS_ENVS ? b : 0;
   float* o = out + (size_t)b * (T + 1) * 3;
