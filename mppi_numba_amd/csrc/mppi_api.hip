@@ -148,6 +148,10 @@ struct mppi_tdm {
   uint64_t grid_version = 0;  // bumped whenever `grid` changes
   uint64_t sampled_maps_version = ~0ULL;
   double sampled_alpha = -1.0;
+  // solve() of a CVaR planner samples straight into the planner's cell words (Philox only):
+  // the int8 grids are then produced on demand from the same counters
+  bool grid_stale = false;      // `grid` does not hold the draws of (sampled_epoch, sampled_alpha) yet
+  uint64_t sampled_epoch = 0;   // Philox epoch of the current draws
   bool injected = false;  // grids came from mppi_tdm_set_sampled_grids
   int8_t injected_max = 0, injected_min = 0;
 };
@@ -394,16 +398,53 @@ extern "C" int mppi_tdm_get_maps(mppi_tdm* t, int8_t* pmf, int8_t* obstacle, int
   return MPPI_OK;
 }
 
+// the Philox draws of (epoch, alpha_dyn) into the (G, R, C) int8 grids
+static int tdm_launch_philox(mppi_tdm* t, double alpha_dyn, uint64_t epoch, hipStream_t stream) {
+  const int G = t->cfg.num_grids;
+  {
+    const long cell_groups = (long)t->rows * ((t->cols + 3) / 4);
+    if (t->bins <= 64) {
+      // enough workgroups to fill the chip, as many samples per thread as that allows
+      int chunks = ceil_div(256L * 1024, cell_groups);
+      chunks = chunks < 1 ? 1 : (chunks > G ? G : chunks);
+      const int g_chunk = ceil_div(G, chunks);
+      dim3 grid((unsigned)ceil_div(cell_groups, 256), (unsigned)ceil_div(G, g_chunk));
+#define MPPI_SAMPLE(MAXB)                                                                                       \
+  hipLaunchKernelGGL(k_sample_grids_philox_cols<MAXB>, grid, dim3(256), 0, stream, t->pmf, t->bins, t->rows, t->cols, \
+                     t->table, alpha_dyn, t->cfg.seed, epoch, G, g_chunk, t->grid, t->cfg.max_rows, t->cfg.max_cols)
+      if (t->bins <= 8) MPPI_SAMPLE(8);
+      else if (t->bins <= 16) MPPI_SAMPLE(16);
+      else if (t->bins <= 32) MPPI_SAMPLE(32);
+      else MPPI_SAMPLE(64);
+#undef MPPI_SAMPLE
+    } else {
+      long total = (long)G * cell_groups;
+      hipLaunchKernelGGL(k_sample_grids_philox, dim3(ceil_div(total, 256)), dim3(256), 0, stream, t->pmf, t->bins,
+                         t->rows, t->cols, t->table, alpha_dyn, t->cfg.seed, epoch, G, t->grid,
+                         t->cfg.max_rows, t->cfg.max_cols);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return MPPI_OK;
+}
+
+// the int8 grids, if the current draws only exist as a planner's cell words so far
+static int tdm_materialize(mppi_tdm* t, hipStream_t stream) {
+  if (!t->grid_stale) return MPPI_OK;
+  TRY(tdm_launch_philox(t, t->sampled_alpha, t->sampled_epoch, stream));
+  t->grid_stale = false;
+  return MPPI_OK;
+}
+
 // enqueue the sampling kernel on `stream` (no synchronisation)
 static int tdm_sample_on(mppi_tdm* t, double alpha_dyn, hipStream_t stream) {
   REQUIRE(t->maps_set, MPPI_ERR_STATE, "TDM maps not set");
   if (t->one_hot && t->sampled_maps_version == t->maps_version && alpha_dyn > 0.0) return MPPI_OK;
   const int G = t->cfg.num_grids;
   if (t->cfg.rng == MPPI_RNG_PHILOX) {
-    long total = (long)G * t->rows * ((t->cols + 3) / 4);
-    hipLaunchKernelGGL(k_sample_grids_philox, dim3(ceil_div(total, 256)), dim3(256), 0, stream, t->pmf, t->bins,
-                       t->rows, t->cols, t->table, alpha_dyn, t->cfg.seed, t->epoch, G, t->grid,
-                       t->cfg.max_rows, t->cfg.max_cols);
+    TRY(tdm_launch_philox(t, alpha_dyn, t->epoch, stream));
+    t->sampled_epoch = t->epoch;
+    t->grid_stale = false;
     ++t->epoch;
   } else {
     int threads = G * t->cfg.thread_dim_x * t->cfg.thread_dim_y;
@@ -445,6 +486,7 @@ extern "C" int mppi_tdm_set_sampled_grids(mppi_tdm* t, const int8_t* grids, int 
   }
   ++t->grid_version;
   t->sampled_maps_version = ~0ULL;  // injected grids are not a cached sample
+  t->grid_stale = false;             // (a lazy sample, if any, is superseded)
   t->injected = true;                // arbitrary bytes: the 16-bit cell format is not guaranteed
   return MPPI_OK;
 }
@@ -453,6 +495,7 @@ extern "C" int mppi_tdm_get_sampled_grids(mppi_tdm* t, int8_t* out) {
   REQUIRE(t && out, MPPI_ERR_INVALID, "NULL argument");
   HIP_TRY(hipSetDevice(t->cfg.device));
   size_t bytes = (size_t)t->cfg.num_grids * t->cfg.max_rows * t->cfg.max_cols;
+  TRY(tdm_materialize(t, t->stream));
   HIP_TRY(hipMemcpyAsync(out, t->grid, bytes, hipMemcpyDeviceToHost, t->stream));
   HIP_TRY(hipStreamSynchronize(t->stream));
   return MPPI_OK;
@@ -935,6 +978,67 @@ static DevParams make_dev_params(const mppi_planner* p, const mppi_tdm* lin, con
   return d;
 }
 
+static int reserve_cells(mppi_planner* p, const mppi_tdm* lin, int M) {
+  size_t need = (size_t)lin->rows * lin->cols * M;
+  if (need > p->cells_capacity) {
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    dev_free(p->cells);
+    p->cells_capacity = 0;  // (stays 0 if the allocation below fails)
+    TRY(dev_alloc(&p->cells, need));
+    p->cells_capacity = need;
+  }
+  return MPPI_OK;
+}
+
+// solve() of a CVaR planner, Philox generators: both TDMs sampled straight into the cell words
+// the rollout gathers (k_sample_cellsM_philox), no (G, R, C) int8 grids and no transpose; the
+// int8 grids follow on demand from the same counters (tdm_materialize).  Returns false when
+// the ordinary sample + pack path has to run.
+static bool sample_into_cells(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, double alpha_dyn, int* rc) {
+  *rc = MPPI_OK;
+  static const bool disabled = getenv("MPPI_NO_FUSED_SAMPLING") != nullptr;  // developer switch (ablation)
+  if (disabled || p->cfg.mode != MPPI_MODE_TDM || lin == ang) return false;
+  if (lin->cfg.rng != MPPI_RNG_PHILOX || ang->cfg.rng != MPPI_RNG_PHILOX) return false;
+  if (lin->bins > 64 || ang->bins > 64 || !(alpha_dyn > 0.0)) return false;
+  const int M = p->cfg.num_grid_samples;
+  // a wave of this kernel sets up the thresholds of its 4 cells for M/64 rounds of draws: measured
+  // against sample + sample + transpose, 65 vs 61 us at M = 128 and 192 vs 363 us at M = 1024
+  if (M < 192) return false;
+  if ((*rc = reserve_cells(p, lin, M)) != MPPI_OK) return true;
+  const long cell_groups = (long)lin->rows * ((lin->cols + 3) / 4);
+  const int bins = std::max(lin->bins, ang->bins);
+  dim3 grid((unsigned)ceil_div(cell_groups, 4));
+#define MPPI_SAMPLE_CELLS(MAXB)                                                                                    \
+  hipLaunchKernelGGL(k_sample_cellsM_philox<MAXB>, grid, dim3(256), 0, p->stream, lin->pmf, lin->bins, lin->table, \
+                     lin->cfg.seed, lin->epoch, ang->pmf, ang->bins, ang->table, ang->cfg.seed, ang->epoch,        \
+                     lin->obs, lin->unk, lin->rows, lin->cols, alpha_dyn, M, p->cells)
+  if (bins <= 8) MPPI_SAMPLE_CELLS(8);
+  else if (bins <= 16) MPPI_SAMPLE_CELLS(16);
+  else if (bins <= 32) MPPI_SAMPLE_CELLS(32);
+  else MPPI_SAMPLE_CELLS(64);
+#undef MPPI_SAMPLE_CELLS
+  if (hipGetLastError() != hipSuccess) {
+    *rc = fail(MPPI_ERR_HIP, "k_sample_cellsM_philox launch failed");
+    return true;
+  }
+  for (mppi_tdm* t : {lin, ang}) {
+    t->sampled_epoch = t->epoch++;
+    t->sampled_alpha = alpha_dyn;
+    t->sampled_maps_version = t->maps_version;
+    t->grid_stale = true;  // the int8 grids of these draws do not exist yet
+    t->injected = false;
+    ++t->grid_version;
+  }
+  p->cells16_valid = false;
+  p->risk_ref = lin->risk;
+  p->packed_lin = lin;
+  p->packed_ang = ang;
+  p->packed_lin_grid = lin->grid_version;
+  p->packed_ang_grid = ang->grid_version;
+  p->packed_lin_maps = lin->maps_version;
+  return true;
+}
+
 // (re)build the packed cell words when the sampled grids or the masks changed
 static int ensure_packed(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang) {
   if (p->cfg.mode == MPPI_MODE_BAREBONE) return MPPI_OK;
@@ -945,14 +1049,10 @@ static int ensure_packed(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang) {
       p->packed_ang_grid == ang->grid_version && p->packed_lin_maps == lin->maps_version)
     return MPPI_OK;
   const int M = p->cfg.num_grid_samples;
-  size_t need = (size_t)lin->rows * lin->cols * M;
-  if (need > p->cells_capacity) {
-    HIP_TRY(hipStreamSynchronize(p->stream));
-    dev_free(p->cells);
-    p->cells_capacity = 0;  // (stays 0 if the allocation below fails)
-    TRY(dev_alloc(&p->cells, need));
-    p->cells_capacity = need;
-  }
+  TRY(reserve_cells(p, lin, M));
+  // (another planner may have sampled these TDMs straight into ITS cell words)
+  TRY(tdm_materialize(lin, p->stream));
+  TRY(tdm_materialize(ang, p->stream));
   p->cells16_valid = false;
   if (M == 1) {
     hipLaunchKernelGGL(k_pack_cells_single, dim3(ceil_div((long)lin->rows * lin->cols, 256)), dim3(256), 0,
@@ -1615,8 +1715,13 @@ extern "C" int mppi_planner_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang,
     // grids are sampled once per solve(), not per optimisation iteration
     // (mppi.py:247-248, 321-322, 391-394); the deterministic modes pass alpha_dyn = 1
     double alpha = (p->cfg.mode == MPPI_MODE_TDM) ? p->params.alpha_dyn : 1.0;
-    TRY(tdm_sample_on(lin, alpha, p->stream));
-    TRY(tdm_sample_on(ang, alpha, p->stream));
+    int rc = MPPI_OK;
+    if (sample_into_cells(p, lin, ang, alpha, &rc)) {
+      TRY(rc);
+    } else {
+      TRY(tdm_sample_on(lin, alpha, p->stream));
+      TRY(tdm_sample_on(ang, alpha, p->stream));
+    }
   }
   TRY(run_iterations(p, lin, ang, p->params.num_opt));
   const size_t u_bytes = sizeof(float2) * (size_t)p->B * (size_t)p->cfg.num_steps;

@@ -229,6 +229,155 @@ __global__ __launch_bounds__(256) void k_sample_grids_philox(const int8_t* __res
   }
 }
 
+// Philox, column-resident variant (the default): a thread owns 4 consecutive cells of one row
+// and draws them for `g_chunk` samples in a row.  The cumulative PMF of its cells is read ONCE
+// (the kernel above re-reads it for each of the G samples) and kept packed, 4 cells per
+// register; "first bin whose cumulative mass reaches the target" is then evaluated for the 4
+// cells at once with byte-parallel arithmetic:
+//     bit 7 of ((cum | 0x80) - target)  <=>  cum >= target        (cum, target in [0, 127])
+// scanning the bins from the last to the first.  Same distribution and the same int8
+// semantics as draw_bin: the cumulative sum wraps like the reference's int8, a wrapped
+// (negative) value never matches, and an unmatched cell gets the last bin's value.
+// 100 us -> 14 us for 128 samples of a 16-bin 260x260 map.
+// cumulative PMF of 4 consecutive cells of row r (columns cg*4 ..), packed one byte per cell,
+// and the int8 value each bin maps to, replicated into the 4 bytes
+template <int MAXB>
+__device__ __forceinline__ void load_packed_thresholds(const int8_t* __restrict__ pmf, int bins, int rows, int cols,
+                                                       const int8_t* __restrict__ table, int r, int cg,
+                                                       uint32_t (&cum)[MAXB], uint32_t (&val)[MAXB]) {
+  const size_t plane = (size_t)rows * cols;
+  // all loads first (independent addresses: they pipeline), then the running sums
+  uint32_t mass[MAXB];
+  if ((cols & 3) == 0) {  // rows are word-aligned: the 4 cells of a bin are one 32-bit load
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(pmf + (size_t)r * cols + (size_t)cg * 4);
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) mass[b] = (b < bins) ? src[(size_t)b * (plane / 4)] : 0u;
+  } else {
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+      mass[b] = 0;
+      if (b < bins) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          mass[b] |= (uint32_t)(uint8_t)pmf[(size_t)b * plane + (size_t)r * cols + min(cg * 4 + k, cols - 1)] << (8 * k);
+      }
+    }
+  }
+  uint32_t run = 0;
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    // byte-wise run += mass, wrapping like the reference's int8 accumulator
+    run = ((run & 0x7f7f7f7fu) + (mass[b] & 0x7f7f7f7fu)) ^ ((run ^ mass[b]) & 0x80808080u);
+    // a wrapped (negative) sum never satisfies target <= cum: store 0 for it
+    const uint32_t negative = ((run & 0x80808080u) >> 7) * 255u;
+    cum[b] = (b < bins ? (run & ~negative) : 0u) | 0x80808080u;  // (bins past the end: 0, never reached)
+    val[b] = (b < bins) ? (uint32_t)(uint8_t)table[b] * 0x01010101u : 0u;
+  }
+}
+
+// the 4 cells of cell group `cgid` in sample g: one Philox block -> 4 targets -> 4 int8 values
+template <int MAXB>
+__device__ __forceinline__ uint32_t draw_packed(const uint32_t (&cum)[MAXB], const uint32_t (&val)[MAXB], int bins,
+                                                uint32_t last, uint64_t seed, uint64_t epoch, uint64_t index,
+                                                double scale) {
+  const uint4 x = philox4x32_10(make_uint4((unsigned int)epoch, (unsigned int)(epoch >> 32), (unsigned int)index,
+                                           (unsigned int)(index >> 32)),
+                                make_uint2((unsigned int)seed, (unsigned int)(seed >> 32)));
+  const unsigned int xs[4] = {x.x, x.y, x.z, x.w};
+  uint32_t target = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float u = fmaf((float)xs[k], 2.3283064365386963e-10f, 1.1641532182693481e-10f);  // (0, 1]
+    const int t = (int)(int8_t)(int)ceil((double)u * scale);  // terrain.py:676: int8(ceil(rnd*100*alpha))
+    target |= (uint32_t)min(max(t, 0), 127) << (8 * k);
+  }
+  uint32_t picked = last;
+#pragma unroll
+  for (int b = MAXB - 1; b >= 0; --b) {
+    if (b < bins) {
+      const uint32_t reached = (((cum[b] - target) & 0x80808080u) >> 7) * 255u;  // 0xFF per cell that matched
+      picked = (val[b] & reached) | (picked & ~reached);
+    }
+  }
+  return picked;
+}
+
+template <int MAXB>
+__global__ __launch_bounds__(256) void k_sample_grids_philox_cols(const int8_t* __restrict__ pmf, int bins, int rows,
+                                                                  int cols, const int8_t* __restrict__ table,
+                                                                  double alpha_dyn, uint64_t seed, uint64_t epoch,
+                                                                  int n_grids, int g_chunk, int8_t* __restrict__ out,
+                                                                  int out_rows, int out_stride) {
+  const int groups = (cols + 3) / 4;
+  const int cgid = blockIdx.x * 256 + threadIdx.x;
+  if (cgid >= rows * groups) return;
+  const int r = cgid / groups, cg = cgid - r * groups;
+  uint32_t cum[MAXB], val[MAXB];
+  load_packed_thresholds<MAXB>(pmf, bins, rows, cols, table, r, cg, cum, val);
+  const uint32_t last = (uint32_t)(uint8_t)table[bins - 1] * 0x01010101u;
+  const int g0 = blockIdx.y * g_chunk, g1 = min(g0 + g_chunk, n_grids);
+  const double scale = 100.0 * alpha_dyn;
+  // hipMalloc'ed base, stride a multiple of 4, group inside the row: one aligned 32-bit store
+  const bool word_store = (out_stride & 3) == 0 && cg * 4 + 3 < cols;
+  for (int g = g0; g < g1; ++g) {
+    const uint64_t index = (uint64_t)g * (uint64_t)(rows * groups) + (uint64_t)cgid;
+    const uint32_t picked = draw_packed<MAXB>(cum, val, bins, last, seed, epoch, index, scale);
+    int8_t* o = out + ((size_t)g * out_rows + r) * out_stride + cg * 4;
+    if (word_store) {  // uniform except for the last group of a row
+      *reinterpret_cast<uint32_t*>(o) = picked;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (cg * 4 + k < cols) o[k] = (int8_t)(picked >> (8 * k));
+    }
+  }
+}
+
+// The planner's view of the same draws, without the detour through the (G, R, C) int8 grids:
+// linear and angular traction of one solve() sampled straight into the cell words the CVaR
+// rollout gathers, cellsM[(r*cols + c)*M + m] = lin | ang << 8 | obstacle << 16 | unknown << 24.
+// A wave owns one group of 4 cells (its PMF columns are loaded once), lane = sample m (strided
+// if M > 64): every store is 64 consecutive words.  Philox counters are those of
+// k_sample_grids_philox_cols, so the int8 grids can be produced later from the same
+// (seed, epoch) when somebody asks for them (mppi_tdm_get_sampled_grids).
+// M = 128, 260x260, 16 bins: 2 x 27 us (sample) + 25 us (transpose) -> one launch.
+template <int MAXB>
+__global__ __launch_bounds__(256) void k_sample_cellsM_philox(
+    const int8_t* __restrict__ lin_pmf, int lin_bins, const int8_t* __restrict__ lin_table, uint64_t lin_seed,
+    uint64_t lin_epoch, const int8_t* __restrict__ ang_pmf, int ang_bins, const int8_t* __restrict__ ang_table,
+    uint64_t ang_seed, uint64_t ang_epoch, const int8_t* __restrict__ obs, const int8_t* __restrict__ unk,
+    int rows, int cols, double alpha_dyn, int n_grids, uint32_t* __restrict__ cells) {
+  const int groups = (cols + 3) / 4;
+  const int cgid = blockIdx.x * 4 + (threadIdx.x >> 6);  // one cell group per wave
+  if (cgid >= rows * groups) return;
+  const int lane = threadIdx.x & 63;
+  const int r = cgid / groups, cg = cgid - r * groups;
+  uint32_t lcum[MAXB], lval[MAXB], acum[MAXB], aval[MAXB];
+  load_packed_thresholds<MAXB>(lin_pmf, lin_bins, rows, cols, lin_table, r, cg, lcum, lval);
+  load_packed_thresholds<MAXB>(ang_pmf, ang_bins, rows, cols, ang_table, r, cg, acum, aval);
+  const uint32_t llast = (uint32_t)(uint8_t)lin_table[lin_bins - 1] * 0x01010101u;
+  const uint32_t alast = (uint32_t)(uint8_t)ang_table[ang_bins - 1] * 0x01010101u;
+  uint32_t flags[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const size_t ci = (size_t)r * cols + min(cg * 4 + k, cols - 1);
+    flags[k] = ((uint32_t)(uint8_t)obs[ci] << 16) | ((uint32_t)(uint8_t)unk[ci] << 24);
+  }
+  const double scale = 100.0 * alpha_dyn;
+  for (int m = lane; m < n_grids; m += 64) {
+    const uint64_t index = (uint64_t)m * (uint64_t)(rows * groups) + (uint64_t)cgid;
+    const uint32_t lp = draw_packed<MAXB>(lcum, lval, lin_bins, llast, lin_seed, lin_epoch, index, scale);
+    const uint32_t ap = draw_packed<MAXB>(acum, aval, ang_bins, alast, ang_seed, ang_epoch, index, scale);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = cg * 4 + k;
+      if (c < cols)
+        cells[((size_t)r * cols + c) * n_grids + m] =
+            ((lp >> (8 * k)) & 0xffu) | (((ap >> (8 * k)) & 0xffu) << 8) | flags[k];
+    }
+  }
+}
+
 // reference-compatible: launch geometry [(1,G),(tx,ty)] flattened; thread (i,j)
 // of block g owns stream i*ty*G + g*ty + j and walks its tile row-major
 // (terrain.py:645-668)

@@ -291,3 +291,43 @@ def test_closed_loop_reaches_goal_like_test_ipynb():
     assert reached_at is not None, "robot at %s after 250 steps" % x
     sr = planner.get_state_rollout()
     assert sr.shape == (cfg.num_vis_state_rollouts, cfg.num_steps + 1, 3) and np.isfinite(sr).all()
+
+
+def test_sampling_straight_into_cell_words_equals_sample_then_pack():
+    """solve() of a CVaR planner with many samples draws both TDMs directly into the planner's
+    cell words; the int8 grids follow on demand from the same Philox counters.  Same costs as the
+    ordinary path (grids sampled, then transposed), same grids."""
+    import bench
+    from mppi_numba_amd.config import Config
+    from mppi_numba_amd.mppi import MPPI_Numba
+    from mppi_numba_amd.terrain import TDM_Numba
+    m, n, t_steps = 256, 96, 20
+    pmf, obstacle, unknown, td = bench.synthetic_world("c3", np.random.default_rng(3))
+    pmf, obstacle, unknown = pmf[:, :70, :90].copy(), obstacle[:70, :90].copy(), unknown[:70, :90].copy()
+    td = dict(td, xlimits=(0.0, 90 * 0.25), ylimits=(0.0, 70 * 0.25))
+    handles = []
+    for _ in range(2):
+        cfg = Config(T=t_steps * 0.1, dt=0.1, num_grid_samples=m, num_control_rollouts=n, max_speed_padding=4.0,
+                     num_vis_state_rollouts=1, max_map_dim=(80, 100), seed=9, enforce_recommended_limits=False,
+                     use_tdm=True)
+        lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
+        lin.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)
+        ang.set_TDM_from_PMF_grid(pmf[::-1].copy(), td, obstacle, unknown)
+        planner = MPPI_Numba(cfg)
+        params = bench.make_params("c3")
+        params.update(x0=np.array([5.0, 6.0, 0.4]), xgoal=np.array([9.0, 9.0]), alpha_dyn=0.8)
+        planner.setup(params, lin, ang)
+        handles.append((lin, ang, planner, params))
+    (lin_a, ang_a, fused, _), (lin_b, ang_b, staged, params) = handles
+    for _ in range(2):  # two solves: the epochs advance alike
+        u_fused = fused.solve()
+        # the ordinary path by hand: sample both TDMs, then one staged iteration
+        lin_b.sample_grids(params["alpha_dyn"])
+        ang_b.sample_grids(params["alpha_dyn"])
+        staged.sample_noise()
+        staged.rollout()
+        staged.update()
+        assert np.array_equal(fused.costs_d.copy_to_host(), staged.costs_d.copy_to_host())
+        assert np.array_equal(u_fused, staged.u_cur_d.copy_to_host())
+        assert np.array_equal(lin_a.sample_grid_batch_d.copy_to_host(), lin_b.sample_grid_batch_d.copy_to_host())
+        assert np.array_equal(ang_a.sample_grid_batch_d.copy_to_host(), ang_b.sample_grid_batch_d.copy_to_host())
