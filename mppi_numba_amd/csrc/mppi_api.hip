@@ -1465,24 +1465,33 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
   const int N = p->n_local, T = p->cfg.num_steps;
   const mppi_params& a = p->params;
   double* my_packet = p->packets + (size_t)p->cfg.rank * p->B * packet_len(T);
-  if (!p->tile_packets_fresh)
+  // rollout kernels without the weight epilogue: the row kernel forms the tile weights itself
+  // from the costs (same bits) unless there are too many tiles for its LDS arrays
+  const bool from_costs = !p->tile_packets_fresh && 2 * sizeof(float) * (size_t)p->inst_tiles <= 60 * 1024;
+  if (!p->tile_packets_fresh && !from_costs)
     hipLaunchKernelGGL(k_tile_weights, dim3(p->n_tiles), dim3(64), 0, p->stream, p->costs, N, a.lambda_weight,
                        p->w_rel, p->tile_beta);
   p->tile_packets_fresh = false;
-  const size_t lds = sizeof(float) * (size_t)p->inst_tiles;
+  const size_t lds = sizeof(float) * (size_t)p->inst_tiles * (from_costs ? 2 : 1);
   REQUIRE(lds <= 60 * 1024, MPPI_ERR_INVALID, "too many rollouts per GPU for the update kernel (%d)", N);
   // rows per workgroup: see k_update_rows
   const bool many_rows = (long)T * p->B >= 2048;
   const dim3 grid(many_rows ? ceil_div(T, 4) : T, p->B);
-#define MPPI_LAUNCH_ROWS(APPLY, TC)                                                                             \
-  hipLaunchKernelGGL((k_update_rows<APPLY, TC>), grid, dim3(kRowThreads), lds, p->stream, p->w_rel, p->tile_beta, \
-                     p->n_inst, p->inst_tiles, p->noise, T, a.lambda_weight, my_packet, p->u, p->u_prev,        \
-                     p->u_host_dev, a.vrange[0], a.vrange[1], a.wrange[0], a.wrange[1], p->stats,                \
-                     p->graph_on ? p->gen_dev : (unsigned long long*)nullptr)
-  if (apply_here && many_rows) MPPI_LAUNCH_ROWS(true, 4);
-  else if (apply_here) MPPI_LAUNCH_ROWS(true, 1);
-  else if (many_rows) MPPI_LAUNCH_ROWS(false, 4);
-  else MPPI_LAUNCH_ROWS(false, 1);
+#define MPPI_LAUNCH_ROWS(APPLY, TC, FC)                                                                         \
+  hipLaunchKernelGGL((k_update_rows<APPLY, TC, FC>), grid, dim3(kRowThreads), lds, p->stream,                   \
+                     FC ? p->costs : p->w_rel, p->tile_beta, p->n_inst, p->inst_tiles, p->noise, T,             \
+                     a.lambda_weight, my_packet, p->u, p->u_prev, p->u_host_dev, a.vrange[0], a.vrange[1],      \
+                     a.wrange[0], a.wrange[1], p->stats, p->graph_on ? p->gen_dev : (unsigned long long*)nullptr)
+#define MPPI_LAUNCH_ROWS_TC(APPLY, FC)        \
+  do {                                        \
+    if (many_rows) MPPI_LAUNCH_ROWS(APPLY, 4, FC); \
+    else MPPI_LAUNCH_ROWS(APPLY, 1, FC);           \
+  } while (0)
+  if (apply_here && from_costs) MPPI_LAUNCH_ROWS_TC(true, true);
+  else if (apply_here) MPPI_LAUNCH_ROWS_TC(true, false);
+  else if (from_costs) MPPI_LAUNCH_ROWS_TC(false, true);
+  else MPPI_LAUNCH_ROWS_TC(false, false);
+#undef MPPI_LAUNCH_ROWS_TC
 #undef MPPI_LAUNCH_ROWS
   if (p->graph_on) ++p->bumps_launched;
   HIP_TRY(hipGetLastError());

@@ -75,7 +75,11 @@ constexpr int kRowThreads = 1024;
 // grid would otherwise be thousands of short-lived workgroups (batched handles).  Each
 // thread sums its strided subset in increasing i whatever TC and UN are, so the result does
 // not depend on them.
-template <bool APPLY, int TC>
+// FROM_COSTS: `w_rel` is the cost vector; the tile minima and the tile-relative weights are
+// formed here with the very expressions of emit_tile_weights (same bits), which saves the
+// k_tile_weights launch after the rollout kernels that have no such epilogue (CVaR, speed-map
+// fallback, barebone).
+template <bool APPLY, int TC, bool FROM_COSTS = false>
 __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __restrict__ w_rel,
                                                              const float* __restrict__ tile_beta, int n, int n_tiles,
                                                              const float2* __restrict__ noise, int n_steps,
@@ -103,6 +107,17 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
     u_mirror += (size_t)inst * n_steps;
     stats += 2 * inst;
   }
+  const double neg_inv_lambda = -1.0 / (double)lambda;
+  float* tb_sh = scale_sh + n_tiles;  // FROM_COSTS: [n_tiles] tile minima
+  if (FROM_COSTS) {
+    for (int g = wave; g < n_tiles; g += kRowThreads / 64) {
+      const int i = g * 64 + lane;
+      const float m = wave_min_f32(i < n ? w_rel[i] : __builtin_inff());
+      if (lane == 0) tb_sh[g] = m;
+    }
+    __syncthreads();
+    tile_beta = tb_sh;
+  }
   float b = __builtin_inff();
   for (int g = threadIdx.x; g < n_tiles; g += kRowThreads) b = fminf(b, tile_beta[g]);
   b = wave_min_f32(b);
@@ -110,7 +125,6 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
   __syncthreads();
   float beta = redf[0];
   for (int k = 1; k < kRowThreads / 64; ++k) beta = fminf(beta, redf[k]);
-  const double neg_inv_lambda = -1.0 / (double)lambda;
   for (int g = threadIdx.x; g < n_tiles; g += kRowThreads)
     scale_sh[g] = (float)exp(neg_inv_lambda * (double)(tile_beta[g] - beta));
   __syncthreads();
@@ -136,7 +150,9 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
     }
 #pragma unroll
     for (int k = 0; k < UN; ++k) {
-      double w = (double)scale_sh[(i + k * kRowThreads) >> 6] * (double)wr[k];
+      const int tile = (i + k * kRowThreads) >> 6;
+      if (FROM_COSTS) wr[k] = (float)exp(neg_inv_lambda * (double)(wr[k] - tb_sh[tile]));  // emit_tile_weights
+      double w = (double)scale_sh[tile] * (double)wr[k];
       den += w;
 #pragma unroll
       for (int j = 0; j < TC; ++j) {
@@ -146,7 +162,9 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
     }
   }
   for (; i < n; i += kRowThreads) {
-    double w = (double)scale_sh[i >> 6] * (double)w_rel[i];
+    float wr1 = w_rel[i];
+    if (FROM_COSTS) wr1 = (float)exp(neg_inv_lambda * (double)(wr1 - tb_sh[i >> 6]));
+    double w = (double)scale_sh[i >> 6] * (double)wr1;
     const float2* tile = noise + (size_t)(i >> 6) * n_steps * 64 + (i & 63);
     den += w;
 #pragma unroll

@@ -400,3 +400,27 @@ def test_sharded_iterations_track_the_single_gpu_loop(world):
     costs = np.concatenate([s.costs_d.copy_to_host() for s in shards])
     rel = np.abs(costs - full.costs_d.copy_to_host()) / np.abs(full.costs_d.copy_to_host())
     assert np.quantile(rel, 0.99) < 1e-4  # u differs by float64 rounding of the partial sums -> costs by ulps
+
+
+def test_update_from_costs_has_the_bits_of_the_epilogue_path():
+    """Tile-relative weights come from the rollout kernel's epilogue (pipelined / fused kernels)
+    or are formed by the row kernel itself from the cost vector (every other rollout kernel,
+    injected costs): same expressions, same bits."""
+    _, _, _, _, a, _ = build("c2", 4096 + 37)  # ragged last tile
+    _, _, _, _, b, _ = build("c2", 4096 + 37)
+    a.solve()
+    a.iterate_async(2)
+    a.synchronize()
+    u_in = a.u_cur_d.copy_to_host()
+    a.sample_noise()
+    noise = a.noise_samples_d.copy_to_host()
+    a.rollout()
+    assert "k_rollout_pipe" in a.last_rollout_kernel()
+    costs = a.costs_d.copy_to_host()
+    a.update()
+    b.set_u(u_in)
+    b.set_noise(noise)
+    b.set_costs(costs)
+    b.update()
+    assert np.array_equal(a.u_cur_d.copy_to_host(), b.u_cur_d.copy_to_host())
+    assert np.array_equal(a.weights_d.copy_to_host(), b.weights_d.copy_to_host())
