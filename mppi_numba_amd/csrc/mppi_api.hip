@@ -578,6 +578,10 @@ struct mppi_planner {
   // view of the same memory), solve() reads it after the stream has drained -- no copy on the hot path
   float2* u_host = nullptr;
   float2* u_host_dev = nullptr;
+  // set_u(): pinned staging + asynchronous copy; the next set_u waits for the previous copy only
+  float2* u_stage = nullptr;
+  hipEvent_t ev_u_staged = nullptr;
+  bool u_stage_busy = false;
   // device buffers
   float2* noise = nullptr;    // tile-major (n_local, T): the buffer the NEXT rollout/update reads
   float2* noise_buf[2] = {nullptr, nullptr};  // double buffer: noise of iteration k+1 is generated
@@ -671,6 +675,8 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   if (p->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(p->comm);
   dev_free(p->inst_dev);
   if (p->u_host) (void)hipHostFree(p->u_host);
+  if (p->u_stage) (void)hipHostFree(p->u_stage);
+  if (p->ev_u_staged) (void)hipEventDestroy(p->ev_u_staged);
   dev_free(p->noise_buf[0]);
   dev_free(p->noise_buf[1]);
   dev_free(p->staging);
@@ -731,6 +737,8 @@ static int planner_alloc(mppi_planner* p) {
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->u_host), B * T * sizeof(float2), hipHostMallocMapped));
   HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->u_host_dev), p->u_host, 0));
   memset(p->u_host, 0, B * T * sizeof(float2));
+  HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->u_stage), B * T * sizeof(float2), hipHostMallocDefault));
+  HIP_TRY(hipEventCreateWithFlags(&p->ev_u_staged, hipEventDisableTiming));
   p->inst_host.assign(B, BatchInst{});
   TRY(dev_alloc(&p->costs, N));
   TRY(dev_alloc(&p->weights_out, N));
@@ -860,12 +868,6 @@ extern "C" int mppi_planner_set_disc_obstacles(mppi_planner* p, const float* pos
   return MPPI_OK;
 }
 
-static int copy_in(mppi_planner* p, void* dst, const void* src, size_t bytes) {
-  HIP_TRY(hipSetDevice(p->cfg.device));
-  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, p->stream));
-  HIP_TRY(hipStreamSynchronize(p->stream));
-  return MPPI_OK;
-}
 static int copy_out(mppi_planner* p, void* dst, const void* src, size_t bytes) {
   HIP_TRY(hipSetDevice(p->cfg.device));
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, p->stream));
@@ -875,7 +877,16 @@ static int copy_out(mppi_planner* p, void* dst, const void* src, size_t bytes) {
 
 extern "C" int mppi_planner_set_u(mppi_planner* p, const float* u) {
   REQUIRE(p && u, MPPI_ERR_INVALID, "NULL argument");
-  return copy_in(p, p->u, u, sizeof(float2) * (size_t)p->B * (size_t)p->cfg.num_steps);
+  // on the control path (shift_and_update): no pageable copy, no stream synchronisation -- the
+  // caller's array is consumed before returning, the device copy is ordered on the planner's stream
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  const size_t bytes = sizeof(float2) * (size_t)p->B * (size_t)p->cfg.num_steps;
+  if (p->u_stage_busy) HIP_TRY(hipEventSynchronize(p->ev_u_staged));
+  memcpy(p->u_stage, u, bytes);
+  HIP_TRY(hipMemcpyAsync(p->u, p->u_stage, bytes, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipEventRecord(p->ev_u_staged, p->stream));
+  p->u_stage_busy = true;
+  return MPPI_OK;
 }
 extern "C" int mppi_planner_get_u(mppi_planner* p, float* u) {
   REQUIRE(p && u, MPPI_ERR_INVALID, "NULL argument");
