@@ -258,7 +258,8 @@ int mppi_planner_rng_states(mppi_planner* p, uint64_t* out, long capacity, long*
  * [0] noise  [1] rollout  [2] update (weights + weighted sum + apply)  [3] collective */
 int mppi_planner_set_profiling(mppi_planner* p, int enabled);
 int mppi_planner_stage_times(mppi_planner* p, float ms[4]);
-/* GPU time (ms, hipEvents on the planner's stream) of the last iterate/solve call */
+/* GPU time (ms, hipEvents on the planner's stream) of the last iterate_async call (of the
+ * last solve too while profiling is enabled; solve() does not time itself otherwise) */
 int mppi_planner_last_elapsed_ms(mppi_planner* p, float* ms);
 
 /* diagnostic: which rollout kernel variant (and its launch geometry) the last rollout used */

@@ -1613,25 +1613,30 @@ static void graph_signature(const mppi_planner* p, const DevParams& d, const mpp
   out.assign(reinterpret_cast<unsigned char*>(&sig), reinterpret_cast<unsigned char*>(&sig) + sizeof(sig));
 }
 
-static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int iterations) {
+// `timed`: bracket the iterations with events for mppi_planner_last_elapsed_ms / stage_times
+// (iterate_async, profiling); solve() on the control path skips them
+static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int iterations, bool timed = true) {
   REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
   TRY(check_tdms(p, lin, ang));
   TRY(ensure_packed(p, lin, ang));
   DevParams d = make_dev_params(p, lin, ang);
-  HIP_TRY(hipEventRecord(p->ev_begin, p->stream));
+  timed = timed || p->profile_stages;
+  if (timed) HIP_TRY(hipEventRecord(p->ev_begin, p->stream));
   // The noise of iteration k+1 does not depend on iteration k.  When the pipelined rollout
   // kernel runs, its spare workgroups generate it into the other half of the double buffer
   // (same launch, no extra dependency); otherwise it is generated in line.
   const bool use_graph = p->graph_on && !p->profile_stages && p->cfg.world_size == 1 && !p->comm;
   if (!use_graph) {
-    bool have_noise = p->graph_on && p->primed;
-    p->primed = false;
+    // Every iteration, the last one of a call included, asks for its successor's noise: when the
+    // rollout kernel can produce it on the side (spare workgroups, second stream) the next call --
+    // the next control step -- starts with its noise already there (`primed`).
+    bool have_noise = p->primed;
     for (int k = 0; k < iterations; ++k) {
-      // profiled iteration: a steady-state one when there is one (its rollout launch then
-      // also carries the noise of the following iteration), else the last
+      // profiled iteration: a steady-state one when there is one, else the last
       bool prof = p->profile_stages && k == (iterations >= 3 ? iterations - 2 : iterations - 1);
-      TRY(launch_iteration(p, d, have_noise, k + 1 < iterations, prof));
+      TRY(launch_iteration(p, d, have_noise, true, prof));
     }
+    p->primed = have_noise;
   } else {
     // Graph mode.  Every iteration also asks for the noise of its successor (`primed`; kernels that
     // cannot produce it ahead generate in line instead), so that all iterations look alike; two of
@@ -1685,9 +1690,11 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
     for (; k < iterations; ++k) TRY(launch_iteration(p, d, have_noise, true, false));
     p->primed = have_noise;
   }
-  HIP_TRY(hipEventRecord(p->ev_end, p->stream));
-  p->elapsed_pending = true;
-  p->last_iterations = iterations;
+  if (timed) {
+    HIP_TRY(hipEventRecord(p->ev_end, p->stream));
+    p->elapsed_pending = true;
+    p->last_iterations = iterations;
+  }
   return MPPI_OK;
 }
 
@@ -1743,7 +1750,7 @@ extern "C" int mppi_planner_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang,
       TRY(tdm_sample_on(ang, alpha, p->stream));
     }
   }
-  TRY(run_iterations(p, lin, ang, p->params.num_opt));
+  TRY(run_iterations(p, lin, ang, p->params.num_opt, /*timed=*/false));
   const size_t u_bytes = sizeof(float2) * (size_t)p->B * (size_t)p->cfg.num_steps;
   // with at least one iteration the last update kernel has written the host-mapped mirror
   if (p->params.num_opt < 1) HIP_TRY(hipMemcpyAsync(p->u_host, p->u, u_bytes, hipMemcpyDeviceToHost, p->stream));
@@ -1757,6 +1764,17 @@ extern "C" int mppi_planner_sample_noise(mppi_planner* p) {
   REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
   REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
   HIP_TRY(hipSetDevice(p->cfg.device));
+  if (p->primed) {
+    // the next block of the noise sequence has already been generated (by the last iteration of
+    // the previous call): hand it out instead of skipping it
+    if (p->noise_on_side_stream) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_noise_ready, 0));
+    p->noise_on_side_stream = false;
+    p->noise_cur ^= 1;
+    p->noise = p->noise_buf[p->noise_cur];
+    p->primed = false;
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return MPPI_OK;
+  }
   TRY(launch_noise(p, p->noise));
   HIP_TRY(hipStreamSynchronize(p->stream));
   return MPPI_OK;

@@ -219,25 +219,36 @@ class MPPI_Numba(object):
         everywhere except dist_weight / alpha_dyn) and hand it to the library."""
         p = self.params
         c = _lib.Params()
+        # (assigning a Python / numpy scalar to a c_float field rounds float64 -> float32 to
+        # nearest, which is what the reference's np.float32(...) casts do; no numpy temporaries
+        # on the control path)
         for name, count in (("x0", 3), ("xgoal", 2), ("vrange", 2), ("wrange", 2), ("u_std", 2)):
-            arr = _f32(p[name])
+            src, dst = p[name], getattr(c, name)
             for i in range(count):
-                getattr(c, name)[i] = arr[i]
-        c.dt = np.float32(p['dt'])
-        c.goal_tolerance = np.float32(p['goal_tolerance'])
-        c.v_post_rollout = np.float32(p['v_post_rollout'])
-        c.lambda_weight = np.float32(p['lambda_weight'])
-        c.cvar_alpha = np.float32(p['cvar_alpha'])
-        c.obs_cost = np.float32(DEFAULT_OBS_COST if 'obs_penalty' not in p else p['obs_penalty'])
-        c.unknown_cost = np.float32(DEFAULT_UNKNOWN_COST if 'unknown_penalty' not in p else p['unknown_penalty'])
-        c.res = np.float32(self.lin_tdm.res)
-        c.xlo = _f32(self.lin_tdm.padded_xlimits)[0]
-        c.ylo = _f32(self.lin_tdm.padded_ylimits)[0]
-        c.dist_weight = float(DEFAULT_DIST_WEIGHT if 'dist_weight' not in p else p['dist_weight'])
-        c.alpha_dyn = float(1.0 if 'alpha_dyn' not in p else p['alpha_dyn'])
+                dst[i] = float(src[i])
+        c.dt = float(p['dt'])
+        c.goal_tolerance = float(p['goal_tolerance'])
+        c.v_post_rollout = float(p['v_post_rollout'])
+        c.lambda_weight = float(p['lambda_weight'])
+        c.cvar_alpha = float(p['cvar_alpha'])
+        c.obs_cost = float(p.get('obs_penalty', DEFAULT_OBS_COST))
+        c.unknown_cost = float(p.get('unknown_penalty', DEFAULT_UNKNOWN_COST))
+        c.res = float(np.float32(self.lin_tdm.res))
+        c.xlo, c.ylo = self._padded_origin()
+        c.dist_weight = float(p.get('dist_weight', DEFAULT_DIST_WEIGHT))
+        c.alpha_dyn = float(p.get('alpha_dyn', 1.0))
         c.num_opt = int(p['num_opt'])
         _lib.call("mppi_planner_set_params", self._handle, C.byref(c))
         return c
+
+    def _padded_origin(self):
+        """float32 lower corner of the padded map (mppi.py:226-227), cached per map."""
+        tdm = self.lin_tdm
+        key = (id(tdm), float(tdm.padded_xlimits[0]), float(tdm.padded_ylimits[0]))
+        if getattr(self, "_origin_key", None) != key:
+            self._origin_key = key
+            self._origin = (float(_f32(tdm.padded_xlimits)[0]), float(_f32(tdm.padded_ylimits)[0]))
+        return self._origin
 
     def solve(self):
         """Entry point: sample the traction grids once, run params['num_opt']
