@@ -833,6 +833,9 @@ extern "C" int mppi_planner_create(const mppi_planner_cfg* cfg, mppi_planner** o
 static void discard_noise_ahead(mppi_planner* p) {
   if (p->primed && p->cfg.rng == MPPI_RNG_PHILOX) --p->noise_epoch;
   p->primed = false;
+  // a generator still in flight on the second stream must not overlap the next one on the main
+  // stream (they share the xoroshiro states)
+  if (p->noise_on_side_stream) (void)hipStreamWaitEvent(p->stream, p->ev_noise_ready, 0);
   p->noise_on_side_stream = false;
 }
 
