@@ -407,7 +407,7 @@ static int tdm_launch_philox(mppi_tdm* t, double alpha_dyn, uint64_t epoch, hipS
       // enough workgroups to fill the chip, as many samples per thread as that allows
       int chunks = ceil_div(256L * 1024, cell_groups);
       chunks = chunks < 1 ? 1 : (chunks > G ? G : chunks);
-      const int g_chunk = ceil_div(G, chunks);
+      const int g_chunk = (ceil_div(G, chunks) + 1) & ~1;  // even: a Philox block serves a pair of samples
       dim3 grid((unsigned)ceil_div(cell_groups, 256), (unsigned)ceil_div(G, g_chunk));
 #define MPPI_SAMPLE(MAXB)                                                                                       \
   hipLaunchKernelGGL(k_sample_grids_philox_cols<MAXB>, grid, dim3(256), 0, stream, t->pmf, t->bins, t->rows, t->cols, \

@@ -275,31 +275,36 @@ __device__ __forceinline__ void load_packed_thresholds(const int8_t* __restrict_
   }
 }
 
-// the 4 cells of cell group `cgid` in sample g: one Philox block -> 4 targets -> 4 int8 values
+// The 4 cells of cell group `cgid` in the sample PAIR (2p, 2p+1): one Philox block, each 32-bit
+// word split into two 16-bit uniforms (h + 1) / 65536 in (0, 1] -- the targets are integers in
+// [1, 100], 16 bits resolve the PMF's percent steps to 1.5e-5 -- so that a block serves 8 draws.
 template <int MAXB>
-__device__ __forceinline__ uint32_t draw_packed(const uint32_t (&cum)[MAXB], const uint32_t (&val)[MAXB], int bins,
-                                                uint32_t last, uint64_t seed, uint64_t epoch, uint64_t index,
-                                                double scale) {
-  const uint4 x = philox4x32_10(make_uint4((unsigned int)epoch, (unsigned int)(epoch >> 32), (unsigned int)index,
-                                           (unsigned int)(index >> 32)),
+__device__ __forceinline__ void draw_packed_pair(const uint32_t (&cum)[MAXB], const uint32_t (&val)[MAXB], int bins,
+                                                 uint32_t last, uint64_t seed, uint64_t epoch, uint64_t pair_index,
+                                                 double scale, uint32_t& picked0, uint32_t& picked1) {
+  const uint4 x = philox4x32_10(make_uint4((unsigned int)epoch, (unsigned int)(epoch >> 32),
+                                           (unsigned int)pair_index, (unsigned int)(pair_index >> 32)),
                                 make_uint2((unsigned int)seed, (unsigned int)(seed >> 32)));
   const unsigned int xs[4] = {x.x, x.y, x.z, x.w};
-  uint32_t target = 0;
+  uint32_t target0 = 0, target1 = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const float u = fmaf((float)xs[k], 2.3283064365386963e-10f, 1.1641532182693481e-10f);  // (0, 1]
-    const int t = (int)(int8_t)(int)ceil((double)u * scale);  // terrain.py:676: int8(ceil(rnd*100*alpha))
-    target |= (uint32_t)min(max(t, 0), 127) << (8 * k);
+    // terrain.py:676: int8(ceil(rnd * 100 * alpha)), rnd uniform in (0, 1]
+    const int t0 = (int)(int8_t)(int)ceil((double)((xs[k] & 0xffffu) + 1u) * (1.0 / 65536.0) * scale);
+    const int t1 = (int)(int8_t)(int)ceil((double)((xs[k] >> 16) + 1u) * (1.0 / 65536.0) * scale);
+    target0 |= (uint32_t)min(max(t0, 0), 127) << (8 * k);
+    target1 |= (uint32_t)min(max(t1, 0), 127) << (8 * k);
   }
-  uint32_t picked = last;
+  picked0 = picked1 = last;
 #pragma unroll
   for (int b = MAXB - 1; b >= 0; --b) {
     if (b < bins) {
-      const uint32_t reached = (((cum[b] - target) & 0x80808080u) >> 7) * 255u;  // 0xFF per cell that matched
-      picked = (val[b] & reached) | (picked & ~reached);
+      const uint32_t r0 = (((cum[b] - target0) & 0x80808080u) >> 7) * 255u;  // 0xFF per cell that matched
+      const uint32_t r1 = (((cum[b] - target1) & 0x80808080u) >> 7) * 255u;
+      picked0 = (val[b] & r0) | (picked0 & ~r0);
+      picked1 = (val[b] & r1) | (picked1 & ~r1);
     }
   }
-  return picked;
 }
 
 template <int MAXB>
@@ -315,13 +320,11 @@ __global__ __launch_bounds__(256) void k_sample_grids_philox_cols(const int8_t* 
   uint32_t cum[MAXB], val[MAXB];
   load_packed_thresholds<MAXB>(pmf, bins, rows, cols, table, r, cg, cum, val);
   const uint32_t last = (uint32_t)(uint8_t)table[bins - 1] * 0x01010101u;
-  const int g0 = blockIdx.y * g_chunk, g1 = min(g0 + g_chunk, n_grids);
+  const int g0 = blockIdx.y * g_chunk, g1 = min(g0 + g_chunk, n_grids);  // g_chunk is even
   const double scale = 100.0 * alpha_dyn;
   // hipMalloc'ed base, stride a multiple of 4, group inside the row: one aligned 32-bit store
   const bool word_store = (out_stride & 3) == 0 && cg * 4 + 3 < cols;
-  for (int g = g0; g < g1; ++g) {
-    const uint64_t index = (uint64_t)g * (uint64_t)(rows * groups) + (uint64_t)cgid;
-    const uint32_t picked = draw_packed<MAXB>(cum, val, bins, last, seed, epoch, index, scale);
+  auto store = [&](int g, uint32_t picked) {
     int8_t* o = out + ((size_t)g * out_rows + r) * out_stride + cg * 4;
     if (word_store) {  // uniform except for the last group of a row
       *reinterpret_cast<uint32_t*>(o) = picked;
@@ -330,17 +333,23 @@ __global__ __launch_bounds__(256) void k_sample_grids_philox_cols(const int8_t* 
       for (int k = 0; k < 4; ++k)
         if (cg * 4 + k < cols) o[k] = (int8_t)(picked >> (8 * k));
     }
+  };
+  for (int g = g0; g < g1; g += 2) {
+    const uint64_t pair_index = (uint64_t)(g >> 1) * (uint64_t)(rows * groups) + (uint64_t)cgid;
+    uint32_t p0, p1;
+    draw_packed_pair<MAXB>(cum, val, bins, last, seed, epoch, pair_index, scale, p0, p1);
+    store(g, p0);
+    if (g + 1 < n_grids) store(g + 1, p1);
   }
 }
 
 // The planner's view of the same draws, without the detour through the (G, R, C) int8 grids:
 // linear and angular traction of one solve() sampled straight into the cell words the CVaR
 // rollout gathers, cellsM[(r*cols + c)*M + m] = lin | ang << 8 | obstacle << 16 | unknown << 24.
-// A wave owns one group of 4 cells (its PMF columns are loaded once), lane = sample m (strided
-// if M > 64): every store is 64 consecutive words.  Philox counters are those of
-// k_sample_grids_philox_cols, so the int8 grids can be produced later from the same
-// (seed, epoch) when somebody asks for them (mppi_tdm_get_sampled_grids).
-// M = 128, 260x260, 16 bins: 2 x 27 us (sample) + 25 us (transpose) -> one launch.
+// A wave owns one group of 4 cells (its PMF columns are loaded once), a lane the sample pair
+// (2*lane, 2*lane + 1) (strided if M > 128): every store is 64 consecutive 8-byte pairs.
+// Philox counters are those of k_sample_grids_philox_cols, so the int8 grids can be produced
+// later from the same (seed, epoch) when somebody asks for them (mppi_tdm_get_sampled_grids).
 template <int MAXB>
 __global__ __launch_bounds__(256) void k_sample_cellsM_philox(
     const int8_t* __restrict__ lin_pmf, int lin_bins, const int8_t* __restrict__ lin_table, uint64_t lin_seed,
@@ -364,16 +373,26 @@ __global__ __launch_bounds__(256) void k_sample_cellsM_philox(
     flags[k] = ((uint32_t)(uint8_t)obs[ci] << 16) | ((uint32_t)(uint8_t)unk[ci] << 24);
   }
   const double scale = 100.0 * alpha_dyn;
-  for (int m = lane; m < n_grids; m += 64) {
-    const uint64_t index = (uint64_t)m * (uint64_t)(rows * groups) + (uint64_t)cgid;
-    const uint32_t lp = draw_packed<MAXB>(lcum, lval, lin_bins, llast, lin_seed, lin_epoch, index, scale);
-    const uint32_t ap = draw_packed<MAXB>(acum, aval, ang_bins, alast, ang_seed, ang_epoch, index, scale);
+  const bool pair_store = (n_grids & 1) == 0;  // rows of cellsM are 8-byte aligned
+  for (int pr = lane; 2 * pr < n_grids; pr += 64) {
+    const uint64_t pair_index = (uint64_t)pr * (uint64_t)(rows * groups) + (uint64_t)cgid;
+    uint32_t l0, l1, a0, a1;
+    draw_packed_pair<MAXB>(lcum, lval, lin_bins, llast, lin_seed, lin_epoch, pair_index, scale, l0, l1);
+    draw_packed_pair<MAXB>(acum, aval, ang_bins, alast, ang_seed, ang_epoch, pair_index, scale, a0, a1);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = cg * 4 + k;
-      if (c < cols)
-        cells[((size_t)r * cols + c) * n_grids + m] =
-            ((lp >> (8 * k)) & 0xffu) | (((ap >> (8 * k)) & 0xffu) << 8) | flags[k];
+      if (c < cols) {
+        const uint32_t w0 = ((l0 >> (8 * k)) & 0xffu) | (((a0 >> (8 * k)) & 0xffu) << 8) | flags[k];
+        const uint32_t w1 = ((l1 >> (8 * k)) & 0xffu) | (((a1 >> (8 * k)) & 0xffu) << 8) | flags[k];
+        uint32_t* o = cells + ((size_t)r * cols + c) * n_grids + 2 * pr;
+        if (pair_store) {
+          *reinterpret_cast<uint2*>(o) = make_uint2(w0, w1);
+        } else {
+          o[0] = w0;
+          if (2 * pr + 1 < n_grids) o[1] = w1;
+        }
+      }
     }
   }
 }
