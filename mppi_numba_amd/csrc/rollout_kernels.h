@@ -1,11 +1,14 @@
 // rollout_kernels.h -- the integrator kernels (gfx950, wave64).
 //
 // Replaces (reference paths relative to /root/reference/mppi_numba):
-//   rollout_det_dyn_numba              mppi.py:916-1009   -> k_rollout_map<DET>
-//   rollout_det_dyn_w_speed_map_numba  mppi.py:1013-1111  -> k_rollout_map<SPEED>
-//   rollout_numba / rollout_oversized  mppi.py:613-913    -> k_rollout_tdm
-//   barebone rollout_numba             barebone_mppi_numba.ipynb cell 3
-//   get_state_rollout_* kernels        mppi.py:1194-1351  -> k_state_rollout_*
+//   rollout_det_dyn_numba              mppi.py:916-1009   -> k_rollout_pipe (latency regime),
+//                                                             k_rollout_fused (throughput regime),
+//                                                             k_rollout_map<DET> (general)
+//   rollout_det_dyn_w_speed_map_numba  mppi.py:1013-1111  -> k_rollout_fused<.., SPEED>, k_rollout_map<SPEED>
+//   rollout_numba / rollout_oversized  mppi.py:613-913    -> k_rollout_tdm_fast, k_rollout_tdm
+//   barebone rollout_numba             barebone_mppi_numba.ipynb cell 3 -> k_rollout_barebone
+//   get_state_rollout_* kernels        mppi.py:1194-1351  -> k_state_rollout<..>
+// (which one runs: launch_rollout_t in mppi_api.hip)
 //
 // Device data layout (private to the library):
 //   noise  [N/64][T][64] float2   tile-major (device_math.h tile_index): lane n of a
