@@ -1210,6 +1210,30 @@ static bool plan_lds_window(mppi_planner* p, DevParams& d, size_t* lds_bytes) {
   return true;
 }
 
+// Waves (tiles of 64 rollouts) per workgroup of the one-wave-per-tile kernels that keep the map
+// window in LDS.  The window makes it one workgroup per CU, so the workgroup is sized to cover
+// the problem in one round: at least 4 waves (one per SIMD, and enough lanes to copy the
+// window), at most 16.  Batched handle: a workgroup stays inside one problem, i.e. the count
+// divides the tiles per problem -- among the divisors the one with the fewest rounds, then the
+// smallest (1536 tiles: 8 waves in 1 round, not 4 waves in 2; measured 130 -> 105 us).
+static int fused_waves_per_workgroup(const mppi_planner* p, int n_rollouts) {
+  const int tiles = ceil_div(n_rollouts, 64);
+  int waves = ceil_div(tiles, p->num_cus);
+  waves = waves < 4 ? 4 : (waves > 16 ? 16 : waves);
+  if (!p->inst_set) return waves;
+  auto pick = [&](int lowest) {
+    int best = 0, best_rounds = 1 << 30;
+    for (int d = lowest; d <= 16; ++d) {
+      if (p->inst_tiles % d != 0) continue;
+      const int rounds = ceil_div(ceil_div(tiles, d), p->num_cus);
+      if (rounds < best_rounds) { best = d; best_rounds = rounds; }  // ascending: ties keep the smallest
+    }
+    return best;
+  };
+  const int at_least_four = pick(4);
+  return at_least_four ? at_least_four : pick(1);
+}
+
 // per-problem start / goal / window origin -> device, when they changed
 static int upload_instances(mppi_planner* p) {
   if (!p->inst_set || !p->inst_dirty) return MPPI_OK;
@@ -1325,10 +1349,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         // the window makes it one workgroup per CU: size the workgroup so that the grid
         // is at most one wave of workgroups over the CUs
         // (at least 4 waves: one per SIMD, and four times the lanes to copy the window)
-        int waves = ceil_div(ceil_div(N, 64), p->num_cus);
-        waves = waves < 4 ? 4 : (waves > 16 ? 16 : waves);
-        // batched handle: a workgroup stays inside one problem
-        if (p->inst_set) while (p->inst_tiles % waves != 0) --waves;
+        const int waves = fused_waves_per_workgroup(p, N);
         int block = 64 * waves;
         static const bool no_fused = getenv("MPPI_NO_FUSED") != nullptr;  // developer switch (ablation)
         if (rot_ok && !no_fused) {
@@ -1376,9 +1397,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
       double dmax = (double)a.dt * wmax * trmax;
       static const bool no_fused = getenv("MPPI_NO_FUSED") != nullptr;  // developer switch (ablation)
       if (have_window && EXACT && BOUNDED && std::isfinite(dmax) && dmax <= 0.36 && T <= 2000 && !no_fused) {
-        int waves = ceil_div(ceil_div(N, 64), p->num_cus);
-        waves = waves < 4 ? 4 : (waves > 16 ? 16 : waves);
-        if (p->inst_set) while (p->inst_tiles % waves != 0) --waves;
+        const int waves = fused_waves_per_workgroup(p, N);
         int res_exp = 0;
         const bool pow2res = std::frexp((double)a.res, &res_exp) == 0.5;
         auto fused = pow2res ? k_rollout_fused<true, true> : k_rollout_fused<false, true>;
