@@ -30,7 +30,9 @@ def build(mode, n, t_steps, m):
     return cfg, lin, ang, planner, params
 
 
-@pytest.mark.parametrize("n,t_steps", [(1, 1), (1, 9), (2, 2), (63, 7), (64, 8), (65, 17), (130, 1), (257, 33)])
+@pytest.mark.parametrize("n,t_steps", [(1, 1), (1, 9), (2, 2), (63, 7), (64, 8), (65, 17), (130, 1), (257, 33),
+                                       (130, 1500),   # long horizon, still inside the incremental trig's proof
+                                       (70, 2500)])   # beyond it (T > 2000): the full-sincos kernel
 def test_det_edge_sizes(n, t_steps):
     cfg, lin, ang, planner, params = build(dict(use_det_dynamics=True), n, t_steps, 1)
     u0 = planner.solve()
