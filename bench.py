@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the MPPI hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5] [--graph ITERATIONS]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one MPPI iteration: sample control noise -> roll every control
@@ -11,7 +11,8 @@ Inputs (maps, sampled grids, warm-started u) are resident in HBM before the
 timed region; the K steps run back to back on the planner's stream (u stays on
 the device between steps, exactly the data dependence of params['num_opt'] = K).
 
-Workloads (synthetic; BASELINE.json configs[1..3]):
+Workloads (synthetic; BASELINE.json configs[1..4]; default c2, the
+configuration BASELINE.json's metric is quoted on):
   c2  use_det_dynamics, N=8192 per GPU, T=100, 256x256 nominal traction grid
   c3  use_tdm (CVaR), N=4096 x M=128, 16-bin PMF, 256x256
   c4  use_det_dynamics, N=65536 per GPU, T=200, CVaR-bin traction
@@ -22,7 +23,9 @@ Multi-GPU is weak scaling: every rank owns `N` control samples of a global
 problem of N*world samples (noise is keyed by the global sample index).
 
 Prints ONE JSON line (rank 0).  torch is imported only for the multi-process
-rendezvous (gloo): the product path is ctypes -> libmppi_hip.so.
+rendezvous (gloo): the product path is ctypes -> libmppi_hip.so.  If the RCCL
+communicator cannot be created the ranks exchange their packets through the host
+(gloo) instead and the JSON says so (config.exchange).
 """
 import argparse
 import json
