@@ -339,7 +339,7 @@ def main():
         "metric": "rollouts/sec (MPPI iteration = noise + rollout + update)",
         "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32 state / f64 intermediates (reference CPU-path roundings)"
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64 intermediates / f32 state (the reference CPU path's roundings)"
         if args.math == "exact" else "f32",
         "data": "synthetic",
         "config": {"workload": w["label"], "rollouts_per_gpu": n_local, "global_rollouts": n_global,
