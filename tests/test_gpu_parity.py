@@ -22,7 +22,10 @@ pytestmark = pytest.mark.gpu
 MAP_FIXTURES = ["det_cvar", "det_mean", "speedmap_cvar", "speedmap_mean", "tdm_cvar",
                 "tdm_mean_alpha_dyn", "tdm_cvar_odd", "tdm_oversized_mean",
                 # res = 0.3, dt = 0.05, reverse driving, |theta0| of several turns, bounds (0, 1.2)
-                "det_odd_units", "speedmap_odd_units", "tdm_odd_units"]
+                "det_odd_units", "speedmap_odd_units", "tdm_odd_units",
+                # the same set-ups on other random worlds (GOLDEN_SEED_OFFSET=101 / 202)
+                "det_odd_units_w101", "speedmap_odd_units_w101", "tdm_odd_units_w101",
+                "det_odd_units_w202", "speedmap_odd_units_w202", "tdm_odd_units_w202"]
 
 
 def control_scale(P):
