@@ -97,7 +97,8 @@ def test_update_vs_golden(name):
 
 
 @pytest.mark.parametrize("name", ["det_cvar", "speedmap_cvar", "tdm_cvar", "tdm_mean_alpha_dyn",
-                                  "tdm_cvar_odd", "tdm_oversized_mean"])
+                                  "tdm_cvar_odd", "tdm_oversized_mean", "det_odd_units", "speedmap_odd_units",
+                                  "tdm_odd_units", "det_odd_units_w101", "tdm_odd_units_w202"])
 def test_end_to_end_from_seed_xoroshiro(name):
     """Level L3: with the numba-compatible generator the whole closed loop
     (sample grids -> noise -> rollout -> update -> shift) reproduces the
@@ -131,7 +132,8 @@ def test_end_to_end_from_seed_xoroshiro(name):
         s += 1
 
 
-@pytest.mark.parametrize("name", ["det_cvar", "speedmap_cvar", "tdm_cvar", "tdm_mean_alpha_dyn"])
+@pytest.mark.parametrize("name", ["det_cvar", "speedmap_cvar", "tdm_cvar", "tdm_mean_alpha_dyn", "det_odd_units",
+                                  "speedmap_odd_units_w101", "tdm_odd_units_w202"])
 def test_state_rollout_vs_golden(name):
     g = golden(name)
     _, lin, ang, planner, P = build_from_golden(name, g)

@@ -125,7 +125,8 @@ def test_update_reference_launch(name):
 
 
 @pytest.mark.parametrize("name", ["det_cvar", "speedmap_cvar", "tdm_cvar", "tdm_mean_alpha_dyn",
-                                  "tdm_cvar_odd", "tdm_oversized_mean"])
+                                  "tdm_cvar_odd", "tdm_oversized_mean", "det_odd_units", "speedmap_odd_units",
+                                  "tdm_odd_units", "det_odd_units_w101", "tdm_odd_units_w202"])
 def test_noise_and_grids_from_seed(name):
     """xoroshiro streams persist across sample_noise / sample_grids calls."""
     g = golden(name)
