@@ -507,10 +507,19 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
   // control-cost products of this triple's 64 rollouts, [T][64] float64, when LDS has room
   double* cc_lds = reinterpret_cast<double*>(ring_base + (size_t)W * Ring::kBytesPerPair) + (size_t)triple * T * 64;
 
-  // the control sequence first (small), so that the producer waves can publish chunk 0
-  // while the state and cost waves copy the map window
-  for (int t = threadIdx.x; t < T; t += blockDim.x) us[t] = u[t];
-  stage_control_ratios(P, u, uos);  // ends with a barrier
+  // Only the producer waves read the staged controls (us) and control-cost ratios (uos): each of
+  // them stages the arrays itself (the same values to the same addresses when there are several)
+  // and goes on without a workgroup barrier -- a wave's LDS operations complete in order --
+  // while the state and cost waves are already copying the map window.
+  if (role == 2) {
+    for (int t = lane; t < T; t += 64) {
+      const float2 ut = u[t];
+      us[t] = ut;
+      uos[t] = make_double2((double)ut.x / P.s0sq, (double)ut.y / P.s1sq);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
   // (24 loads in flight per lane instead of 8 was measured: no change)
   copy_window_to_lds(P, cells16, lds_map, 0, 128 * W);  // waves of roles 0 and 1
 
