@@ -23,7 +23,7 @@ pytestmark = pytest.mark.skipif(
     reason="needs the reference and its numba interpreter (build container only)")
 
 
-@pytest.fixture(scope="module", params=[101, 202])
+@pytest.fixture(scope="module", params=[303])
 def live_fixtures(request, tmp_path_factory):
     out = tmp_path_factory.mktemp("live_golden_%d" % request.param)
     cmd = [NUMBA_PYTHON, os.path.join(ROOT, "oracle", "gen_golden.py"), "--out", str(out)]
