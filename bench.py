@@ -2,7 +2,6 @@
 """Benchmark of the MPPI hot path on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5] [--graph ITERATIONS]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one MPPI iteration: sample control noise -> roll every control
 sample through the horizon with traction-grid lookups -> min-subtract +
@@ -10,6 +9,15 @@ exp-weighted control update (+ one RCCL all-gather of 2T+2 doubles when N > 1).
 Inputs (maps, sampled grids, warm-started u) are resident in HBM before the
 timed region; the K steps run back to back on the planner's stream (u stays on
 the device between steps, exactly the data dependence of params['num_opt'] = K).
+
+Multi-GPU (`--gpus N`, one node): one process per GPU.  Launched plainly, this script
+starts its N ranks itself (mppi_numba_amd/launch.py); launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` it takes
+RANK / LOCAL_RANK / WORLD_SIZE from the launcher.  Either way there is no torch in the
+process: the RCCL unique id, the barrier and the max-over-ranks clock go over a small
+TCP hub on 127.0.0.1, the data path is RCCL on the planner's stream.
+`--single-process` instead drives all N devices from ONE process (mppi_group_*: the
+communicators and every iteration's all-gathers are issued inside RCCL groups).
 
 Workloads (synthetic; BASELINE.json configs[1..4]; default c2, the
 configuration BASELINE.json's metric is quoted on):
@@ -22,10 +30,9 @@ configuration BASELINE.json's metric is quoted on):
 Multi-GPU is weak scaling: every rank owns `N` control samples of a global
 problem of N*world samples (noise is keyed by the global sample index).
 
-Prints ONE JSON line (rank 0).  torch is imported only for the multi-process
-rendezvous (gloo): the product path is ctypes -> libmppi_hip.so.  If the RCCL
-communicator cannot be created the ranks exchange their packets through the host
-(gloo) instead and the JSON says so (config.exchange).
+Prints ONE JSON line (rank 0).  If the RCCL communicator cannot be created the ranks
+exchange their packets through the host (the TCP hub) instead and the JSON says so
+(config.exchange).
 """
 import argparse
 import json
@@ -159,9 +166,55 @@ def cpu_baseline(w, world_params, lin, ang, planner, budget_s=12.0):
         if el > budget_s or iters >= 5000:
             break
     return dict(value=n_cpu * iters / el, unit="rollouts/s", cores=threads, kind="port",
+                parity_check=parity_margin(w, p, P, (lin_g, ang_g, obs, unk), planner),
                 sample="%d iterations of {xoroshiro noise, rollout, update} on %d of the %d "
                        "control samples (T=%d, M=%d), oracle/liboracle.so with OpenMP over rollouts, "
                        "%.1f s" % (iters, n_cpu, n, t, m, el))
+
+
+def parity_margin(w, p, P, grids, planner):
+    """One stage-level iteration of the benchmarked handle against the oracle on the same noise
+    and controls (the oracle as the CHECKER): fraction of bit-identical costs and the achieved
+    max |du| / control range (bound 1e-5, BASELINE.json north_star)."""
+    from oracle import oracle as O
+    t = w["t"]
+    if planner.num_instances != 1 or planner.world_size != 1:
+        return None  # checked per problem / per shard in tests/
+    planner.sample_noise()
+    noise = planner.noise_samples_d.copy_to_host()
+    u_in = planner.u_cur_d.copy_to_host().reshape(t, 2)
+    planner.rollout()
+    got = planner.costs_d.copy_to_host()
+    planner.update()
+    u_out = planner.u_cur_d.copy_to_host().reshape(t, 2)
+    want = (O.rollout_det if w["m"] == 1 else O.rollout_tdm)(p, *grids, noise, u_in)
+    _, u_ref, _ = O.update_useq(P["lambda_weight"], want, noise, P["vrange"], P["wrange"], u_in)
+    span = np.array([P["vrange"][1] - P["vrange"][0], P["wrange"][1] - P["wrange"][0]])
+    return dict(costs_bit_identical=float((got.view(np.int32) == want.view(np.int32)).mean()),
+                costs_max_rel=float((np.abs(got - want) / np.abs(want)).max()),
+                u_max_abs_over_range=float((np.abs(u_out - u_ref) / span).max()), u_bound=1e-5)
+
+
+def reference_cpu_path():
+    """BASELINE configs[0] through the reference's own code under the CUDA
+    simulator, when this box has both the reference and its interpreter; otherwise say so and
+    quote the build-container measurement committed under profiles/."""
+    script = os.path.join(ROOT, "oracle", "time_reference_cudasim.py")
+    py, ref = "/opt/conda/bin/python3.9", "/root/reference/mppi_numba/mppi.py"
+    if os.path.exists(py) and os.path.exists(ref):
+        import subprocess
+        try:
+            run = subprocess.run([py, script, "--solves", "3"], capture_output=True, text=True, timeout=300)
+            return json.loads(run.stdout.strip().splitlines()[-1])
+        except Exception as e:  # noqa: BLE001 -- a diagnostic leg must not take the bench down
+            return dict(status="failed: %s" % e)
+    out = dict(status="unavailable on this box (%s absent)" % ("/root/reference" if not os.path.exists(ref) else py))
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_reference_cudasim.json")) as fh:
+            out["measured_in_build_container"] = json.loads(fh.read())
+    except (OSError, ValueError):
+        pass
+    return out
 
 
 def main():
@@ -179,23 +232,22 @@ def main():
                          "0 = direct launches (single GPU; same results)")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "host"],
                     help="multi-GPU packet exchange: RCCL all-gather on the stream (default) or, for debugging "
-                         "on a box where several ranks must share one GPU, host-staged over gloo")
+                         "on a box where several ranks must share one GPU, host-staged over the rendezvous hub")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N from ONE process driving N devices (mppi_group_*) instead of one process per GPU")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
-                     "(--nproc-per-node %d)" % (args.gpus, args.gpus))
-        args.gpus = world
+    from mppi_numba_amd import launch
+    if args.gpus > 1 and not args.single_process and not launch.launched_by_a_launcher():
+        # plain `python bench.py --gpus N`: start the N ranks (one per GPU) ourselves
+        sys.exit(launch.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
-    dist = None
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        import torch.distributed as dist  # rendezvous + barrier only (gloo, CPU)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rank, local_rank, world = launch.rank_from_env()
+    if args.single_process:
+        rank, local_rank, world = 0, 0, 1
+    elif world != args.gpus:
+        args.gpus = world  # the launcher's word counts
+    hub = launch.Hub(rank, world)
 
     from mppi_numba_amd import _lib
     from mppi_numba_amd.config import Config
@@ -209,6 +261,11 @@ def main():
     problems = (args.problems or w["problems"]) if "problems" in w else 0
     n_global = n_local if problems else n_local * world  # c5: the ranks are independent
     device = local_rank % max(1, _lib.device_count())
+    group_size = args.gpus if args.single_process else 1
+    if group_size > 1:
+        assert not problems and not args.graph, "--single-process: sharded workloads, direct launches"
+        assert _lib.device_count() >= group_size, "%d devices for --gpus %d" % (_lib.device_count(), group_size)
+        n_global = n_local * group_size
 
     import contextlib
     import io
@@ -229,6 +286,20 @@ def main():
             from mppi_numba_amd.batch import MPPI_Batch
             planner = MPPI_Batch(cfg, problems)
             planner.setup(params, lin, ang, *batch_problems(problems, np.random.default_rng(100 + rank)))
+        elif group_size > 1:
+            import copy
+            from mppi_numba_amd.mppi import MPPI_Group
+            cfgs, lins, angs = [cfg], [lin], [ang]
+            for g in range(1, group_size):
+                c = copy.deepcopy(cfg)
+                c.device = g
+                lg, ag = TDM_Numba(c), TDM_Numba(c)
+                lg.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
+                ag.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
+                cfgs.append(c); lins.append(lg); angs.append(ag)
+            group = MPPI_Group(cfgs)
+            group.setup(params, lins, angs)
+            planner = group.planners[0]
         else:
             planner = MPPI_Numba(cfg, rank=rank, world_size=world)
             planner.setup(params, lin, ang)
@@ -236,41 +307,34 @@ def main():
 
     exchange_note = None
     if world > 1 and args.exchange == "rccl" and not problems:
-        import torch
         err = ""
         try:
-            ids = [comm_unique_id() if rank == 0 else None]
+            uid = comm_unique_id() if rank == 0 else None
         except Exception as e:  # rank 0 could not even load RCCL
-            ids, err = [None], str(e)
-        dist.broadcast_object_list(ids, src=0)
-        if ids[0] is not None:
+            uid, err = None, str(e)
+        uid = hub.broadcast(uid)
+        if uid is not None:
             try:
-                planner.comm_init(ids[0])
+                planner.comm_init(uid)
             except Exception as e:
                 err = str(e)
-        failed = torch.tensor([1 if (err or ids[0] is None) else 0])
-        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
-        if int(failed.item()):
+        failed = hub.all_max(1 if (err or uid is None) else 0)
+        if failed:
             # keep the run alive and say so: same kernels, packets staged through the host
             args.exchange = "host"
-            exchange_note = "RCCL communicator unavailable (%s): packets exchanged over gloo" % (err or "on another rank")
+            exchange_note = "RCCL communicator unavailable (%s): packets exchanged through the host" % (err or "on another rank")
             print("bench.py rank %d: %s" % (rank, exchange_note), file=sys.stderr)
-            if err == "" and ids[0] is not None:
+            if err == "" and uid is not None:
                 # this rank did create a communicator the others lack: never use it
                 planner = MPPI_Numba(cfg, rank=rank, world_size=world)
                 planner.setup(params, lin, ang)
 
     if world > 1 and args.exchange == "host" and not problems:
-        import torch
-
-        def iterate(k):  # one launch sequence per iteration, packets over gloo
+        def iterate(k):  # one launch sequence per iteration, packets over the hub
             for _ in range(k):
                 planner.sample_noise()
                 planner.rollout()
-                mine = torch.from_numpy(planner.update_local())
-                gathered = [torch.zeros_like(mine) for _ in range(world)]
-                dist.all_gather(gathered, mine)
-                planner.update_apply(np.stack([g.numpy() for g in gathered]))
+                planner.update_apply(np.stack(hub.all_gather(planner.update_local())))
         def solve_staged():  # solve() = sample the traction grids once, then iterate
             lin.sample_grids(params.get("alpha_dyn", 1.0) if w["m"] > 1 else 1.0)
             ang.sample_grids(params.get("alpha_dyn", 1.0) if w["m"] > 1 else 1.0)
@@ -278,41 +342,39 @@ def main():
         planner.iterate_async = iterate
         planner.solve = solve_staged
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    runner = group if group_size > 1 else planner  # what iterates: one handle or the device group
 
-    if args.graph and world == 1:
+    def barrier():
+        hub.barrier()
+
+    if args.graph and world == 1 and group_size == 1:
         planner.set_graph_replay(True, args.graph)
 
     # warm start: one full solve (samples the grids) + 10 iterations
-    planner.solve()
-    planner.iterate_async(10)
-    planner.synchronize()
+    runner.solve()
+    runner.iterate_async(10)
+    runner.synchronize()
 
     # ---- timed region ------------------------------------------------------------
-    planner.iterate_async(args.warmup)
-    planner.synchronize()
+    runner.iterate_async(args.warmup)
+    runner.synchronize()
     barrier()
     t0 = time.perf_counter()
-    planner.iterate_async(args.steps)
-    planner.synchronize()
+    runner.iterate_async(args.steps)
+    runner.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     gpu_ms = planner.last_elapsed_ms()
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = hub.all_max(elapsed)
     ms_per_step = 1e3 * elapsed / args.steps
     rollouts_per_step = (problems * n_local * world) if problems else n_global
     value = rollouts_per_step * args.steps / elapsed
+    rccl_ranks = planner.comm_count()
 
     # ---- per-kernel durations with HIP events on the planner's stream ---------------
     planner.set_profiling(True)
     stage = dict(noise=0.0, rollout=0.0, update=0.0, collective=0.0)
-    reps = 0 if (world > 1 and args.exchange == "host" and not problems) else 50
+    reps = 0 if ((world > 1 and args.exchange == "host" and not problems) or group_size > 1) else 50
     for _ in range(reps):
         planner.iterate_async(3)  # the middle iteration is profiled: steady state
         planner.synchronize()
@@ -322,6 +384,7 @@ def main():
 
     if rank != 0:
         barrier()
+        hub.close()
         return
 
     kernel_name = planner.last_rollout_kernel().split(" ")[0]
@@ -337,28 +400,38 @@ def main():
     achieved = bytes_roll / roll_s / 1e9 if roll_s > 0 else 0.0
     out = {
         "metric": "rollouts/sec (MPPI iteration = noise + rollout + update)",
-        "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": args.steps,
+        "value": value, "unit": "rollouts/s", "n_gpus": world * group_size, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64 intermediates / f32 state (the reference CPU path's roundings)"
         if args.math == "exact" else "f32",
         "data": "synthetic",
         "config": {"workload": w["label"], "rollouts_per_gpu": n_local, "global_rollouts": n_global,
                    "horizon_steps": t_steps, "traction_samples": m, "padded_grid": [int(rp), int(cp)],
-                   "rng": "rocRAND philox4x32-10", "math": args.math,
+                   "rng": "Philox4x32-10 counters (rocRAND-identical engine) + hardware Box-Muller", "math": args.math,
                    "problems_per_gpu": problems or 1,
                    "graph_replay_iterations": args.graph if world == 1 else 0,
                    "rollout_kernel": planner.last_rollout_kernel(),
                    "sharding": "independent problems over ranks, no exchange" if problems else
                                "control samples over ranks, 1 all-gather of (2T+2) f64 per step",
-                   "exchange": "none" if (world == 1 or problems) else
+                   "exchange": "none" if ((world == 1 and group_size == 1) or problems) else
                                ("RCCL all-gather on the planner's stream" if args.exchange == "rccl" else
-                                (exchange_note or "host-staged over gloo (--exchange host)"))},
+                                (exchange_note or "host-staged through the rendezvous hub (--exchange host)")),
+                   "n_ranks_seen_by_rccl": rccl_ranks,
+                   "launcher": ("one process, %d devices (mppi_group_*)" % group_size) if group_size > 1 else
+                               ("one process per GPU, %s" % ("external launcher (RANK/WORLD_SIZE)"
+                                                             if "MPPI_RDZV_FILE" not in os.environ else
+                                                             "started by bench.py itself")) if world > 1 else "single process"},
         "gpu_ms_per_step_events": gpu_ms / args.steps,
         "kernel_ms": stage,
+        "kernel_ms_note": "each stage of ONE iteration bracketed by its own HIP events on the planner's stream; every "
+                          "bracket adds ~3 us of event overhead, so the stages sum to more than ms_per_step (which has "
+                          "no events inside the loop); rocprofv3 durations of the same kernels: profiles/",
         "roofline": {"bound": "hbm",
                      "kernel": kernel_name + (" (rollout + next iteration's noise)" if kernel_name == "k_rollout_pipe" else ""),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                       "kernel on this workload (committed; not re-measured in this run)",
                      "algorithmic_bytes_per_launch": bytes_roll,
                      "kernel_ms": stage["rollout"]},
         "roofline_iteration": {"bound": "hbm", "achieved": bytes_iter / (ms_per_step * 1e-3) / 1e9,
@@ -369,8 +442,11 @@ def main():
     if not args.no_cpu_baseline:
         with quiet:
             out["cpu_baseline"] = cpu_baseline(w, params, lin, ang, planner)
+        out["cpu_baseline_reference"] = reference_cpu_path()
     print(json.dumps(out))
+    sys.stdout.flush()
     barrier()
+    hub.close()
 
 
 if __name__ == "__main__":

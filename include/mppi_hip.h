@@ -268,7 +268,8 @@ int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity)
 /* diagnostic: compares the library's single-block Philox4x32-10 with rocRAND's engine on
  * 65536 (seed, subsequence, offset) triples; *mismatches must come back 0 */
 int mppi_selftest_philox(int device, int* mismatches);
-/* hipGraph replay of the iteration loop (off by default; single GPU).
+/* hipGraph replay of the iteration loop (off by default).  A sharded handle needs its RCCL
+ * communicator first: the all-gather is captured with the kernels.
  * iterations_per_graph: 0 = off, else an even number (the noise double buffer must come
  * back to where it was).  When on, every iteration also produces the noise of its
  * successor, that many iterations are captured into a graph the first time and replayed
@@ -291,6 +292,15 @@ int mppi_planner_graph_probe(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int 
 #define MPPI_COMM_ID_BYTES 128
 int mppi_comm_unique_id(char id[MPPI_COMM_ID_BYTES]);
 int mppi_planner_comm_init(mppi_planner* p, const char id[MPPI_COMM_ID_BYTES]);
+/* ranks RCCL itself reports for the handle's communicator (ncclCommCount); 0 without one */
+int mppi_planner_comm_count(mppi_planner* p, int* ranks);
+/* One process driving `count` devices: planners[g] is rank g of `count` on its own device.
+ * comm_init creates all communicators inside one RCCL group; iterate_async runs `iterations` x
+ * {per device: noise, rollout, shard packet | one group of all-gathers | per device: apply} and
+ * returns without waiting (mppi_planner_synchronize each handle).  Replaces, for a multi-GPU
+ * planner, the single-device numba context of the reference (config.py:9, mppi.py:186-303). */
+int mppi_group_comm_init(mppi_planner** planners, int count);
+int mppi_group_iterate_async(mppi_planner** planners, mppi_tdm** lins, mppi_tdm** angs, int count, int iterations);
 /* host-staged alternative to RCCL (the exchange itself is then done by the
  * caller, e.g. over gloo): packet = {beta, den, num[T][2]} of the local shard,
  * 2T+2 doubles; update_apply takes the packets of all ranks in rank order */

@@ -123,6 +123,9 @@ SIGNATURES = {
     "mppi_planner_graph_stats": [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)],
     "mppi_comm_unique_id": [C.c_char_p],
     "mppi_planner_comm_init": [_vp, C.c_char_p],
+    "mppi_planner_comm_count": [_vp, C.POINTER(C.c_int)],
+    "mppi_group_comm_init": [C.POINTER(_vp), C.c_int],
+    "mppi_group_iterate_async": [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.c_int, C.c_int],
     "mppi_planner_packet_len": [_vp, C.POINTER(C.c_int)],
     "mppi_planner_update_local": [_vp, _f64p],
     "mppi_planner_update_apply": [_vp, _f64p, C.c_int],

@@ -27,8 +27,11 @@ def _query_limits():
             limits = dict(max_threads_per_block=pr.max_threads_per_block,
                           max_block_dim_x=pr.max_block_dim_x,
                           max_grid_dim_x=pr.max_grid_dim_x)
-    except (ImportError, OSError):
-        pass  # Config-only use without the built library
+    except (ImportError, OSError, AttributeError, RuntimeError):
+        # Config-only use: library not built (ImportError / OSError), a stale build that lacks an
+        # entry point (AttributeError from the symbol lookup), or a device query that fails
+        # (MppiError, a RuntimeError).  The limits only steer clamps and messages.
+        pass
     return limits
 
 

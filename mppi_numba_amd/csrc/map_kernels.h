@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256) void k_prepare_maps(PrepJob J) {
     J.risk[i] = 0;
   } else {  // PREP_SPEED
     for (int b = 0; b < J.bins; ++b) J.pmf[(size_t)b * plane + i] = (b == J.bins - 1) ? (int8_t)100 : (int8_t)0;
-    const double scaled = 100.0 * ((target - (double)J.lo) / (double)J.span);
+    // the mean is scaled as (100*(mean - lo))/range (terrain.py:476-478), the CVaR as
+    // 100*((cvar - lo)/range) (terrain.py:488-490): after truncation the two can differ by one
+    const double scaled = (J.alpha == 1.0) ? (100.0 * (target - (double)J.lo)) / (double)J.span
+                                           : 100.0 * ((target - (double)J.lo) / (double)J.span);
     J.risk[i] = (int8_t)(int)scaled;  // astype(np.int8) of a value in [0, 100]: truncation
   }
 }

@@ -519,6 +519,9 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -535,9 +538,12 @@ static int rccl_load() {
   g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
   g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
   g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
+  g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
+  g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(h, "ncclGroupStart");
+  g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(h, "ncclGroupEnd");
   g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
   REQUIRE(g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllGather &&
-              g_rccl.GetErrorString,
+              g_rccl.GetErrorString && g_rccl.CommCount && g_rccl.GroupStart && g_rccl.GroupEnd,
           MPPI_ERR_COMM, "librccl.so lacks expected symbols");
   g_rccl.handle = h;
   return MPPI_OK;
@@ -847,6 +853,9 @@ extern "C" int mppi_planner_set_params(mppi_planner* p, const mppi_params* param
   REQUIRE(params->u_std[0] > 0.0f && params->u_std[1] > 0.0f, MPPI_ERR_INVALID, "u_std must be > 0");
   if (p->params_set && (p->params.u_std[0] != params->u_std[0] || p->params.u_std[1] != params->u_std[1]))
     discard_noise_ahead(p);  // it was scaled with the old standard deviations
+  // tile-relative weights emitted by the last rollout's epilogue are exp(-(c - beta_tile)/lambda_old):
+  // a stage-level update() after a temperature change must form them again from the costs
+  if (p->params_set && p->params.lambda_weight != params->lambda_weight) p->tile_packets_fresh = false;
   p->params = *params;
   p->params_set = true;
   p->inst_dirty = true;  // the per-problem window origins depend on the reach
@@ -907,7 +916,7 @@ extern "C" int mppi_planner_shift_u(mppi_planner* p, int k) {
   hipLaunchKernelGGL(k_shift_u, dim3(p->B), dim3(256), sizeof(float2) * (size_t)p->cfg.num_steps, p->stream, p->u,
                      p->cfg.num_steps, k);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  // (control path: no synchronisation -- every consumer of u is ordered behind this on the stream)
   return MPPI_OK;
 }
 
@@ -1540,7 +1549,10 @@ static int launch_apply(mppi_planner* p) {
   return MPPI_OK;
 }
 
-static int launch_update(mppi_planner* p, bool prof) {
+// `defer_exchange` (mppi_group_iterate_async): stop after this rank's packet; the caller issues the
+// all-gathers of all its devices inside one RCCL group and then launches k_apply on each
+static int launch_update(mppi_planner* p, bool prof, bool defer_exchange = false) {
+  if (defer_exchange) return launch_update_local(p, false);
   // (a communicator on a single rank is honoured too: it exercises the same path as N ranks)
   if (p->cfg.world_size == 1 && !p->comm) {
     TRY(launch_update_local(p, true));
@@ -1566,7 +1578,8 @@ static int launch_update(mppi_planner* p, bool prof) {
 // One iteration: {noise unless it was produced ahead, rollout (+ the next iteration's noise when
 // `want_next`), update}.  `have_noise`: noise_buf[noise_cur ^ 1] already holds this iteration's
 // noise; on return it says the same for the following iteration.
-static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_noise, bool want_next, bool prof) {
+static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_noise, bool want_next, bool prof,
+                            bool defer_exchange = false) {
   // (below ~4M rollout-steps the generator takes less than the ~12 us a cross-stream dependency costs)
   static const bool no_side_stream = getenv("MPPI_NO_SIDE_STREAM") != nullptr;  // developer switch
   // and above 8 rollout waves per CU the register file has no room for the generator's waves: it
@@ -1603,7 +1616,7 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
   }
   p->next_noise_wanted = false;
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[2], p->stream));
-  TRY(launch_update(p, prof));
+  TRY(launch_update(p, prof, defer_exchange));
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[5], p->stream));
   return MPPI_OK;
 }
@@ -1647,7 +1660,9 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
   // The noise of iteration k+1 does not depend on iteration k.  When the pipelined rollout
   // kernel runs, its spare workgroups generate it into the other half of the double buffer
   // (same launch, no extra dependency); otherwise it is generated in line.
-  const bool use_graph = p->graph_on && !p->profile_stages && p->cfg.world_size == 1 && !p->comm;
+  // (a sharded handle replays too: RCCL's all-gather is captured into the graph with the kernels;
+  //  without a communicator the exchange is host-staged and cannot be captured)
+  const bool use_graph = p->graph_on && !p->profile_stages && (p->cfg.world_size == 1 || p->comm);
   if (!use_graph) {
     // Every iteration, the last one of a call included, asks for its successor's noise: when the
     // rollout kernel can produce it on the side (spare workgroups, second stream) the next call --
@@ -2046,8 +2061,9 @@ extern "C" int mppi_planner_set_graph_replay(mppi_planner* p, int iterations_per
   REQUIRE(!enabled || (iterations_per_graph >= 2 && iterations_per_graph % 2 == 0 && iterations_per_graph <= 256),
           MPPI_ERR_INVALID, "iterations_per_graph must be 0 (off) or even in [2, 256], got %d",
           iterations_per_graph);
-  REQUIRE(!enabled || (p->cfg.world_size == 1 && !p->comm), MPPI_ERR_INVALID,
-          "graph replay is a single-GPU feature (the exchange is not captured)");
+  REQUIRE(!enabled || p->cfg.world_size == 1 || p->comm, MPPI_ERR_INVALID,
+          "graph replay of a sharded handle needs its RCCL communicator first (mppi_planner_comm_init): "
+          "a host-staged exchange cannot be captured");
   HIP_TRY(hipSetDevice(p->cfg.device));
   HIP_TRY(hipStreamSynchronize(p->stream));
   drop_graphs(p);
@@ -2086,6 +2102,101 @@ extern "C" int mppi_selftest_philox(int device, int* mismatches) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(mismatches, d, sizeof(int), hipMemcpyDeviceToHost));
   dev_free(d);
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_comm_count(mppi_planner* p, int* ranks) {
+  REQUIRE(p && ranks, MPPI_ERR_INVALID, "NULL argument");
+  *ranks = 0;
+  if (!p->comm) return MPPI_OK;
+  RCCL_TRY(g_rccl.CommCount(p->comm, ranks));
+  return MPPI_OK;
+}
+
+// ---- one process, several devices --------------------------------------------------------
+// A single control thread driving G shard handles (one per device): the communicators are created
+// inside one RCCL group, and every iteration issues the G all-gathers inside one group as well
+// (a lone blocking ncclCommInitRank / collective per device from one thread would deadlock).
+extern "C" int mppi_group_comm_init(mppi_planner** ps, int count) {
+  REQUIRE(ps && count >= 1, MPPI_ERR_INVALID, "bad handle array");
+  for (int g = 0; g < count; ++g) {
+    REQUIRE(ps[g], MPPI_ERR_INVALID, "NULL planner %d", g);
+    REQUIRE(!ps[g]->comm, MPPI_ERR_STATE, "planner %d already has a communicator", g);
+    REQUIRE(ps[g]->cfg.world_size == count && ps[g]->cfg.rank == g, MPPI_ERR_INVALID,
+            "planner %d is rank %d of %d; the group wants rank %d of %d", g, ps[g]->cfg.rank, ps[g]->cfg.world_size,
+            g, count);
+    for (int h = 0; h < g; ++h)
+      REQUIRE(ps[h]->cfg.device != ps[g]->cfg.device, MPPI_ERR_INVALID,
+              "planners %d and %d share device %d (RCCL wants one rank per device)", h, g, ps[g]->cfg.device);
+  }
+  TRY(rccl_load());
+  ncclUniqueId uid;
+  RCCL_TRY(g_rccl.GetUniqueId(&uid));
+  RCCL_TRY(g_rccl.GroupStart());
+  int rc = MPPI_OK;
+  for (int g = 0; g < count && rc == MPPI_OK; ++g) {
+    if (hipSetDevice(ps[g]->cfg.device) != hipSuccess) { rc = fail(MPPI_ERR_HIP, "hipSetDevice(%d) failed", ps[g]->cfg.device); break; }
+    ncclResult_t r = g_rccl.CommInitRank(&ps[g]->comm, count, uid, g);
+    if (r != ncclSuccess) rc = fail(MPPI_ERR_COMM, "ncclCommInitRank(rank %d) failed: %s", g, g_rccl.GetErrorString(r));
+  }
+  ncclResult_t end = g_rccl.GroupEnd();
+  if (rc == MPPI_OK && end != ncclSuccess) rc = fail(MPPI_ERR_COMM, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(end));
+  if (rc != MPPI_OK)
+    for (int g = 0; g < count; ++g) ps[g]->comm = nullptr;  // (whatever was created is leaked rather than half-used)
+  return rc;
+}
+
+// `iterations` x {per device: noise, rollout, shard packet; one group of all-gathers; per device:
+// apply}.  Asynchronous like mppi_planner_iterate_async: synchronise each handle afterwards.
+extern "C" int mppi_group_iterate_async(mppi_planner** ps, mppi_tdm** lins, mppi_tdm** angs, int count,
+                                        int iterations) {
+  REQUIRE(ps && lins && angs && count >= 1 && iterations >= 0, MPPI_ERR_INVALID, "bad arguments");
+  std::vector<DevParams> d((size_t)count);
+  std::vector<char> have((size_t)count);
+  for (int g = 0; g < count; ++g) {
+    mppi_planner* p = ps[g];
+    REQUIRE(p && p->comm, MPPI_ERR_STATE, "planner %d has no communicator (mppi_group_comm_init)", g);
+    REQUIRE(p->params_set, MPPI_ERR_STATE, "planner %d: params not set", g);
+    REQUIRE(!p->graph_on, MPPI_ERR_STATE, "graph replay and group iteration do not combine");
+    HIP_TRY(hipSetDevice(p->cfg.device));
+    TRY(check_tdms(p, lins[g], angs[g]));
+    TRY(ensure_packed(p, lins[g], angs[g]));
+    d[(size_t)g] = make_dev_params(p, lins[g], angs[g]);
+    have[(size_t)g] = p->primed;
+    HIP_TRY(hipEventRecord(p->ev_begin, p->stream));
+  }
+  for (int k = 0; k < iterations; ++k) {
+    for (int g = 0; g < count; ++g) {
+      HIP_TRY(hipSetDevice(ps[g]->cfg.device));
+      bool h = have[(size_t)g] != 0;
+      TRY(launch_iteration(ps[g], d[(size_t)g], h, true, false, /*defer_exchange=*/true));
+      have[(size_t)g] = h;
+    }
+    RCCL_TRY(g_rccl.GroupStart());
+    int rc = MPPI_OK;
+    for (int g = 0; g < count && rc == MPPI_OK; ++g) {
+      mppi_planner* p = ps[g];
+      const int len = p->B * packet_len(p->cfg.num_steps);
+      ncclResult_t r = g_rccl.AllGather(p->packets + (size_t)p->cfg.rank * len, p->packets, (size_t)len, ncclDouble,
+                                        p->comm, p->stream);
+      if (r != ncclSuccess) rc = fail(MPPI_ERR_COMM, "ncclAllGather(rank %d) failed: %s", g, g_rccl.GetErrorString(r));
+    }
+    ncclResult_t end = g_rccl.GroupEnd();
+    if (rc == MPPI_OK && end != ncclSuccess) rc = fail(MPPI_ERR_COMM, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(end));
+    TRY(rc);
+    for (int g = 0; g < count; ++g) {
+      HIP_TRY(hipSetDevice(ps[g]->cfg.device));
+      TRY(launch_apply(ps[g]));
+    }
+  }
+  for (int g = 0; g < count; ++g) {
+    mppi_planner* p = ps[g];
+    HIP_TRY(hipSetDevice(p->cfg.device));
+    p->primed = have[(size_t)g] != 0;
+    HIP_TRY(hipEventRecord(p->ev_end, p->stream));
+    p->elapsed_pending = true;
+    p->last_iterations = iterations;
+  }
   return MPPI_OK;
 }
 

@@ -397,6 +397,12 @@ class MPPI_Numba(object):
         assert len(unique_id) == _lib.COMM_ID_BYTES
         _lib.call("mppi_planner_comm_init", self._handle, C.c_char_p(bytes(unique_id)))
 
+    def comm_count(self):
+        """Ranks RCCL itself reports for this handle's communicator (0: none)."""
+        n = C.c_int(0)
+        _lib.call("mppi_planner_comm_count", self._handle, C.byref(n))
+        return int(n.value)
+
     def update_local(self):
         n = C.c_int(0)
         _lib.call("mppi_planner_packet_len", self._handle, C.byref(n))
@@ -418,3 +424,58 @@ def comm_unique_id():
     buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
     _lib.call("mppi_comm_unique_id", buf)
     return bytes(buf.raw)
+
+
+class MPPI_Group(object):
+    """One process, several GPUs: G shard planners (rank g on device g) driven by one control
+    thread (include/mppi_hip.h: mppi_group_comm_init / mppi_group_iterate_async).  Every device
+    holds its own copy of the maps (its own pair of TDMs).  The sharded problem is the one a
+    single MPPI_Numba with N control samples solves: the noise is keyed by the global sample
+    index and the packets are combined in rank order, so u is the same on every device.
+
+        cfgs = [copy of cfg with .device = g for g in range(G)]          # cfg.num_control_rollouts = N (global)
+        group = MPPI_Group(cfgs); group.setup(params, lin_tdms, ang_tdms); u = group.solve()
+    """
+
+    def __init__(self, cfgs):
+        world = len(cfgs)
+        self.planners = [MPPI_Numba(cfg, rank=g, world_size=world) for g, cfg in enumerate(cfgs)]
+        self.world_size = world
+        self._comm = False
+
+    def setup(self, mppi_params, lin_tdms, ang_tdms):
+        for p, lin, ang in zip(self.planners, lin_tdms, ang_tdms):
+            p.setup(mppi_params, lin, ang)
+        if not self._comm:
+            handles = (C.c_void_p * self.world_size)(*[p._handle for p in self.planners])
+            _lib.call("mppi_group_comm_init", handles, self.world_size)
+            self._comm = True
+
+    def _arrays(self):
+        mk = lambda hs: (C.c_void_p * self.world_size)(*hs)
+        return (mk([p._handle for p in self.planners]), mk([p.lin_tdm._handle for p in self.planners]),
+                mk([p.ang_tdm._handle for p in self.planners]))
+
+    def iterate_async(self, iterations):
+        for p in self.planners:
+            p.move_mppi_task_vars_to_device()
+        ps, lins, angs = self._arrays()
+        _lib.call("mppi_group_iterate_async", ps, lins, angs, self.world_size, int(iterations))
+
+    def synchronize(self):
+        for p in self.planners:
+            p.synchronize()
+
+    def solve(self):
+        """Sample the traction grids on every device, run params['num_opt'] iterations, return u."""
+        alpha = self.planners[0].params.get("alpha_dyn", 1.0) if self.planners[0].use_tdm else 1.0
+        for p in self.planners:
+            p.lin_tdm.sample_grids(alpha)
+            p.ang_tdm.sample_grids(alpha)
+        self.iterate_async(int(self.planners[0].params["num_opt"]))
+        self.synchronize()
+        return self.planners[0].u_cur_d.copy_to_host()
+
+    def shift_and_update(self, new_x0, u_cur, num_shifts=1):
+        for p in self.planners:
+            p.shift_and_update(new_x0, u_cur, num_shifts=num_shifts)

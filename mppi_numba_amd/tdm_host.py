@@ -83,7 +83,12 @@ def risk_traction_map(pmf_grid, bin_values_f32, bounds_f32, alpha):
     _, rows, cols = pmf_grid.shape
     target = cvar_traction(pmf_grid, bin_values_f32, alpha)
     span = bounds_f32[1] - bounds_f32[0]
-    scaled = 100 * np.asarray((target - bounds_f32[0]) / span)
+    if alpha == 1.0:
+        # the reference scales the mean as (100*(mean - lo))/range (terrain.py:476-478) but the
+        # CVaR as 100*((cvar - lo)/range) (terrain.py:488-490): after truncation they can differ by one
+        scaled = 100 * (target - bounds_f32[0]) / span
+    else:
+        scaled = 100 * np.asarray((target - bounds_f32[0]) / span)
     return np.reshape(scaled, (1, rows, cols)).astype(np.int8)
 
 

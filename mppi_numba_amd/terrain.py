@@ -8,16 +8,18 @@ attributes; what used to be numba device arrays and the
 `sample_grids_numba` kernel (terrain.py:633-695) now lives behind the C ABI
 (include/mppi_hip.h: mppi_tdm_*).
 
-PMF grids are int8 (num_bins, rows, cols) whose bins sum to 100 per cell.  The
-map preprocessing that the reference does with numpy on the host stays numpy on
-the host here (it runs once per map change, not per control step):
+PMF grids are int8 (num_bins, rows, cols) whose bins sum to 100 per cell.  The map
+preprocessing the reference does with numpy on the host,
   * use_tdm: keep the PMF as given;
   * use_det_dynamics: all mass in the bin closest above the CVaR_alpha traction
     (terrain.py:408-452);
   * use_nom_dynamics_with_speed_map: nominal traction for the dynamics plus an
     int8 map of CVaR_alpha traction that scales the time cost (terrain.py:455-495);
-then a ring of zero-traction cells, ceil(max_speed_padding*dt/res) wide, is
-added so that rollouts can never leave the allocated map (terrain.py:511-583).
+then a ring of zero-traction cells, ceil(max_speed_padding*dt/res) wide, so that rollouts
+can never leave the allocated map (terrain.py:511-583),
+runs by default on the DEVICE (`Config(map_preprocessing="device")`, one HIP kernel,
+csrc/map_kernels.h, bit-identical results); `Config(map_preprocessing="host")` selects the
+numpy restatement in tdm_host.py, which is also what `set_TDM_from_semantic_grid` uses.
 """
 import copy
 import ctypes as C
@@ -273,7 +275,7 @@ class TDM_Numba(object):
         assert self.bin_values[0] == 0, "Assume minimum bin value is 0 for now"
         assert self.bin_values_bounds[0] == 0, "Assume minimum traction is 0 for now"
 
-        if getattr(self.cfg, "map_preprocessing", "host") == "device":
+        if getattr(self.cfg, "map_preprocessing", "device") == "device":
             return self._set_TDM_from_PMF_grid_on_device(pmf_grid, alpha, obstacle_map, unknown_map,
                                                          num_rows, num_cols, res)
 
@@ -355,8 +357,17 @@ class TDM_Numba(object):
                   float(alpha), _lib.ptr(table, C.c_int8), lo, ratio,
                   None if masks[0] is None else _lib.ptr(masks[0], C.c_int8),
                   None if masks[1] is None else _lib.ptr(masks[1], C.c_int8), C.byref(bad))
-        if bad.value:
-            print("WARNING: the provided PMF has {} columns that don't sum up to 100".format(bad.value))
+        if bad.value or vr < num_rows or vc < num_cols:
+            # rare path: the same warnings, under the same mode conditions and with the same cell
+            # indices, as the host path above prints (the kernel only counts the offending columns
+            # inside the crop)
+            col_sums = np.sum(pmf_grid, axis=0)
+            if (col_sums != 100).any():
+                if self.use_det_dynamics or self.use_nom_dynamics_with_speed_map:
+                    print("WARNING: the provided PMF has columns that don't sum up to 100: {}".format(
+                        np.argwhere(col_sums != 100)))
+                else:
+                    print("WARNING: some PMF columns do not sum to 100: {}".format(np.argwhere(col_sums != 100)))
         bins, rows_p, cols_p = self.num_pmf_bins, vr + 2 * pad, vc + 2 * pad
         handle = self._handle
 

@@ -276,15 +276,15 @@ def gen_rng():
 
 def _det_like(mode_kw, n_rollouts=48, seed_world=3, alpha=0.4, num_opt=2,
               goal=(2.8, 4.2), n_solves=2, extra_params=None, res=0.5, dt=0.1, horizon=2.0,
-              x0=(1.6, 2.1, 0.3), bounds=None):
+              x0=(1.6, 2.1, 0.3), bounds=None, world_kw=None, max_map_dim=(30, 32)):
     rng = np.random.default_rng(seed_world + SEED_OFFSET)
-    pmf, obstacle, unknown, tdm_dict = _world(rng, res=res)
+    pmf, obstacle, unknown, tdm_dict = _world(rng, res=res, **(world_kw or {}))
     tdm_dict["det_dynamics_cvar_alpha"] = alpha
     if bounds is not None:
         tdm_dict["bin_values_bounds"] = bounds
     cfg = _make_cfg(n_rollouts, T=horizon, dt=dt, num_grid_samples=8,
                     max_speed_padding=3.0, tdm_sample_thread_dim=(4, 4),
-                    num_vis_state_rollouts=5, max_map_dim=(30, 32), seed=1, **mode_kw)
+                    num_vis_state_rollouts=5, max_map_dim=max_map_dim, seed=1, **mode_kw)
     lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
     lin.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
     ang_pmf = _random_pmf(rng, pmf.shape[0], pmf.shape[1], pmf.shape[2])
@@ -329,6 +329,15 @@ def gen_speedmap():
 def gen_speedmap_mean():
     return _det_like(dict(use_nom_dynamics_with_speed_map=True), alpha=1.0,
                      num_opt=1, n_solves=1, seed_world=8)
+
+
+def gen_speedmap_mean_bounds():
+    # mean risk map (terrain.py:476-478 scales it as (100*(mean-lo))/range, the CVaR branch as
+    # 100*((cvar-lo)/range)) with traction bounds away from (0, 1) on a map large enough for the
+    # two operation orders to truncate differently in some cells
+    return _det_like(dict(use_nom_dynamics_with_speed_map=True), alpha=1.0, num_opt=1, n_solves=1,
+                     seed_world=9, bounds=(0.0, 1.7), world_kw=dict(rows=44, cols=52), max_map_dim=(60, 68),
+                     x0=(9.6, 8.1, 0.3), goal=(14.0, 12.5))
 
 
 # Units and ranges away from the notebooks' defaults: a resolution that is not a power of two
@@ -518,6 +527,7 @@ FIXTURES = {
     "det_mean": gen_det_mean,
     "speedmap_cvar": gen_speedmap,
     "speedmap_mean": gen_speedmap_mean,
+    "speedmap_mean_bounds": gen_speedmap_mean_bounds,
     "det_odd_units": gen_det_odd_units,
     "speedmap_odd_units": gen_speedmap_odd_units,
     "tdm_cvar": gen_tdm_cvar,

@@ -105,6 +105,46 @@ def test_batch_matches_single_problem_handles_and_oracle(workload, n, t_steps, m
         assert (np.abs(u_out[b] - u_ref) / np.array([3.0, np.pi])).max() <= 1e-5
 
 
+def test_c5_full_size_vs_oracle():
+    """BASELINE configs[4] at full size: 64 problems x N=4096, T=100 in one launch (the objects
+    bench.py --workload c5 times), every problem against the CPU restatement of
+    mppi.py:916-1009 and 1113-1191."""
+    from mppi_numba_amd.batch import MPPI_Batch
+    w = bench.WORKLOADS["c5"]
+    n, t_steps, count = w["n"], w["t"], w["problems"]
+    cfg, lin, ang, params = make_world("c5", n, t_steps)
+    x0s, goals = bench.batch_problems(count, np.random.default_rng(100))
+    batch = MPPI_Batch(cfg, count)
+    batch.setup(params, lin, ang, x0s, goals)
+    batch.solve()
+    batch.iterate_async(3)
+    batch.synchronize()
+    assert batch.last_rollout_kernel().startswith("k_rollout_fused"), batch.last_rollout_kernel()
+    assert "problems=%d" % count in batch.last_rollout_kernel()
+    u_in = batch.u_cur_d.copy_to_host()
+    batch.sample_noise()
+    noise = batch.noise_samples_d.copy_to_host().reshape(count, n, t_steps, 2)
+    batch.rollout()
+    costs = batch.costs_d.copy_to_host()
+    batch.update()
+    u_out = batch.u_cur_d.copy_to_host()
+    grids = (lin.sample_grid_batch_d.copy_to_host(), ang.sample_grid_batch_d.copy_to_host(),
+             lin.obstacle_map_d.copy_to_host(), lin.unknown_map_d.copy_to_host())
+    exact, worst_u = [], 0.0
+    for b in range(count):
+        p = dict(params)
+        p["x0"], p["xgoal"] = x0s[b], goals[b]
+        ref = O.rollout_det(oracle_params(p, lin, ang), *grids, noise[b], u_in[b])
+        ulps = ulp_diff_f32(costs[b], ref)
+        exact.append((ulps == 0).mean())
+        assert exact[-1] >= 0.999, "problem %d: exact fraction %.5f" % (b, exact[-1])
+        assert (np.abs(costs[b] - ref) / np.abs(ref)).max() < 1e-6
+        _, u_ref, _ = O.update_useq(p["lambda_weight"], ref, noise[b], p["vrange"], p["wrange"], u_in[b])
+        worst_u = max(worst_u, float((np.abs(u_out[b] - u_ref) / np.array([3.0, np.pi])).max()))
+    print("\nc5 64 x 4096: exact costs min %.5f, max |du|/range %.3e" % (min(exact), worst_u))
+    assert worst_u <= 1e-5
+
+
 def test_one_problem_through_the_instance_path_equals_the_classic_path():
     """count = 1 takes the per-problem device parameters; params['x0'] the by-value ones."""
     from mppi_numba_amd.batch import MPPI_Batch

@@ -78,7 +78,7 @@ def test_cropping_and_missing_masks_and_bad_columns(capsys):
     assert np.array_equal(host.pmf_grid[:, :dev.pmf_grid.shape[1], :dev.pmf_grid.shape[2]], dev.pmf_grid)
 
 
-@pytest.mark.parametrize("name", ["det_cvar", "det_mean", "speedmap_cvar", "speedmap_mean", "tdm_cvar",
+@pytest.mark.parametrize("name", ["det_cvar", "det_mean", "speedmap_cvar", "speedmap_mean", "speedmap_mean_bounds", "tdm_cvar",
                                   "det_odd_units", "speedmap_odd_units", "tdm_odd_units"])
 def test_device_preprocessing_reproduces_the_reference_fixtures(name):
     """The maps the REFERENCE built from the fixture's raw PMF (its padded PMF, masks, risk

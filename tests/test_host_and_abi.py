@@ -103,7 +103,7 @@ def test_config_mirrors_reference_clamps(capsys):
     capsys.readouterr()
 
 
-MODES = {"det_cvar": "det", "det_mean": "det", "speedmap_cvar": "speed", "speedmap_mean": "speed",
+MODES = {"det_cvar": "det", "det_mean": "det", "speedmap_cvar": "speed", "speedmap_mean": "speed", "speedmap_mean_bounds": "speed",
          "tdm_cvar": "tdm", "det_odd_units": "det", "speedmap_odd_units": "speed", "tdm_odd_units": "tdm"}
 
 
@@ -192,3 +192,33 @@ def test_semantic_grid_preprocessing_vs_reference(name):
     table = tdm_host.bin_table(tdm_host.as_device_float(values), tdm_host.as_device_float(np.array([0.0, 1.0])))
     assert table[3] == 35
     assert set(np.unique(g["lin_sample_grid"])) <= set(table.tolist())
+
+
+def test_mean_risk_map_scales_like_the_reference_for_any_bounds():
+    """terrain.py:476-478 scales the MEAN risk traction as (100*(mean - lo))/range, terrain.py:488-490
+    the CVaR one as 100*((cvar - lo)/range): after the int8 truncation the two orders differ in
+    a few cells per thousand once the bounds are not (0, 1).  One- and two-hot PMFs, decimal
+    upper bounds (where 100*mean/hi lands on integers)."""
+    from mppi_numba_amd import tdm_host
+    rng = np.random.default_rng(17)
+    bins, rows, cols = 6, 120, 200
+    bin_values = np.linspace(0.0, 1.0, bins).astype(np.float32)
+    differing = 0
+    for trial in range(8):
+        pmf = np.zeros((bins, rows * cols), dtype=np.int8)
+        first = rng.integers(0, bins, rows * cols)
+        second = rng.integers(0, bins, rows * cols)
+        share = rng.integers(0, 101, rows * cols)
+        np.add.at(pmf, (first, np.arange(rows * cols)), share.astype(np.int8))
+        np.add.at(pmf, (second, np.arange(rows * cols)), (100 - share).astype(np.int8))
+        pmf = pmf.reshape(bins, rows, cols)
+        bounds = np.array([0.0, (0.3, 0.5, 0.8, 1.2, 1.7, 2.0, 2.5, 3.0)[trial]], dtype=np.float32)
+        # the reference's expressions, literally (float64 cumsums, float32 bounds)
+        weighted = np.cumsum(0.01 * pmf.astype(float) * bin_values.reshape((-1, 1, 1)), axis=0)
+        traction_range = bounds[1] - bounds[0]
+        want_mean = np.reshape(100 * (weighted[-1] - bounds[0]) / traction_range, (1, rows, cols)).astype(np.int8)
+        got_mean = tdm_host.risk_traction_map(pmf, bin_values, bounds, 1.0)
+        assert np.array_equal(got_mean, want_mean)
+        other_order = np.reshape(100 * np.asarray((weighted[-1] - bounds[0]) / traction_range), (1, rows, cols)).astype(np.int8)
+        differing += int((other_order != want_mean).sum())
+    assert differing > 0  # the sweep does exercise the distinction

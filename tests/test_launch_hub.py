@@ -1,0 +1,93 @@
+"""The framework-free launcher bench.py uses for `--gpus N`: rank spawning, the rendezvous
+file and the TCP hub (mppi_numba_amd/launch.py), with real processes on CPU; and the sharded
+update arithmetic carried over it (the exchange RCCL's all-gather does on the GPUs)."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import numpy as np
+    from mppi_numba_amd import launch
+    rank, local_rank, world = launch.rank_from_env()
+    hub = launch.Hub(rank, world)
+    uid = hub.broadcast(b"id-from-rank-0" if rank == 0 else None)
+    got = hub.all_gather({"rank": rank, "pid": os.getpid()})
+    hub.barrier()
+    slowest = hub.all_max(0.25 * (rank + 1))
+    # the sharded update (update_kernels.h): packets {beta_g, den_g, num_g[T][2]} combined in rank order
+    rng = np.random.default_rng(7)
+    n, t, lam = 96 * world, 5, 0.7
+    costs, eps = rng.uniform(3, 40, n), rng.normal(size=(n, t, 2))
+    mine = slice(rank * n // world, (rank + 1) * n // world)
+    beta_g = costs[mine].min()
+    w_g = np.exp(-(costs[mine] - beta_g) / lam)
+    packet = np.concatenate(([beta_g, w_g.sum()], np.einsum("n,ntc->tc", w_g, eps[mine]).ravel()))
+    packets = np.stack(hub.all_gather(packet))
+    beta = packets[:, 0].min()
+    scale = np.exp(-(packets[:, 0] - beta) / lam)
+    du = (scale[:, None] * packets[:, 2:]).sum(0) / (scale * packets[:, 1]).sum()
+    w = np.exp(-(costs - costs.min()) / lam)
+    want = np.einsum("n,ntc->tc", w / w.sum(), eps).ravel()
+    if rank == 0:
+        print(json.dumps({"uid": uid.decode(), "ranks": [g["rank"] for g in got], "pids": len({g["pid"] for g in got}),
+                          "slowest": slowest, "err": float(np.abs(du - want).max())}))
+    hub.close()
+    """) % ROOT
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_spawned_ranks_meet_at_the_hub(world, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    driver = ("import sys; sys.path.insert(0, %r)\n"
+              "from mppi_numba_amd import launch\n"
+              "sys.exit(launch.spawn_ranks(%d, [sys.executable, %r], timeout=120))\n" % (ROOT, world, str(script)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MPPI_RDZV_FILE")}
+    out = subprocess.run([sys.executable, "-c", driver], capture_output=True, text=True, timeout=180, env=env)
+    assert out.returncode == 0, out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["uid"] == "id-from-rank-0" and res["ranks"] == list(range(world)) and res["pids"] == world
+    assert res["slowest"] == 0.25 * world
+    assert res["err"] < 1e-12
+
+
+def test_launcher_environment_of_torch_distributed_run(tmp_path):
+    """The contract's launch line (`python -m torch.distributed.run --nproc-per-node N ...`) sets
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT and makes all workers children of one agent
+    process: the rendezvous file name derived from (parent pid, port) is shared and the hub
+    forms without MPPI_RDZV_FILE."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MPPI_RDZV_FILE")}
+    agent = textwrap.dedent("""
+        import os, subprocess, sys
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29431")
+            procs.append(subprocess.Popen([sys.executable, %r], env=env))
+        sys.exit(max(p.wait() for p in procs))
+        """) % str(script)
+    out = subprocess.run([sys.executable, "-c", agent], capture_output=True, text=True, timeout=180, env=env)
+    assert out.returncode == 0, out.stderr
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["ranks"] == [0, 1] and res["err"] < 1e-12
+
+
+def test_a_dying_rank_takes_the_job_down(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(3)\ntime.sleep(60)\n")
+    driver = ("import sys; sys.path.insert(0, %r)\n"
+              "from mppi_numba_amd import launch\n"
+              "sys.exit(launch.spawn_ranks(2, [sys.executable, %r], timeout=120))\n" % (ROOT, str(script)))
+    out = subprocess.run([sys.executable, "-c", driver], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 3
+    assert "rank(s) [1] failed" in out.stderr

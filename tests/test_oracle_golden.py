@@ -12,7 +12,7 @@ import pytest
 from helpers import golden, iterations, params_from_golden, ulp_diff_f32
 from oracle import oracle as O
 
-MAP_FIXTURES = ["det_cvar", "det_mean", "speedmap_cvar", "speedmap_mean", "tdm_cvar",
+MAP_FIXTURES = ["det_cvar", "det_mean", "speedmap_cvar", "speedmap_mean", "speedmap_mean_bounds", "tdm_cvar",
                 "tdm_mean_alpha_dyn", "tdm_cvar_odd", "tdm_oversized_mean",
                 # res = 0.3, dt = 0.05, reverse driving, |theta0| of several turns, bounds (0, 1.2)
                 "det_odd_units", "speedmap_odd_units", "tdm_odd_units",
