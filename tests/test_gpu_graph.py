@@ -127,8 +127,10 @@ def test_batched_handle_keeps_its_graph_across_new_start_states():
     assert stats["captures"] <= 2 and stats["replays"] >= 8, stats
 
 
-def test_graph_replay_refused_for_sharded_handles():
+def test_graph_replay_of_a_sharded_handle_needs_its_communicator():
+    """A host-staged exchange cannot be captured; with an RCCL communicator the all-gather is
+    part of the graph (tests/test_gpu_multi.py)."""
     from mppi_numba_amd import _lib
     _, _, _, _, half, _ = build("c2", 1024, rank=0, world=2)
-    with pytest.raises(_lib.MppiError, match="single-GPU"):
+    with pytest.raises(_lib.MppiError, match="communicator"):
         half.set_graph_replay(True)
