@@ -267,7 +267,15 @@ int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity)
 
 /* diagnostic: compares the library's single-block Philox4x32-10 with rocRAND's engine on
  * 65536 (seed, subsequence, offset) triples; *mismatches must come back 0 */
+/* developer switches for the parity tests, which pin every rollout kernel variant by name
+ * (mppi_planner_describe_last_rollout): results never depend on them */
+#define MPPI_DEBUG_NO_SPEC_KERNEL 1  /* latency regime: k_rollout_pipe instead of k_rollout_spec */
+#define MPPI_DEBUG_NO_SPECULATION 2  /* k_rollout_spec on its exact schedule from the first step */
+int mppi_planner_set_debug_flags(mppi_planner* p, int flags);
 int mppi_selftest_philox(int device, int* mismatches);
+/* developer instrumentation: in-kernel clock stamps of a -DMPPI_STAMPS build
+ * (csrc/Makefile target `stamps`, tools/stamp_timeline.py); MPPI_ERR_STATE otherwise */
+int mppi_debug_read_stamps(unsigned long long* out, int count, int clear);
 /* hipGraph replay of the iteration loop (off by default).  A sharded handle needs its RCCL
  * communicator first: the all-gather is captured with the kernels.
  * iterations_per_graph: 0 = off, else an even number (the noise double buffer must come

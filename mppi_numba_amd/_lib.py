@@ -18,6 +18,7 @@ RNG_PHILOX, RNG_XOROSHIRO = 0, 1
 MATH_EXACT, MATH_FAST = 0, 1
 COMM_ID_BYTES = 128
 PREP_TDM, PREP_DET, PREP_SPEED = 0, 1, 2
+DEBUG_NO_SPEC_KERNEL, DEBUG_NO_SPECULATION = 1, 2
 ABI_VERSION = 1
 
 
@@ -117,7 +118,9 @@ SIGNATURES = {
     "mppi_planner_stage_times": [_vp, _f32p],
     "mppi_planner_last_elapsed_ms": [_vp, _f32p],
     "mppi_planner_describe_last_rollout": [_vp, C.c_char_p, C.c_int],
+    "mppi_planner_set_debug_flags": [_vp, C.c_int],
     "mppi_selftest_philox": [C.c_int, C.POINTER(C.c_int)],
+    "mppi_debug_read_stamps": [C.POINTER(C.c_ulonglong), C.c_int, C.c_int],
     "mppi_planner_graph_probe": [_vp, _vp, _vp, C.c_int, C.c_int, _f32p, _f32p],
     "mppi_planner_set_graph_replay": [_vp, C.c_int],
     "mppi_planner_graph_stats": [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)],

@@ -15,6 +15,21 @@
 
 namespace mppi {
 
+// Developer instrumentation (tools/stamp_timeline.py): -DMPPI_STAMPS builds a library whose
+// kernels record the shader clock (s_memtime) of lane 0 of chosen waves at chosen points into
+// g_stamps; mppi_debug_read_stamps() copies them out.  Compiled out of the product build.
+#ifdef MPPI_STAMPS
+__device__ unsigned long long g_stamps[4096];
+#define MPPI_STAMP(cond, slot)                                                                  \
+  do {                                                                                          \
+    if ((cond) && (threadIdx.x & 63) == 0) g_stamps[(slot)] = __builtin_readcyclecounter();     \
+  } while (0)
+#else
+#define MPPI_STAMP(cond, slot) \
+  do {                         \
+  } while (0)
+#endif
+
 // Tile-major layout of per-(step, rollout) arrays (noise, control-cost products):
 // the T x 64 block of every 64 consecutive rollouts is contiguous, so that the wave
 // integrating those rollouts walks one ~T*512-byte run (one page, one DRAM row
@@ -118,6 +133,30 @@ __device__ __forceinline__ double fma3(double a, double b, double c) {
 // FMA3: use fma3 for the Horner steps.  Measured per kernel (profiles/r01_ablation.md): the CVaR
 // kernel gains 10 %; the pipelined and the throughput kernel lose 2-8 % (the opaque asm costs
 // the scheduler more than the copies cost those loops), so they keep the compiler's choice.
+// the two halves of rotate_sincos_f64 below, for callers that evaluate the polynomials of several
+// steps side by side (independent instruction streams) before walking the rotation chain
+__device__ __forceinline__ void sincos_increment_f64(double delta, double& sd, double& cd) {
+  const double z = delta * delta;
+  double ps = fma(z, 1.6059043836821613e-10, -2.5052108385441720e-08);  // 1/13!, -1/11!
+  ps = fma(z, ps, 2.7557319223985893e-06);                               // 1/9!
+  ps = fma(z, ps, -1.9841269841269841e-04);                              // -1/7!
+  ps = fma(z, ps, 8.3333333333333332e-03);                               // 1/5!
+  ps = fma(z, ps, -1.6666666666666666e-01);                              // -1/3!
+  sd = fma(delta * z, ps, delta);
+  double pc = fma(z, 2.0876756987868100e-09, -2.7557319223985888e-07);   // 1/12!, -1/10!
+  pc = fma(z, pc, 2.4801587301587302e-05);                               // 1/8!
+  pc = fma(z, pc, -1.3888888888888889e-03);                              // -1/6!
+  pc = fma(z, pc, 4.1666666666666664e-02);                               // 1/4!
+  pc = fma(z, pc, -0.5);
+  cd = fma(z, pc, 1.0);
+}
+__device__ __forceinline__ void apply_rotation_f64(double sd, double cd, double& s, double& c) {
+  const double c2 = fma(c, cd, -(s * sd));
+  const double s2 = fma(s, cd, c * sd);
+  c = c2;
+  s = s2;
+}
+
 template <bool FMA3 = false>
 __device__ __forceinline__ void rotate_sincos_f64(double delta, double& s, double& c) {
   auto step = [](double a, double b, double k) { return FMA3 ? fma3(a, b, k) : fma(a, b, k); };
@@ -171,16 +210,45 @@ __device__ __forceinline__ float ordered_to_float(uint32_t k) {
   return __uint_as_float(b);
 }
 
-// 64-lane butterfly reductions (wave64; all lanes end with the result)
+// 64-lane reductions (wave64; all lanes end with the result) without LDS traffic: four DPP steps
+// inside every row of 16 lanes (xor 1, xor 2, half-row mirror, row mirror), then the four row
+// results through v_readlane.  (__shfl_xor is ds_bpermute: ~100 dependent cycles per step, six
+// steps -- measured 4.2k cycles for the three float64 sums of the update kernel's epilogue.)
+// Fixed order: deterministic, the same on every run and in every kernel.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+
 __device__ __forceinline__ float wave_min_f32(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
-  return v;
+  v = fminf(v, dpp_f32<kDppXor1>(v));
+  v = fminf(v, dpp_f32<kDppXor2>(v));
+  v = fminf(v, dpp_f32<kDppHalfMirror>(v));
+  v = fminf(v, dpp_f32<kDppMirror>(v));
+  const int b = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+  return fminf(fminf(r0, r1), fminf(r2, r3));
 }
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_f64<kDppXor1>(v);
+  v += dpp_f64<kDppXor2>(v);
+  v += dpp_f64<kDppHalfMirror>(v);
+  v += dpp_f64<kDppMirror>(v);
+  const long long b = __double_as_longlong(v);
+  auto row = [&](int lane) {
+    const int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+  };
+  return ((row(0) + row(16)) + row(32)) + row(48);
 }
 
 }  // namespace mppi

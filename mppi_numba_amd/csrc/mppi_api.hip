@@ -19,6 +19,7 @@
 
 #include "rng_kernels.h"
 #include "rollout_kernels.h"
+#include "rollout_spec_kernel.h"
 #include "map_kernels.h"
 #include "update_kernels.h"
 
@@ -612,6 +613,7 @@ struct mppi_planner {
   std::vector<unsigned char> graph_sig[2];  // everything the captured launches took by value
   long graph_replays = 0, graph_captures = 0;
   std::string last_rollout;        // which rollout kernel variant the last launch used (diagnostic)
+  int debug_flags = 0;             // mppi_planner_set_debug_flags (tests pin every kernel variant through it)
   bool next_noise_wanted = false;  // the coming rollout launch should also generate noise_buf[cur^1]
   bool next_noise_done = false;    // ... and it did
   bool noise_on_side_stream = false;  // the noise produced ahead is still in flight on noise_stream
@@ -730,9 +732,11 @@ static int planner_alloc(mppi_planner* p) {
   HIP_TRY(hipEventCreate(&p->ev_end));
   for (auto& e : p->ev_stage) HIP_TRY(hipEventCreate(&e));
   const size_t n_tiled = (size_t)ceil_div((long)N, 64) * 64;  // tile-major arrays cover whole tiles
+  // (+ 8 chunks of 8 rows: k_rollout_spec prefetches rows past the horizon of the last tile unclamped)
+  const size_t noise_pad = 8 * 8 * 64;
   for (int b = 0; b < 2; ++b) {
-    TRY(dev_alloc(&p->noise_buf[b], n_tiled * T));
-    HIP_TRY(hipMemsetAsync(p->noise_buf[b], 0, n_tiled * T * sizeof(float2), p->stream));
+    TRY(dev_alloc(&p->noise_buf[b], n_tiled * T + noise_pad));
+    HIP_TRY(hipMemsetAsync(p->noise_buf[b], 0, (n_tiled * T + noise_pad) * sizeof(float2), p->stream));
   }
   p->noise = p->noise_buf[0];
   TRY(dev_alloc(&p->staging, N * T));
@@ -987,6 +991,9 @@ static DevParams make_dev_params(const mppi_planner* p, const mppi_tdm* lin, con
   d.v_post_den = (double)a.v_post_rollout + 1e-6;
   if (lin) { d.lin_lo = lin->lo; d.lin_ratio = lin->ratio; d.rows = lin->rows; d.cols = lin->cols; }
   if (ang) { d.ang_lo = ang->lo; d.ang_ratio = ang->ratio; }
+  d.lin_zero_byte = -1;
+  for (int b = 0; b < 128 && lin; ++b)
+    if (std::fma(d.lin_ratio, (double)b, d.lin_lo) == 0.0) { d.lin_zero_byte = b; break; }
   d.lin_max_byte = lin ? tdm_max_byte(lin) : 0;
   d.ang_max_byte = ang ? tdm_max_byte(ang) : 0;
   d.s0sq = (double)a.u_std[0] * (double)a.u_std[0];
@@ -1174,6 +1181,8 @@ static bool plan_lds_window(mppi_planner* p, DevParams& d, size_t* lds_bytes) {
     // batched handle: one window SIZE for all problems (the full reach square, clipped to the
     // map size), one ORIGIN per problem, shifted inwards at the map border
     for (BatchInst& I : p->inst_host) I.win_r0 = I.win_c0 = 0;
+    d.win_step_cells = std::isfinite(reach_m) ? (float)((double)a.dt * vmax * trmax / (double)a.res) : 0.0f;
+    d.win_progressive = std::isfinite(reach_m) ? 1 : 0;
     if (std::isfinite(reach_m)) {
       long reach = (long)std::ceil(reach_m / (double)a.res) + 2;
       long wr = std::min((long)d.rows, 2 * reach + 1);
@@ -1207,6 +1216,10 @@ static bool plan_lds_window(mppi_planner* p, DevParams& d, size_t* lds_bytes) {
     c1 = std::min((long)p->pitch16, (std::min((long)d.cols, xi0 + reach + 1) + 7) / 8 * 8);
     if (r1 > r0 && c1 > c0) bytes = (size_t)(r1 - r0) * (size_t)(c1 - c0) * cell_bytes;
   }
+  // (either way the rollouts spread at most step_cells per step: k_rollout_spec copies the window in
+  //  bands of rows as they go)
+  d.win_step_cells = std::isfinite(reach_m) ? (float)((double)a.dt * vmax * trmax / (double)a.res) : 0.0f;
+  d.win_progressive = std::isfinite(reach_m) ? 1 : 0;
   if (bytes < whole) {  // the reach window is smaller: less to copy, more LDS left
     if (head + bytes > budget) return false;
     d.win_r0 = (int)r0; d.win_c0 = (int)c0; d.win_rows = (int)(r1 - r0); d.win_cols = (int)(c1 - c0);
@@ -1274,6 +1287,83 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         rot_ok = EXACT && BOUNDED && std::isfinite(dmax) && dmax <= 0.36 && T <= 2000;
         int res_exp = 0;
         pow2res = std::frexp((double)a.res, &res_exp) == 0.5;  // res == 2^k exactly
+      }
+      static const bool no_spec = getenv("MPPI_NO_SPEC") != nullptr;  // developer switch (ablation)
+      if (have_window && rot_ok && !no_pipe && !no_spec && !(p->debug_flags & MPPI_DEBUG_NO_SPEC_KERNEL)) {
+        // speculative 4-wave pipeline (rollout_spec_kernel.h): same regime as the pipelined kernel below
+        const size_t map_bytes = lds_win - sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);
+        // (this kernel pads the staged controls to a multiple of 8 steps)
+        const size_t Tp = ((size_t)T + 7) & ~(size_t)7;
+        const size_t lds_win = map_bytes + sizeof(double2) * (Tp + Tp / 2);
+        int tiles_wg = ceil_div(ceil_div(N, 64), p->num_cus);
+        if (tiles_wg < 1) tiles_wg = 1;
+        if (tiles_wg > 3) tiles_wg = 3;  // (three tiles per CU: the pipelined kernel below)
+        if (p->inst_set) while (p->inst_tiles % tiles_wg != 0) --tiles_wg;
+        const size_t budget = (size_t)p->lds_per_cu - 1024;
+        auto ring_bytes = [&](int chunk) {
+          const size_t per_tile = chunk == 8 ? SpecRing<8>::kBytesPerTile : chunk == 4 ? SpecRing<4>::kBytesPerTile
+                                                                                      : SpecRing<2>::kBytesPerTile;
+          return (size_t)tiles_wg * per_tile + 16;
+        };
+        int chunk = 0;
+        for (;;) {
+          for (int cnd : {8, 4, 2})
+            if (lds_win + ring_bytes(cnd) <= budget) { chunk = cnd; break; }
+          if (chunk > 0 || tiles_wg == 1) break;
+          --tiles_wg;
+          if (p->inst_set) while (p->inst_tiles % tiles_wg != 0) --tiles_wg;
+        }
+        const bool latency_regime = tiles_wg <= 2 && ceil_div(ceil_div(N, 64), tiles_wg) <= p->num_cus;
+        if (chunk > 0 && latency_regime) {
+          // (rows padded to whole chunks: the cost wave reads them at immediate offsets)
+          const size_t cc_bytes = (size_t)tiles_wg * ceil_div(T, chunk) * chunk * 64 * sizeof(double);
+          const bool cc_lds = lds_win + ring_bytes(chunk) + cc_bytes <= budget;
+          const size_t lds_total = lds_win + ring_bytes(chunk) + (cc_lds ? cc_bytes : 0);
+          const int block = 256 * tiles_wg;
+          const int grid = ceil_div(N, 64 * tiles_wg);
+          NoiseJob next_job;
+          memset(&next_job, 0, sizeof(next_job));
+          int extra = 0;
+          static const bool no_fused_noise = getenv("MPPI_NO_FUSED_NOISE") != nullptr;  // developer switch
+          if (p->next_noise_wanted && grid < p->num_cus && !no_fused_noise) {  // (no spare CU otherwise: in line)
+            extra = p->num_cus - grid;
+            next_job = make_noise_job(p, p->noise_buf[p->noise_cur ^ 1]);
+            p->next_noise_done = true;
+          }
+          if (!cc_lds && !p->cc_scratch) TRY(dev_alloc(&p->cc_scratch, (size_t)ceil_div(N, 64) * 64 * T));
+          const int speculate = (p->debug_flags & MPPI_DEBUG_NO_SPECULATION) ? 0 : 1;
+#define MPPI_LAUNCH_SPEC(CH, P2, CL)                                                                   \
+  do {                                                                                                \
+    auto kern = tiles_wg == 1 ? k_rollout_spec<CH, P2, CL, 1> : k_rollout_spec<CH, P2, CL, 2>;        \
+    if (lds_total > 64 * 1024)                                                                        \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));       \
+    hipLaunchKernelGGL(kern, dim3(grid + extra), dim3(block), lds_total, p->stream, d, p->cells16,    \
+                       p->noise, p->u, p->costs, p->w_rel, p->tile_beta, p->cc_scratch,                \
+                       (int)map_bytes, grid, speculate, next_job);                                     \
+  } while (0)
+#define MPPI_LAUNCH_SPEC_C(P2, CL)            \
+  do {                                        \
+    if (chunk == 8) MPPI_LAUNCH_SPEC(8, P2, CL);      \
+    else if (chunk == 4) MPPI_LAUNCH_SPEC(4, P2, CL); \
+    else MPPI_LAUNCH_SPEC(2, P2, CL);                 \
+  } while (0)
+          if (pow2res && cc_lds) MPPI_LAUNCH_SPEC_C(true, true);
+          else if (pow2res) MPPI_LAUNCH_SPEC_C(true, false);
+          else if (cc_lds) MPPI_LAUNCH_SPEC_C(false, true);
+          else MPPI_LAUNCH_SPEC_C(false, false);
+#undef MPPI_LAUNCH_SPEC_C
+#undef MPPI_LAUNCH_SPEC
+          char buf[320];
+          snprintf(buf, sizeof(buf),
+                   "k_rollout_spec chunk=%d pow2res=%d cc_lds=%d tiles_per_wg=%d speculate=%d window=%dx%d@(%d,%d) "
+                   "progressive=%d lds=%zu noise_blocks=%d problems=%d",
+                   chunk, (int)pow2res, (int)cc_lds, tiles_wg, speculate, d.win_rows, d.win_cols, d.win_r0, d.win_c0,
+                   d.win_progressive, lds_total, extra, p->inst_set ? p->B : 0);
+          p->last_rollout = buf;
+          p->tile_packets_fresh = true;
+          break;
+        }
       }
       if (have_window && rot_ok && !no_pipe) {
         // pipelined kernel: the map window in LDS + the incremental trig
@@ -2069,6 +2159,9 @@ extern "C" int mppi_planner_set_graph_replay(mppi_planner* p, int iterations_per
   drop_graphs(p);
   discard_noise_ahead(p);
   if (enabled && !p->gen_dev) TRY(dev_alloc(&p->gen_dev, (size_t)1));
+  // lazy allocations of the launch paths must not happen inside a capture
+  if (enabled && p->cfg.mode == MPPI_MODE_DET && !p->cc_scratch)
+    TRY(dev_alloc(&p->cc_scratch, (size_t)ceil_div(p->n_local, 64) * 64 * p->cfg.num_steps));
   if (enabled) HIP_TRY(hipMemset(p->gen_dev, 0, sizeof(unsigned long long)));
   p->bumps_launched = 0;
   p->graph_warm = false;
@@ -2084,10 +2177,35 @@ extern "C" int mppi_planner_graph_stats(mppi_planner* p, long* captures, long* r
   return MPPI_OK;
 }
 
+extern "C" int mppi_planner_set_debug_flags(mppi_planner* p, int flags) {
+  REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
+  p->debug_flags = flags;
+  drop_graphs(p);  // (a captured graph holds the kernels chosen under the old flags)
+  return MPPI_OK;
+}
+
 extern "C" int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity) {
   REQUIRE(p && buf && capacity > 0, MPPI_ERR_INVALID, "bad argument");
   snprintf(buf, (size_t)capacity, "%s", p->last_rollout.c_str());
   return MPPI_OK;
+}
+
+// developer instrumentation: see MPPI_STAMP in device_math.h
+extern "C" int mppi_debug_read_stamps(unsigned long long* out, int count, int clear) {
+#ifdef MPPI_STAMPS
+  REQUIRE(out && count >= 0 && count <= 4096, MPPI_ERR_INVALID, "bad stamp request");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)count, 0,
+                              hipMemcpyDeviceToHost));
+  if (clear) {
+    static unsigned long long zeros[4096];
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice));
+  }
+  return MPPI_OK;
+#else
+  (void)out; (void)count; (void)clear;
+  return fail(MPPI_ERR_STATE, "this library was built without -DMPPI_STAMPS (make stamps)");
+#endif
 }
 
 extern "C" int mppi_selftest_philox(int device, int* mismatches) {

@@ -59,6 +59,13 @@ struct DevParams {
   int win_rows, win_cols;  // window size; win_cols is a multiple of 8
   int pitch16;             // row pitch of the global 16-bit cell array (multiple of 8)
   int lin_max_byte, ang_max_byte;  // host-side bounds only (largest traction byte in the grids)
+  // k_rollout_spec copies the window in bands of rows as the rollouts spread: cells a rollout can
+  // cover per step (dt * max|v| * max traction / res); win_progressive = 0: everything up front
+  float win_step_cells;
+  int win_progressive;
+  // the traction byte b with lin_lo + lin_ratio*b == 0.0 (a rollout that enters such a cell never
+  // moves again), or -1 when there is none
+  int lin_zero_byte;
   // batched multi-query handle: per-problem start / goal / window origin, else nullptr
   const struct BatchInst* inst;
   int inst_tiles;  // tiles of 64 rollouts per problem
@@ -481,11 +488,17 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
     // spare workgroups: the noise of the NEXT iteration, into the other noise buffer.
     // (Also giving every rollout group a fourth, noise-generating wave was measured: the
     // extra waves on the rollout CUs cost the critical waves more than they saved.)
+    MPPI_STAMP(threadIdx.x == 0 && ((int)blockIdx.x == n_rollout_blocks || blockIdx.x == gridDim.x - 1),
+               (int)blockIdx.x == n_rollout_blocks ? 16 : 18);
     if (next_noise.out)
       noise_generate(next_noise, (blockIdx.x - n_rollout_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6),
                      (gridDim.x - n_rollout_blocks) * (blockDim.x >> 6));
+    MPPI_STAMP(threadIdx.x == 0 && ((int)blockIdx.x == n_rollout_blocks || blockIdx.x == gridDim.x - 1),
+               (int)blockIdx.x == n_rollout_blocks ? 17 : 19);
     return;
   }
+  [[maybe_unused]] const bool stamp_wg = blockIdx.x == 5;
+  MPPI_STAMP(stamp_wg && threadIdx.x == 0, 0);
   // these few waves are the critical path of the iteration; the noise of the NEXT
   // iteration is generated concurrently by thousands of throughput-oriented waves on
   // the same SIMDs: win the issue arbitration against them
@@ -520,8 +533,11 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
+  [[maybe_unused]] const int stamp_base = 64 + 64 * role;
+  MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 0);
   // (24 loads in flight per lane instead of 8 was measured: no change)
   copy_window_to_lds(P, cells16, lds_map, 0, 128 * W);  // waves of roles 0 and 1
+  MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 1);
 
   const int tile = blockIdx.x * W + triple;  // 64 consecutive rollouts
   const int n = tile * 64 + lane;
@@ -541,6 +557,7 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
     const int win_pitch_bytes = 2 * P.win_cols;
     const char* lds_bytes = reinterpret_cast<const char*>(lds_map);
     __syncthreads();  // controls of chunk 0 are in the ring
+    MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 2);
     for (int k = 0; k <= K; ++k) {
       if (k < K) {
         const double2* in_qd = ring_qd + (size_t)(k & 1) * Ring::kHalf;
@@ -575,8 +592,10 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
           out_flags[j * 64 + lane] = (uint8_t)(c16 >> 14);  // obstacle | unknown << 1 of the cell just left
         }
       }
+      MPPI_STAMP(stamp_wg && triple == 0 && k < 32, stamp_base + 3 + k);
       __syncthreads();
     }
+    MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 40);
   } else if (role == 2) {
     // the tile past N (if any) reads the last valid tile's noise and writes nothing
     const bool tile_ok = tile * 64 < N;
@@ -600,6 +619,7 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
 #pragma unroll
     for (int j = 0; j < C; ++j) e_nxt[j] = col[(size_t)min(C + j, T - 1) * 64];
     produce(0, e_cur);
+    MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 2);
     __syncthreads();
     for (int k = 0; k <= K; ++k) {
 #pragma unroll
@@ -607,8 +627,10 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
 #pragma unroll
       for (int j = 0; j < C; ++j) e_nxt[j] = col[(size_t)min((k + 2) * C + j, T - 1) * 64];
       if (k + 1 < K) produce(k + 1, e_cur);
+      MPPI_STAMP(stamp_wg && triple == 0 && k < 32, stamp_base + 3 + k);
       __syncthreads();
     }
+    MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 40);
   } else {
     const double dt64 = (double)P.dt, gt2 = (double)P.gt2;
     float cost = 0.0f;
@@ -616,6 +638,7 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
     bool done = false, reached = false;
     const double* my_cc = CC_LDS ? cc_lds + lane : cc_scratch + (live ? tile_base : (size_t)lane);
     __syncthreads();
+    MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 2);
     for (int k = 0; k <= K; ++k) {
       if (k >= 1) {
         const int t0 = (k - 1) * C;
@@ -645,8 +668,10 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
           for (int j = 0; j < count; ++j) cost_step(j);
         }
       }
+      MPPI_STAMP(stamp_wg && triple == 0 && k < 32, stamp_base + 3 + k);
       __syncthreads();
     }
+    MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 40);
     // terminal cost, then the control cost of all T steps (mppi.py:1005-1009); the
     // products were written by the producer wave of this workgroup before its last barrier
     double term = (reached ? 0.0 : 1.0) * sqrt(d2) / P.v_post_den;
@@ -674,9 +699,11 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
 #pragma unroll
       for (int j = 0; j < kTailBatch; ++j) cb[j] = my_cc[(size_t)min(t0 + 2 * kTailBatch + j, T - 1) * 64];
     }
+    MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 41);
     if (live) costs[n] = cost;
     // first half of the control update (update_kernels.h): weights relative to the tile's minimum
     if (tile * 64 < N) emit_tile_weights(cost, live, P.lambda, n, tile, w_rel, tile_beta);
+    MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 42);
   }
 }
 

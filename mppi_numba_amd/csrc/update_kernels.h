@@ -107,6 +107,8 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
     u_mirror += (size_t)inst * n_steps;
     stats += 2 * inst;
   }
+  [[maybe_unused]] const bool stamp_wg = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0;
+  MPPI_STAMP(stamp_wg, 512);
   const double neg_inv_lambda = -1.0 / (double)lambda;
   float* tb_sh = scale_sh + n_tiles;  // FROM_COSTS: [n_tiles] tile minima
   if (FROM_COSTS) {
@@ -123,11 +125,13 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
   b = wave_min_f32(b);
   if (lane == 0) redf[wave] = b;
   __syncthreads();
+  MPPI_STAMP(stamp_wg, 513);
   float beta = redf[0];
   for (int k = 1; k < kRowThreads / 64; ++k) beta = fminf(beta, redf[k]);
   for (int g = threadIdx.x; g < n_tiles; g += kRowThreads)
     scale_sh[g] = (float)exp(neg_inv_lambda * (double)(tile_beta[g] - beta));
   __syncthreads();
+  MPPI_STAMP(stamp_wg, 514);
   double den = 0.0, nx[TC], ny[TC];
 #pragma unroll
   for (int j = 0; j < TC; ++j) nx[j] = ny[j] = 0.0;
@@ -174,6 +178,7 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
       ny[j] = fma(w, (double)e.y, ny[j]);
     }
   }
+  MPPI_STAMP(stamp_wg, 515);
   den = wave_sum_f64(den);
 #pragma unroll
   for (int j = 0; j < TC; ++j) {
@@ -195,6 +200,7 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
     red[0][threadIdx.x] = acc;
   }
   __syncthreads();
+  MPPI_STAMP(stamp_wg, 516);
   if (threadIdx.x < TC && t0 + (int)threadIdx.x < n_steps) {
     const int j = threadIdx.x, t = t0 + j;
     const double d = red[0][0], sx = red[0][1 + 2 * j], sy = red[0][2 + 2 * j];
@@ -211,6 +217,7 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
       stats[1] = d;
     }
   }
+  MPPI_STAMP(stamp_wg, 517);
 }
 
 // combine the packets of all ranks (identical on every GPU, fixed g order).

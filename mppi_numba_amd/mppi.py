@@ -370,6 +370,10 @@ class MPPI_Numba(object):
         _lib.call("mppi_planner_describe_last_rollout", self._handle, buf, 512)
         return buf.value.decode()
 
+    def set_debug_flags(self, flags):
+        """Developer switches (_lib.DEBUG_*): which rollout kernel variant runs; never the results."""
+        _lib.call("mppi_planner_set_debug_flags", self._handle, int(flags))
+
     def set_graph_replay(self, enabled=True, iterations_per_graph=2):
         """hipGraph replay of the iteration loop (include/mppi_hip.h); same results."""
         _lib.call("mppi_planner_set_graph_replay", self._handle, int(iterations_per_graph) if enabled else 0)

@@ -44,7 +44,7 @@ def oracle_costs(w, params, lin, ang, noise, u):
 
 
 # which rollout kernel each BASELINE configuration must take (bench.py runs the same objects)
-EXPECTED_KERNEL = {"c2": "k_rollout_pipe", "c3": "k_rollout_tdm_fast", "c4": "k_rollout_fused"}
+EXPECTED_KERNEL = {"c2": "k_rollout_spec", "c3": "k_rollout_tdm_fast", "c4": "k_rollout_fused"}
 U_MARGINS = {}  # workload -> achieved max |du| / control range (printed by the last test of the file)
 
 
@@ -312,12 +312,12 @@ def custom_world(rows, cols, res, seed):
 
 @pytest.mark.parametrize("label,rows,cols,res,n,t_steps,x0,pad_speed,expect", [
     ("non power-of-two resolution: exact floor division", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0,
-     ["k_rollout_pipe", "pow2res=0"]),
+     ["k_rollout_spec", "pow2res=0"]),
     ("resolution 0.1: cell borders every few float32 ulps", 200, 200, 0.1, 2048, 80, (7.33, 8.21, -2.0), 3.0,
-     ["k_rollout_pipe", "pow2res=0", "cc_lds=1"]),
-    ("two wave triples per workgroup", 256, 256, 0.25, 32768, 40, (20.0, 30.0, 0.3), 5.0,
-     ["k_rollout_pipe", "triples_per_wg=2"]),
-    ("three wave triples per workgroup, ragged last tile", 256, 256, 0.25, 49152 - 37, 40, (20.0, 30.0, 0.3), 5.0,
+     ["k_rollout_spec", "pow2res=0", "cc_lds=0"]),  # 86 KiB window + 60 KiB of rings: the products go to global
+    ("two tiles per workgroup", 256, 256, 0.25, 32768, 40, (20.0, 30.0, 0.3), 5.0,
+     ["k_rollout_spec", "tiles_per_wg=2"]),
+    ("three tiles per CU, ragged last tile: the pipelined kernel", 256, 256, 0.25, 49152 - 37, 40, (20.0, 30.0, 0.3), 5.0,
      ["k_rollout_pipe", "triples_per_wg=3"]),
     ("throughput regime: fused kernel on the LDS window, 4 waves per CU", 256, 256, 0.25, 65536, 40,
      (20.0, 30.0, 0.3), 5.0, ["k_rollout_fused", "waves_per_wg=4"]),
@@ -326,7 +326,18 @@ def custom_world(rows, cols, res, seed):
     ("reach window larger than LDS: global 32-bit cell path", 700, 700, 0.05, 2048, 100, (17.0, 18.0, 1.0), 3.0,
      ["k_rollout_map det global_cells"]),
     ("whole-map window, control-cost products in global scratch", 270, 250, 0.25, 2048, 200, (30.0, 33.0, 0.0), 5.0,
-     ["k_rollout_pipe", "cc_lds=0", "window=274x"]),
+     ["k_rollout_spec", "cc_lds=0", "window=274x"]),
+    # the same regimes on the exact schedule of the speculative kernel and on its predecessor
+    ("no speculation: non power-of-two resolution", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0,
+     ["k_rollout_spec", "pow2res=0", "speculate=0"]),
+    ("no speculation: two tiles per workgroup, ragged last tile", 256, 256, 0.25, 32768 - 37, 40, (20.0, 30.0, 0.3), 5.0,
+     ["k_rollout_spec", "tiles_per_wg=2", "speculate=0"]),
+    ("pipelined kernel: non power-of-two resolution", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0,
+     ["k_rollout_pipe", "pow2res=0"]),
+    ("pipelined kernel: two wave triples per workgroup", 256, 256, 0.25, 32768, 40, (20.0, 30.0, 0.3), 5.0,
+     ["k_rollout_pipe", "triples_per_wg=2"]),
+    ("pipelined kernel: whole-map window, control-cost products in global scratch", 270, 250, 0.25, 2048, 200,
+     (30.0, 33.0, 0.0), 5.0, ["k_rollout_pipe", "cc_lds=0", "window=274x"]),
 ])
 def test_det_rollout_variants_vs_oracle(label, rows, cols, res, n, t_steps, x0, pad_speed, expect):
     """Every code path of the deterministic rollout (pipelined / fused, LDS window kinds,
@@ -344,6 +355,9 @@ def test_det_rollout_variants_vs_oracle(label, rows, cols, res, n, t_steps, x0, 
     lin.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)
     ang.set_TDM_from_PMF_grid(pmf[:, ::-1].copy(), td, obstacle, unknown)
     planner = MPPI_Numba(cfg)
+    from mppi_numba_amd import _lib
+    planner.set_debug_flags((_lib.DEBUG_NO_SPEC_KERNEL if "k_rollout_pipe" in expect else 0) |
+                            (_lib.DEBUG_NO_SPECULATION if "speculate=0" in expect else 0))
     params = bench.make_params("c2")
     params.update(x0=np.array(x0), xgoal=np.array([x0[0] + 3.0, x0[1] + 2.0]), lambda_weight=5.0)
     planner.setup(params, lin, ang)
@@ -365,6 +379,76 @@ def test_det_rollout_variants_vs_oracle(label, rows, cols, res, n, t_steps, x0, 
     planner.update()
     _, u_ref, _ = O.update_useq(params["lambda_weight"], want, noise, params["vrange"], params["wrange"], u_in)
     assert (np.abs(planner.u_cur_d.copy_to_host() - u_ref) / np.array([3.0, np.pi])).max() <= 1e-5, label
+
+
+def patch_world(rows, cols, res, kind, seed):
+    """Traction maps on which the speculation of k_rollout_spec holds for a while: `uniform` (never
+    fails), `far` (other traction beyond ~6 m of the start: fails mid-horizon, at different chunks
+    for different tiles), `near` (other traction 1.5 m away: fails in the first chunks), `stripes`
+    (2 m stripes of two tractions, angular traction constant)."""
+    rng = np.random.default_rng(seed)
+    bins = 8
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    which = np.full((rows, cols), 6)
+    ang_which = np.full((rows, cols), 5)
+    if kind in ("far", "near"):
+        radius = (6.0 if kind == "far" else 1.5) / res
+        outside = (xx - cols / 2) ** 2 + (yy - rows / 2) ** 2 > radius ** 2
+        which[outside] = 3
+        ang_which[outside & (xx > cols / 2)] = 7
+    elif kind == "stripes":
+        which[(xx // int(2.0 / res)) % 2 == 1] = 4
+    pmf = np.zeros((bins, rows, cols), dtype=np.int8)
+    ang_pmf = np.zeros((bins, rows, cols), dtype=np.int8)
+    np.put_along_axis(pmf, which[None], 100, axis=0)
+    np.put_along_axis(ang_pmf, ang_which[None], 100, axis=0)
+    obstacle = (rng.random((rows, cols)) < 0.03).astype(np.int8)
+    unknown = (rng.random((rows, cols)) < 0.03).astype(np.int8)
+    td = dict(xlimits=(0.0, cols * res), ylimits=(0.0, rows * res), res=res, bin_values=np.linspace(0, 1, bins),
+              bin_values_bounds=(0.0, 1.0), det_dynamics_cvar_alpha=1.0)
+    return pmf, ang_pmf, obstacle, unknown, td
+
+
+@pytest.mark.parametrize("flags", [0, 2, 1])
+@pytest.mark.parametrize("kind,t_steps,n", [("uniform", 100, 8192), ("far", 100, 8192), ("near", 100, 4096),
+                                            ("stripes", 60, 8192), ("far", 37, 2048 + 5), ("far", 200, 16384 + 64)])
+def test_speculation_holds_then_fails_same_bits(kind, t_steps, n, flags):
+    """k_rollout_spec assumes the start cell's traction bytes everywhere and falls back, per tile
+    and from the start of the offending chunk, when a lookup says otherwise: costs must be those
+    of the oracle (and of the kernel on its exact schedule, flags=2, and of k_rollout_pipe,
+    flags=1) wherever and whenever the assumption breaks."""
+    from mppi_numba_amd.config import Config
+    from mppi_numba_amd.mppi import MPPI_Numba
+    from mppi_numba_amd.terrain import TDM_Numba
+    rows = cols = 200
+    res = 0.25
+    pmf, ang_pmf, obstacle, unknown, td = patch_world(rows, cols, res, kind, seed=11)
+    cfg = Config(T=t_steps * 0.1, dt=0.1, num_grid_samples=1, num_control_rollouts=n, max_speed_padding=5.0,
+                 num_vis_state_rollouts=1, max_map_dim=(rows + 4, cols + 4), seed=5,
+                 enforce_recommended_limits=False, use_det_dynamics=True)
+    lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
+    lin.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)
+    ang.set_TDM_from_PMF_grid(ang_pmf, td, obstacle, unknown)
+    planner = MPPI_Numba(cfg)
+    planner.set_debug_flags(flags)
+    params = bench.make_params("c2")
+    params.update(x0=np.array([25.1, 24.9, 0.7]), xgoal=np.array([40.0, 38.0]), lambda_weight=5.0)
+    planner.setup(params, lin, ang)
+    planner.solve()
+    planner.iterate_async(2)
+    planner.synchronize()
+    planner.sample_noise()
+    noise, u_in = planner.noise_samples_d.copy_to_host(), planner.u_cur_d.copy_to_host()
+    planner.rollout()
+    kernel = planner.last_rollout_kernel()
+    assert ("k_rollout_pipe" if flags == 1 else "k_rollout_spec speculate=%d" % (0 if flags else 1)).split()[0] in kernel
+    if flags != 1:
+        assert "speculate=%d" % (0 if flags else 1) in kernel, kernel
+    got = planner.costs_d.copy_to_host()
+    want = oracle_costs(dict(m=1), params, lin, ang, noise, u_in)
+    ulps = ulp_diff_f32(got, want)
+    assert (ulps == 0).mean() >= 0.999, "%s: exact fraction %.5f, max ulp %d" % (kind, (ulps == 0).mean(), ulps.max())
+    assert (np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max() < 1e-6
 
 
 def test_overlapped_noise_generation_equals_in_line_generation():
@@ -473,7 +557,7 @@ def test_update_from_costs_has_the_bits_of_the_epilogue_path():
     a.sample_noise()
     noise = a.noise_samples_d.copy_to_host()
     a.rollout()
-    assert "k_rollout_pipe" in a.last_rollout_kernel()
+    assert "k_rollout_spec" in a.last_rollout_kernel()
     costs = a.costs_d.copy_to_host()
     a.update()
     b.set_u(u_in)
