@@ -389,7 +389,7 @@ def main():
 
     kernel_name = planner.last_rollout_kernel().split(" ")[0]
     bytes_iter, bytes_roll = algorithmic_bytes(w, n_local * max(1, problems), rp, cp,
-                                               rollout_writes_noise=(kernel_name in ("k_rollout_pipe", "k_rollout_spec")))
+                                               rollout_writes_noise=(kernel_name in ("k_rollout_pipe", "k_rollout_spec", "k_rollout_deep")))
     traffic = None
     try:  # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
@@ -427,7 +427,7 @@ def main():
                           "bracket adds ~3 us of event overhead, so the stages sum to more than ms_per_step (which has "
                           "no events inside the loop); rocprofv3 durations of the same kernels: profiles/",
         "roofline": {"bound": "hbm",
-                     "kernel": kernel_name + (" (rollout + next iteration's noise)" if kernel_name in ("k_rollout_pipe", "k_rollout_spec") else ""),
+                     "kernel": kernel_name + (" (rollout + next iteration's noise)" if kernel_name in ("k_rollout_pipe", "k_rollout_spec", "k_rollout_deep") else ""),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "

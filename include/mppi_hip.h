@@ -270,7 +270,9 @@ int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity)
 /* developer switches for the parity tests, which pin every rollout kernel variant by name
  * (mppi_planner_describe_last_rollout): results never depend on them */
 #define MPPI_DEBUG_NO_SPEC_KERNEL 1  /* latency regime: k_rollout_pipe instead of k_rollout_spec */
-#define MPPI_DEBUG_NO_SPECULATION 2  /* k_rollout_spec on its exact schedule from the first step */
+#define MPPI_DEBUG_NO_SPECULATION 2  /* the speculative kernels on their exact schedule from the first step */
+#define MPPI_DEBUG_NO_DEEP_KERNEL 4  /* one tile per CU: k_rollout_spec instead of k_rollout_deep */
+#define MPPI_DEBUG_CC_GLOBAL 8       /* control-cost products in the global scratch array even when LDS has room */
 int mppi_planner_set_debug_flags(mppi_planner* p, int flags);
 int mppi_selftest_philox(int device, int* mismatches);
 /* developer instrumentation: in-kernel clock stamps of a -DMPPI_STAMPS build

@@ -195,6 +195,18 @@ __device__ __forceinline__ double sqrt_newton_f64(double a) {
   return (yf > 0.0f) ? y1 : 0.0;
 }
 
+// The same square root for callers that add it, scaled, to a float64 of order >= 1e-3 before
+// rounding to float32 (the stage cost): the seed is kept away from zero instead of selecting an
+// exact 0 at the end -- for a < 1e-60 the result is ~1e-30 instead of 0, invisible in that sum --
+// which saves the compare and the two selects of the float64 result.
+__device__ __forceinline__ double sqrt_newton_nz_f64(double a) {
+  const float yf = fmaxf(__builtin_amdgcn_sqrtf((float)a), 1.0e-30f);
+  const double y0 = (double)yf;
+  const double r = fma(-y0, y0, a);
+  const double h = 0.5 * (double)__builtin_amdgcn_rcpf(yf);
+  return fma(r, h, y0);
+}
+
 __device__ __forceinline__ float clip_f32(float v, float lo, float hi) {
   // max(lo, min(hi, v)) as the reference writes it
   return fmaxf(lo, fminf(hi, v));

@@ -20,6 +20,7 @@
 #include "rng_kernels.h"
 #include "rollout_kernels.h"
 #include "rollout_spec_kernel.h"
+#include "rollout_deep_kernel.h"
 #include "map_kernels.h"
 #include "update_kernels.h"
 
@@ -733,7 +734,7 @@ static int planner_alloc(mppi_planner* p) {
   for (auto& e : p->ev_stage) HIP_TRY(hipEventCreate(&e));
   const size_t n_tiled = (size_t)ceil_div((long)N, 64) * 64;  // tile-major arrays cover whole tiles
   // (+ 8 chunks of 8 rows: k_rollout_spec prefetches rows past the horizon of the last tile unclamped)
-  const size_t noise_pad = 8 * 8 * 64;
+  const size_t noise_pad = 8 * 16 * 64;
   for (int b = 0; b < 2; ++b) {
     TRY(dev_alloc(&p->noise_buf[b], n_tiled * T + noise_pad));
     HIP_TRY(hipMemsetAsync(p->noise_buf[b], 0, (n_tiled * T + noise_pad) * sizeof(float2), p->stream));
@@ -1288,6 +1289,80 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         int res_exp = 0;
         pow2res = std::frexp((double)a.res, &res_exp) == 0.5;  // res == 2^k exactly
       }
+      static const bool no_deep = getenv("MPPI_NO_DEEP") != nullptr;  // developer switch (ablation)
+      if (have_window && rot_ok && !no_pipe && !no_deep &&
+          !(p->debug_flags & (MPPI_DEBUG_NO_SPEC_KERNEL | MPPI_DEBUG_NO_DEEP_KERNEL)) &&
+          ceil_div(N, 64) <= p->num_cus) {
+        // five-stage speculative pipeline, one tile per CU (rollout_deep_kernel.h)
+        const size_t map_bytes = lds_win - sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);
+        const size_t Tp = ((size_t)T + 7) & ~(size_t)7;
+        const size_t head = sizeof(double2) * (Tp + Tp / 2);
+        const size_t budget = (size_t)p->lds_per_cu - 1024;
+        const size_t cc_bytes = Tp * 64 * sizeof(double);
+        // the exact re-execution path (pipe_tile_body<8>) lives in the same allocation
+        const size_t exact_need = lds_win + (size_t)PipeRing<8>::kBytesPerPair;
+        int chunk = 0;
+        auto ring_size = [](int c) {
+          return c == 8 ? (size_t)DeepRing<8>::kBytes : c == 4 ? (size_t)DeepRing<4>::kBytes : (size_t)DeepRing<2>::kBytes;
+        };
+        for (int cnd : {8, 4, 2})
+          if (head + map_bytes + ring_size(cnd) <= budget) { chunk = cnd; break; }
+        // (chunks of 8 with the control-cost products in LDS, else of 4 with them in LDS, else as found)
+        if (chunk == 8 && head + map_bytes + ring_size(8) + cc_bytes > budget &&
+            head + map_bytes + ring_size(4) + cc_bytes <= budget)
+          chunk = 4;
+        if (chunk > 0 && exact_need <= budget) {
+          const size_t rings = ring_size(chunk);
+          const size_t spec_need = head + map_bytes + rings;
+          const bool cc_lds = spec_need + cc_bytes <= budget && exact_need + (size_t)T * 64 * sizeof(double) <= budget &&
+                              !(p->debug_flags & MPPI_DEBUG_CC_GLOBAL);
+          const size_t lds_total = std::max(spec_need + (cc_lds ? cc_bytes : 0),
+                                            exact_need + (cc_lds ? (size_t)T * 64 * sizeof(double) : 0));
+          const int grid = ceil_div(N, 64);
+          NoiseJob next_job;
+          memset(&next_job, 0, sizeof(next_job));
+          int extra = 0;
+          static const bool no_fused_noise = getenv("MPPI_NO_FUSED_NOISE") != nullptr;  // developer switch
+          if (p->next_noise_wanted && grid < p->num_cus && !no_fused_noise) {  // (no spare CU otherwise: in line)
+            extra = p->num_cus - grid;
+            next_job = make_noise_job(p, p->noise_buf[p->noise_cur ^ 1]);
+            p->next_noise_done = true;
+          }
+          if (!cc_lds && !p->cc_scratch) TRY(dev_alloc(&p->cc_scratch, (size_t)ceil_div(N, 64) * 64 * T));
+          const int speculate = (p->debug_flags & MPPI_DEBUG_NO_SPECULATION) ? 0 : 1;
+#define MPPI_LAUNCH_DEEP(CH, P2, CL)                                                                   \
+  do {                                                                                                \
+    auto kern = k_rollout_deep<CH, P2, CL>;                                                           \
+    if (lds_total > 64 * 1024)                                                                        \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));       \
+    hipLaunchKernelGGL(kern, dim3(grid + extra), dim3(64 * kDeepWaves), lds_total, p->stream, d,      \
+                       p->cells16, p->noise, p->u, p->costs, p->w_rel, p->tile_beta, p->cc_scratch,   \
+                       (int)map_bytes, grid, speculate, next_job);                                     \
+  } while (0)
+#define MPPI_LAUNCH_DEEP_C(P2, CL)            \
+  do {                                        \
+    if (chunk == 8) MPPI_LAUNCH_DEEP(8, P2, CL);      \
+    else if (chunk == 4) MPPI_LAUNCH_DEEP(4, P2, CL); \
+    else MPPI_LAUNCH_DEEP(2, P2, CL);                 \
+  } while (0)
+          if (pow2res && cc_lds) MPPI_LAUNCH_DEEP_C(true, true);
+          else if (pow2res) MPPI_LAUNCH_DEEP_C(true, false);
+          else if (cc_lds) MPPI_LAUNCH_DEEP_C(false, true);
+          else MPPI_LAUNCH_DEEP_C(false, false);
+#undef MPPI_LAUNCH_DEEP_C
+#undef MPPI_LAUNCH_DEEP
+          char buf[320];
+          snprintf(buf, sizeof(buf),
+                   "k_rollout_deep chunk=%d pow2res=%d cc_lds=%d speculate=%d window=%dx%d@(%d,%d) lds=%zu "
+                   "noise_blocks=%d problems=%d",
+                   chunk, (int)pow2res, (int)cc_lds, speculate, d.win_rows, d.win_cols, d.win_r0, d.win_c0, lds_total,
+                   extra, p->inst_set ? p->B : 0);
+          p->last_rollout = buf;
+          p->tile_packets_fresh = true;
+          break;
+        }
+      }
       static const bool no_spec = getenv("MPPI_NO_SPEC") != nullptr;  // developer switch (ablation)
       if (have_window && rot_ok && !no_pipe && !no_spec && !(p->debug_flags & MPPI_DEBUG_NO_SPEC_KERNEL)) {
         // speculative 4-wave pipeline (rollout_spec_kernel.h): same regime as the pipelined kernel below
@@ -1317,7 +1392,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         if (chunk > 0 && latency_regime) {
           // (rows padded to whole chunks: the cost wave reads them at immediate offsets)
           const size_t cc_bytes = (size_t)tiles_wg * ceil_div(T, chunk) * chunk * 64 * sizeof(double);
-          const bool cc_lds = lds_win + ring_bytes(chunk) + cc_bytes <= budget;
+          const bool cc_lds = lds_win + ring_bytes(chunk) + cc_bytes <= budget && !(p->debug_flags & MPPI_DEBUG_CC_GLOBAL);
           const size_t lds_total = lds_win + ring_bytes(chunk) + (cc_lds ? cc_bytes : 0);
           const int block = 256 * tiles_wg;
           const int grid = ceil_div(N, 64 * tiles_wg);

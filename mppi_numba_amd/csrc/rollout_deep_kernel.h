@@ -1,0 +1,501 @@
+// rollout_deep_kernel.h -- k_rollout_deep: the latency-regime rollout as a five-stage software
+// pipeline over ONE tile of 64 rollouts per CU, built on a speculation about the traction map
+// (gfx950, wave64).
+//
+// Replaces rollout_det_dyn_numba (mppi.py:916-1009) with the reference's rounding points (bits
+// identical to k_rollout_pipe / k_rollout_spec / the oracle).
+//
+// What bounds a step.  A wave that is alone on its SIMD issues ONE instruction per ~5 cycles,
+// float32 or float64, however independent its instructions are; conversions to and from float64
+// take 8, a 16-byte LDS store 27-52 (tools/microbench/issue_cost.hip).  N = 8192 gives every CU one
+// tile, so a step costs what its busiest wave issues.  In k_rollout_pipe that is the state wave:
+// position -> cell -> LDS lookup -> traction -> heading -> (cos, sin) rotation -> position is ONE
+// dependent chain of 53 instructions (~340-360 cycles per step measured): the heading needs the
+// angular traction of the visited cell, the position needs the heading.  Here every tile ASSUMES
+// that all of its lookups return the traction bytes of the start cell -- traction is piecewise
+// constant; over maps of nominal dynamics (the reference's own use_det_dynamics recipe,
+// README.md:136-151) or large terrain patches the assumption holds for the whole horizon -- and
+// the chain falls apart into stages that no longer wait for each other:
+//   stage 0  P  noise -> clipped controls {dt*v, dt*w} (float64), control-cost products
+//   stage 1  H  heading theta' = float32(theta + wtr0*dt*w), (cos, sin) by the exact-increment
+//               rotation, the products dt*v*cos, dt*v*sin            (no lookup needed)
+//   stage 2  V  position x' = float32(x + vtr0*dt*v*cos) (3 instructions per axis), and -- off that
+//               chain -- the LDS map lookup of every position
+//   stage 3  S  the vote on the assumption; a rollout that enters a cell of ZERO linear traction
+//               never moves again, whatever its heading does: it is frozen there, exactly as the
+//               reference computes, and stops voting (the zero-traction padding ring of every map
+//               would otherwise fail some lane of every tile); obstacle / unknown bits, squared goal
+//               distance, sqrt (float32 seed + one Newton step), stage cost
+//   stage 4  C  penalties, goal test, float32-rounded accumulation; then terminal cost, control
+//               costs, the tile's half of the weight computation.
+// Chunks of CH steps go from stage to stage through LDS rings, one light workgroup barrier (LDS
+// complete, global loads in flight) per chunk.  (An 11-wave, 10-stage cut of the same work was
+// measured too: the ring traffic and per-interval overhead of so many hand-offs took the SIMDs to
+// ~4 cycles per instruction and the step to 325 cycles -- more waves than instructions to share.)
+// A lookup that contradicts the assumption for a rollout that is still moving (S votes per
+// chunk) abandons the speculation: all waves leave the pipeline after the same barrier, waves 0-2
+// re-execute the tile from its first step on the exact schedule of k_rollout_pipe
+// (pipe_tile_body), the others retire.  Nothing computed under the assumption reaches global
+// memory before the last stage has seen the last chunk.  A map whose traction changes from cell to
+// cell pays the three intervals until the first vote; the host can also launch with speculate = 0
+// (exact schedule from the start).
+//
+// LDS: [Tp] double2 ratios | [Tp] float2 u | map window | rings (DeepRing) | 2 fail flags |
+//      (CC_LDS) [Tp][64] double control-cost products          (Tp = T rounded up to 8)
+#pragma once
+#include "rollout_spec_kernel.h"
+
+namespace mppi {
+
+template <int CH>
+struct DeepRing {
+  static constexpr int kE = CH * 64;             // entries per chunk
+  static constexpr int oVw = 0;                  // vw[2][kE] float2  clipped controls {v, w}  P -> H
+  static constexpr int oPp = oVw + 2 * kE * 8;   // pp[2][kE] double2 dt*v*{cos, sin}         H -> V
+  static constexpr int oXy = oPp + 2 * kE * 16;  // xy[2][kE] float2  position after step     V -> S
+  static constexpr int oCl = oXy + 2 * kE * 8;   // cl[2][kE] uint32  16-bit map cell         V -> S
+  static constexpr int oN2 = oCl + 2 * kE * 4;   // n2[2][kE] double  squared goal distance   S -> C
+  static constexpr int oFl = oN2 + 2 * kE * 8;   // fl[2][64] uint32  2 flag bits per step    S -> C
+  static constexpr int oFail = oFl + 2 * 64 * 4;  // fail[2] int (by interval parity) + padding
+  static constexpr int kBytes = oFail + 16;
+};
+
+enum DeepRole { kP = 0, kH, kS, kC, kV, kDeepWaves };  // (wave 4 shares its SIMD with wave 0: the lightest role)
+
+template <int CH, bool POW2RES, bool CC_LDS>
+__global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
+    DevParams P, const uint16_t* __restrict__ cells16, const float2* __restrict__ noise,
+    const float2* __restrict__ u, float* __restrict__ costs, float* __restrict__ w_rel,
+    float* __restrict__ tile_beta, double* __restrict__ cc_scratch, int map_bytes, int n_rollout_blocks,
+    int speculate, NoiseJob next_noise) {
+  extern __shared__ double2 uos[];
+  if ((int)blockIdx.x >= n_rollout_blocks) {
+    // spare workgroups: the noise of the NEXT iteration, into the other noise buffer
+    MPPI_STAMP(threadIdx.x == 0 && ((int)blockIdx.x == n_rollout_blocks || blockIdx.x == gridDim.x - 1),
+               (int)blockIdx.x == n_rollout_blocks ? 16 : 18);
+    if (next_noise.out)
+      noise_generate(next_noise, (blockIdx.x - n_rollout_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6),
+                     (gridDim.x - n_rollout_blocks) * (blockDim.x >> 6));
+    MPPI_STAMP(threadIdx.x == 0 && ((int)blockIdx.x == n_rollout_blocks || blockIdx.x == gridDim.x - 1),
+               (int)blockIdx.x == n_rollout_blocks ? 17 : 19);
+    return;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  bool exact = !speculate;
+  if (!exact) {
+    // ================================================================ speculative pipeline
+    [[maybe_unused]] const bool stamp_wg = blockIdx.x == 5;
+    MPPI_STAMP(stamp_wg && threadIdx.x == 0, 0);
+    __builtin_amdgcn_s_setprio(3);  // win the issue arbitration against the noise-generating waves
+    DevParams Q = P;
+    const float2* uq = select_instance(Q, u, Q.inst ? (int)blockIdx.x / Q.inst_tiles : 0);
+    const int T = Q.n_steps, N = Q.n_local;
+    const int Tp = (T + 7) & ~7;
+    float2* us = reinterpret_cast<float2*>(uos + Tp);
+    uint16_t* lds_map = reinterpret_cast<uint16_t*>(uos + Tp + Tp / 2);
+    char* rings = reinterpret_cast<char*>(lds_map) + map_bytes;
+    using R = DeepRing<CH>;
+    float2* ring_vw = reinterpret_cast<float2*>(rings + R::oVw);
+    double2* ring_pp = reinterpret_cast<double2*>(rings + R::oPp);
+    float2* ring_xy = reinterpret_cast<float2*>(rings + R::oXy);
+    uint32_t* ring_cl = reinterpret_cast<uint32_t*>(rings + R::oCl);
+    double* ring_n2 = reinterpret_cast<double*>(rings + R::oN2);
+    uint32_t* ring_fl = reinterpret_cast<uint32_t*>(rings + R::oFl);
+    int* fail = reinterpret_cast<int*>(rings + R::oFail);
+    double* cc_lds = reinterpret_cast<double*>(rings + R::kBytes);  // [Tp][64]
+    const int K = (T + CH - 1) / CH;
+    constexpr int kLastStage = 4;
+    const int tile = blockIdx.x;
+    const int n = tile * 64 + lane;
+    const bool live = n < N;
+    const bool tile_ok = tile * 64 < N;
+    const size_t tile_base = (size_t)tile * T * 64 + lane;  // + t*64: element (t, n)
+    constexpr int E = R::kE;
+    [[maybe_unused]] const int stamp_base = 64 + 32 * wave;
+
+    // ---- prologue.  No workgroup barrier before the pipeline starts: P and H need no map (H takes
+    //      the traction bytes of the start cell straight from global memory), V's first lookups
+    //      are two intervals away -- so the three waves that idle through intervals 0 and 1 (S, C, V)
+    //      request the whole map window now and store it to LDS in interval 1.
+    const float2* col = noise + (tile_ok ? tile_base : (size_t)0);
+    float2 e[4][CH];  // producer only: e[c & 3] = noise of chunk c, requested four intervals ahead
+    auto load_noise = [&](float2 (&dst)[CH], int chunk) {
+      // (the noise buffers are padded: rows past the horizon are read unclamped and ignored)
+      const float2* at = col + (size_t)min(chunk, K + 4) * CH * 64;
+#pragma unroll
+      for (int j = 0; j < CH; ++j) dst[j] = at[j * 64];
+    };
+    if (wave == kP) {
+      load_noise(e[0], 0);
+      load_noise(e[1], 1);
+      load_noise(e[2], 2);
+      load_noise(e[3], 3);
+    }
+    const float win_c0f = (float)Q.win_c0, win_r0f = (float)Q.win_r0;
+    const float win_last_col = (float)(Q.win_cols - 1), win_last_row = (float)(Q.win_rows - 1);
+    const int win_pitch_bytes = 2 * Q.win_cols;
+    const char* lds_bytes = reinterpret_cast<const char*>(lds_map);
+    auto window_coords = [&](float x, float y, int& xi, int& yi) {
+      // the window holds every cell reachable within the horizon (host-proved); the clamp is for
+      // memory safety only (and for the positions of frozen rollouts, which V keeps integrating)
+      if (POW2RES) {  // res is a power of two: see cell_coord_pow2
+        xi = cell_coord_pow2(x, Q.xlo, Q.inv_res, win_c0f, win_last_col);
+        yi = cell_coord_pow2(y, Q.ylo, Q.inv_res, win_r0f, win_last_row);
+      } else {
+        xi = clamp_index(floordiv_to_int(x - Q.xlo, Q.res, Q.inv_res) - Q.win_c0, Q.win_cols);
+        yi = clamp_index(floordiv_to_int(y - Q.ylo, Q.res, Q.inv_res) - Q.win_r0, Q.win_rows);
+      }
+    };
+    auto lookup = [&](float x, float y) -> uint32_t {
+      int xi, yi;
+      window_coords(x, y, xi, yi);
+      return *reinterpret_cast<const uint16_t*>(lds_bytes + (__mul24(yi, win_pitch_bytes) + (xi << 1)));
+    };
+    // the assumption: every visited cell carries the traction bytes of the start cell
+    uint32_t ref;
+    {
+      int xi, yi;
+      window_coords(Q.x0, Q.y0, xi, yi);
+      ref = cells16[(size_t)(yi + Q.win_r0) * Q.pitch16 + (xi + Q.win_c0)] & 0x3fffu;
+    }
+    // the map window: vector i of the window (row-major, 16 bytes) by thread i % 192 of waves 2..4
+    constexpr int kCopyVecs = 14;  // per thread in registers (2688 vectors = 42 KiB); a larger window's
+                                   // remainder is copied before the first barrier
+    u32x4 win_v[kCopyVecs];
+    const int copy_tid = (int)threadIdx.x - 128;
+    const int win_vpr = Q.win_cols >> 3, win_total = Q.win_rows * win_vpr;
+    if (wave >= 2) {
+      const u32x4* src = reinterpret_cast<const u32x4*>(cells16) + ((size_t)Q.win_r0 * Q.pitch16 + Q.win_c0) / 8;
+      const int src_pitch = Q.pitch16 >> 3;
+      const float inv_vpr = 1.0f / (float)win_vpr;
+      auto source_of = [&](int i) {
+        int r = (int)((float)i * inv_vpr);  // i < 2^20: within one of the quotient
+        r -= (r * win_vpr > i);
+        r += ((r + 1) * win_vpr <= i);
+        return r * src_pitch + (i - r * win_vpr);
+      };
+#pragma unroll
+      for (int q = 0; q < kCopyVecs; ++q) win_v[q] = src[source_of(min(copy_tid + q * 192, win_total - 1))];
+      for (int i = copy_tid + kCopyVecs * 192; i < win_total; i += 192)
+        reinterpret_cast<u32x4*>(lds_map)[i] = src[source_of(i)];
+    }
+    if (wave == kP) {
+      for (int t = lane; t < Tp; t += 64) {
+        const float2 ut = t < T ? uq[t] : make_float2(0.0f, 0.0f);
+        us[t] = ut;
+        uos[t] = make_double2((double)ut.x / Q.s0sq, (double)ut.y / Q.s1sq);
+      }
+      if (lane < 2) fail[lane] = 0;  // (visible to the others after the first barrier; nobody reads before)
+    }
+    MPPI_STAMP(stamp_wg, stamp_base + 0);
+    const double vtr0 = fma(Q.lin_ratio, (double)(int)(ref & 127u), Q.lin_lo);
+    const double wtr0 = fma(Q.ang_ratio, (double)(int)((ref >> 7) & 127u), Q.ang_lo);
+    MPPI_STAMP(stamp_wg, stamp_base + 1);
+    // stored by waves 2..4 at the end of interval 1 (called from their loops below)
+    auto store_window = [&]() {
+      u32x4* dst = reinterpret_cast<u32x4*>(lds_map);
+#pragma unroll
+      for (int q = 0; q < kCopyVecs; ++q) dst[min(copy_tid + q * 192, win_total - 1)] = win_v[q];
+    };
+
+    // One interval of a stage: its work on chunk c = k - stage when that chunk exists, the light
+    // barrier, the vote of the PREVIOUS interval (requested at the top, complete at the barrier;
+    // S writes the slot of the interval it ran in, everybody reads the other one: race-free).
+    // Returns 1 to leave on a failed vote, 2 after the last chunk has passed the last stage.
+    auto interval_end = [&](int k, int flag) -> int {
+      MPPI_STAMP(stamp_wg && k < 24, stamp_base + 2 + k);
+      lds_barrier();
+      asm volatile("" : "+v"(flag));  // (the flag register is written by the LDS unit: complete only here)
+      if (flag) return 1;
+      return k >= K - 1 + kLastStage ? 2 : 0;
+    };
+    auto read_flag = [&](int k) -> int {  // issued at the top of interval k: the vote of interval k-1
+      if (k == 0) return 0;  // (the flags are being initialised)
+      int v;
+      typedef __attribute__((address_space(3))) int lds_int;
+      const unsigned at = (unsigned)(size_t)(lds_int*)(fail + ((k + 1) & 1));  // LDS byte offset
+      asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(at) : "memory");
+      return v;
+    };
+    int outcome = 0;
+
+    if (wave == kP) {
+      // -------------------------------------------------------------- stage 0: controls and control costs
+      // (loop unrolled by 4: static register sets.  The noise loads are issued in EVERY interval,
+      //  also past the horizon, and the wait for the set consumed now -- requested four intervals
+      //  earlier, three younger groups of CH loads may stay in flight -- is written out by hand with
+      //  the registers as operands: hipcc's own vmcnt bookkeeping across the inline-asm barriers of
+      //  the unrolled loop waits either for the newest loads or not at all.)
+      double* my_cc = CC_LDS ? cc_lds + lane : cc_scratch + tile_base;
+      auto step = [&](auto ph, int k) -> int {
+        constexpr int PH = decltype(ph)::value;  // == k & 3
+        const int flag = read_flag(k);
+        const int kk = min(k, K - 1);
+        const float2* us_c = us + kk * CH;
+        const double2* uos_c = uos + kk * CH;
+        float2 vw[CH];
+        double cc[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+          asm volatile("s_waitcnt vmcnt(%2)" : "+v"(e[PH][j].x), "+v"(e[PH][j].y) : "n"(3 * CH));
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          const float2 ut = us_c[j];  // steps past the horizon: zero controls, produced and ignored
+          vw[j] = make_float2(clip_f32(ut.x + e[PH][j].x, Q.v_lo, Q.v_hi), clip_f32(ut.y + e[PH][j].y, Q.w_lo, Q.w_hi));
+          cc[j] = control_cost(Q, uos_c[j], e[PH][j]);
+        }
+        // the last use of this register set comes before its reload (results as operands of the
+        // fence): the set then keeps its physical registers around the loop, and hipcc has no
+        // copies of in-flight registers -- each behind an s_waitcnt vmcnt(0) -- to make at the latch
+#pragma unroll
+        for (int j = 0; j < CH; ++j) asm volatile("" : : "v"(vw[j].x), "v"(vw[j].y), "v"(cc[j]) : "memory");
+        load_noise(e[PH], k + 4);
+        pin_memory_order();
+        if (k < K) {
+          float2* out = ring_vw + (k & 1) * E;
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            out[j * 64 + lane] = vw[j];
+            if (tile_ok && k * CH + j < T) my_cc[(size_t)(k * CH + j) * 64] = cc[j];
+          }
+        }
+        return interval_end(k, flag);
+      };
+      // (two rounds of the four register sets per loop iteration: at the loop header hipcc still
+      //  waits for the newest loads before the first use of a set -- ~400 cycles -- so the header
+      //  should come round as rarely as the code size allows)
+      for (int k = 0;; k += 16) {
+        if ((outcome = step(PhaseTag<0>(), k))) break;
+        if ((outcome = step(PhaseTag<1>(), k + 1))) break;
+        if ((outcome = step(PhaseTag<2>(), k + 2))) break;
+        if ((outcome = step(PhaseTag<3>(), k + 3))) break;
+        if ((outcome = step(PhaseTag<0>(), k + 4))) break;
+        if ((outcome = step(PhaseTag<1>(), k + 5))) break;
+        if ((outcome = step(PhaseTag<2>(), k + 6))) break;
+        if ((outcome = step(PhaseTag<3>(), k + 7))) break;
+        if ((outcome = step(PhaseTag<0>(), k + 8))) break;
+        if ((outcome = step(PhaseTag<1>(), k + 9))) break;
+        if ((outcome = step(PhaseTag<2>(), k + 10))) break;
+        if ((outcome = step(PhaseTag<3>(), k + 11))) break;
+        if ((outcome = step(PhaseTag<0>(), k + 12))) break;
+        if ((outcome = step(PhaseTag<1>(), k + 13))) break;
+        if ((outcome = step(PhaseTag<2>(), k + 14))) break;
+        if ((outcome = step(PhaseTag<3>(), k + 15))) break;
+      }
+      // products in global scratch: out before the cost wave's tail reads them
+      if (!CC_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (wave == kH) {
+      // -------------------------------------------------------------- stage 1: heading (assumed traction)
+      const double dt64 = (double)Q.dt;
+      float th = Q.th0;
+      double th64 = (double)th, s, c0;
+      sincos_f64<false>(th64, s, c0);
+      for (int k = 0;; ++k) {
+        const int flag = read_flag(k), c = k - 1;
+        if (c >= 0 && c < K) {
+          const float2* in = ring_vw + (c & 1) * E;
+          float2 vw[CH];
+          double2 qd[CH], pp[CH];
+          double sd[CH], cd[CH];
+#pragma unroll
+          for (int j = 0; j < CH; ++j) vw[j] = in[j * 64 + lane];
+          pin_memory_order();
+#pragma unroll
+          for (int j = 0; j < CH; ++j)  // dt*v, dt*w: exact products of float32 factors
+            qd[j] = make_double2(dt64 * (double)vw[j].x, dt64 * (double)vw[j].y);
+          // (a) the heading chain, (b) the increment polynomials of all steps side by side, (c) the
+          //     rotation chain with the products
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            th = (float)fma(wtr0, qd[j].y, th64);
+            const double th_new = (double)th;
+            sd[j] = th_new - th64;  // exact increment of the ROUNDED heading
+            th64 = th_new;
+          }
+#pragma unroll
+          for (int j = 0; j < CH; ++j) sincos_increment_f64(sd[j], sd[j], cd[j]);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            pp[j] = make_double2(qd[j].x * c0, qd[j].x * s);
+            apply_rotation_f64(sd[j], cd[j], s, c0);
+          }
+          pin_memory_order();
+          double2* out = ring_pp + (c & 1) * E;
+#pragma unroll
+          for (int j = 0; j < CH; ++j) out[j * 64 + lane] = pp[j];
+        }
+        if ((outcome = interval_end(k, flag))) break;
+      }
+    } else if (wave == kV) {
+      // -------------------------------------------------------------- stage 2: position chain, map lookups
+      float x = Q.x0, y = Q.y0;
+      double x64 = (double)x, y64 = (double)y;
+      for (int k = 0;; ++k) {
+        const int flag = read_flag(k), c = k - 2;
+        if (c >= 0 && c < K) {
+          const double2* in = ring_pp + (c & 1) * E;
+          double2 pp[CH];
+          float xa[CH + 1], ya[CH + 1];
+          uint32_t cl[CH];
+#pragma unroll
+          for (int j = 0; j < CH; ++j) pp[j] = in[j * 64 + lane];
+          pin_memory_order();
+          xa[0] = x;
+          ya[0] = y;
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {  // (a 3-instruction chain per axis)
+            x = (float)fma(vtr0, pp[j].x, x64);
+            y = (float)fma(vtr0, pp[j].y, y64);
+            x64 = (double)x;
+            y64 = (double)y;
+            xa[j + 1] = x;
+            ya[j + 1] = y;
+          }
+#pragma unroll
+          for (int j = 0; j < CH; ++j) cl[j] = lookup(xa[j], ya[j]);  // the cell step j STARTS in
+          pin_memory_order();
+          float2* out_xy = ring_xy + (c & 1) * E;
+          uint32_t* out_cl = ring_cl + (c & 1) * E;
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            out_xy[j * 64 + lane] = make_float2(xa[j + 1], ya[j + 1]);  // position AFTER step j
+            out_cl[j * 64 + lane] = cl[j];
+          }
+        }
+        if (k == 1) store_window();
+        if ((outcome = interval_end(k, flag))) break;
+      }
+    } else if (wave == kS) {
+      // -------------------------------------------------------------- stage 3: the vote; frozen rollouts;
+      //                                                                 squared goal distance
+      bool stuck = false;           // this rollout sits in a cell of zero linear traction
+      float ex = Q.x0, ey = Q.y0;   // effective position (frozen once stuck)
+      uint32_t ecell = 0;           // cell of the previous step (the cell a frozen rollout stays in)
+      for (int k = 0;; ++k) {
+        const int flag = read_flag(k), c = k - 3;
+        if (c >= 0 && c < K) {
+          const float2* in_xy = ring_xy + (c & 1) * E;
+          const uint32_t* in_cl = ring_cl + (c & 1) * E;
+          float2 xy[CH];
+          uint32_t cl[CH];
+          double n2[CH];
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            xy[j] = in_xy[j * 64 + lane];
+            cl[j] = in_cl[j * 64 + lane];
+          }
+          pin_memory_order();
+          uint32_t bad = 0, fl = 0;
+          const int steps_left = T - c * CH;  // steps of this chunk inside the horizon
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            const uint32_t cell = stuck ? ecell : cl[j];  // the cell this step starts in
+            stuck = stuck || (int)(cell & 127u) == Q.lin_zero_byte;
+            bad |= (!stuck && j < steps_left) ? ((cell ^ ref) & 0x3fffu) : 0u;
+            fl |= (cell >> 14) << (2 * j);  // obstacle | unknown << 1 of the cell step j left
+            ecell = cell;
+            ex = stuck ? ex : xy[j].x;
+            ey = stuck ? ey : xy[j].y;
+            const double dx = (double)(Q.xg - ex), dy = (double)(Q.yg - ey);
+            n2[j] = fma(dx, dx, dy * dy);
+          }
+          pin_memory_order();
+          double* out = ring_n2 + (c & 1) * E;
+#pragma unroll
+          for (int j = 0; j < CH; ++j) out[j * 64 + lane] = n2[j];
+          ring_fl[(c & 1) * 64 + lane] = fl;
+          if (__any(bad != 0) && lane == 0) fail[k & 1] = 1;  // read by everybody in interval k+1
+        }
+        if (k == 1) store_window();
+        if ((outcome = interval_end(k, flag))) break;
+      }
+    } else {
+      // -------------------------------------------------------------- stage 4: stage costs, accumulation
+      const double gt2 = (double)Q.gt2, dt64 = (double)Q.dt;
+      float cost = 0.0f;
+      double d2 = 1e9;
+      bool done = false, reached = false;
+      for (int k = 0;; ++k) {
+        const int flag = read_flag(k), c = k - 4;
+        if (c >= 0 && c < K) {
+          const double* in = ring_n2 + (c & 1) * E;
+          double n2[CH], sg[CH];
+#pragma unroll
+          for (int j = 0; j < CH; ++j) n2[j] = in[j * 64 + lane];
+          const uint32_t fl = ring_fl[(c & 1) * 64 + lane];
+          pin_memory_order();
+          // (a) the square roots of all steps side by side, (b) the accumulation chain
+#pragma unroll
+          for (int j = 0; j < CH; ++j) sg[j] = fma(Q.dist_weight, sqrt_newton_nz_f64(n2[j]), dt64);
+          const int count = min(CH, T - c * CH);
+#pragma unroll
+          for (int j = 0; j < CH; ++j) {
+            float c1 = (float)((double)cost + sg[j]);
+            // bits of the cell the step STARTED in (mppi.py:971-998): penalty or +0.0, selected by the
+            // sign-extended flag bit (v_bfe_i32 + v_and_b32)
+            c1 = c1 + __int_as_float(__float_as_int(Q.obs_cost) & __builtin_amdgcn_sbfe((int)fl, 2 * j, 1));
+            c1 = c1 + __int_as_float(__float_as_int(Q.unk_cost) & __builtin_amdgcn_sbfe((int)fl, 2 * j + 1, 1));
+            const bool hit = n2[j] <= gt2, act = !done && j < count;
+            cost = act ? c1 : cost;
+            d2 = act ? n2[j] : d2;
+            reached = reached || (act && hit);
+            done = done || (hit && j < count);
+          }
+        }
+        if (k == 1) store_window();
+        if ((outcome = interval_end(k, flag))) break;
+      }
+      if (outcome == 2) {
+        MPPI_STAMP(stamp_wg, stamp_base + 30);
+        // terminal cost, then the control cost of all T steps (mppi.py:1005-1009)
+        const double term = (reached ? 0.0 : 1.0) * sqrt(d2) / Q.v_post_den;
+        cost = (float)((double)cost + term);
+        if (CC_LDS) {
+          // batches of 8 float32-rounded additions, the next batch's LDS reads in flight meanwhile
+          // (row-padded array: every read is unconditional, at an immediate offset from one base)
+          const double* my_cc = cc_lds + lane;
+          double va[8], vb[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) va[j] = my_cc[(size_t)j * 64];
+          for (int b = 0; b * 8 < T; ++b) {
+            const double* nxt = my_cc + (size_t)min((b + 1) * 8, Tp - 8) * 64;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vb[j] = nxt[(size_t)j * 64];
+            if (b * 8 + 8 <= T) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) cost = (float)((double)cost + va[j]);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (b * 8 + j < T) cost = (float)((double)cost + va[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) va[j] = vb[j];
+          }
+        } else {
+          __threadfence_block();
+          const double* my_cc = cc_scratch + (live ? tile_base : (size_t)lane);
+          for (int t0 = 0; t0 < T; t0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = my_cc[(size_t)min(t0 + j, T - 1) * 64];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (t0 + j < T) cost = (float)((double)cost + v[j]);
+          }
+        }
+        MPPI_STAMP(stamp_wg, stamp_base + 31);
+        if (live) costs[n] = cost;
+        // first half of the control update (update_kernels.h): weights relative to the tile's minimum
+        if (tile_ok) emit_tile_weights(cost, live, Q.lambda, n, tile, w_rel, tile_beta);
+      }
+    }
+    if (outcome == 2) return;  // the assumption held to the end
+    exact = true;               // abandoned: every wave arrives here after the same barrier
+  }
+  // ================================================================== exact schedule (k_rollout_pipe)
+  if (wave >= 3) return;
+  pipe_tile_body<8, POW2RES, CC_LDS>(P, cells16, noise, u, costs, w_rel, tile_beta, cc_scratch, map_bytes, 1);
+}
+
+}  // namespace mppi

@@ -477,26 +477,16 @@ struct PipeRing {
 //   cost      costs chunk k-1 from ring_xy; afterwards terminal + control costs.
 // Tile-major arrays: element (t, n) of noise / cc_scratch lives at
 // ((n / 64) * T + t) * 64 + n % 64, i.e. the T x 64 block of one wave is contiguous.
+// The three cooperating roles of one workgroup of the pipelined rollout (threads [0, 192*W)): the
+// whole kernel below after its noise-generating workgroups have branched off, and the exact
+// re-execution path of k_rollout_deep (rollout_deep_kernel.h) after a failed speculation.
 template <int C, bool POW2RES, bool CC_LDS>
-__global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16,
-                               const float2* __restrict__ noise, const float2* __restrict__ u,
-                               float* __restrict__ costs, float* __restrict__ w_rel,
-                               float* __restrict__ tile_beta, double* __restrict__ cc_scratch, int map_bytes,
-                               int n_rollout_blocks, NoiseJob next_noise) {
+__device__ __forceinline__ void pipe_tile_body(DevParams P, const uint16_t* __restrict__ cells16,
+                                               const float2* __restrict__ noise, const float2* __restrict__ u,
+                                               float* __restrict__ costs, float* __restrict__ w_rel,
+                                               float* __restrict__ tile_beta, double* __restrict__ cc_scratch,
+                                               int map_bytes, const int W) {
   extern __shared__ double2 uos[];
-  if ((int)blockIdx.x >= n_rollout_blocks) {
-    // spare workgroups: the noise of the NEXT iteration, into the other noise buffer.
-    // (Also giving every rollout group a fourth, noise-generating wave was measured: the
-    // extra waves on the rollout CUs cost the critical waves more than they saved.)
-    MPPI_STAMP(threadIdx.x == 0 && ((int)blockIdx.x == n_rollout_blocks || blockIdx.x == gridDim.x - 1),
-               (int)blockIdx.x == n_rollout_blocks ? 16 : 18);
-    if (next_noise.out)
-      noise_generate(next_noise, (blockIdx.x - n_rollout_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6),
-                     (gridDim.x - n_rollout_blocks) * (blockDim.x >> 6));
-    MPPI_STAMP(threadIdx.x == 0 && ((int)blockIdx.x == n_rollout_blocks || blockIdx.x == gridDim.x - 1),
-               (int)blockIdx.x == n_rollout_blocks ? 17 : 19);
-    return;
-  }
   [[maybe_unused]] const bool stamp_wg = blockIdx.x == 5;
   MPPI_STAMP(stamp_wg && threadIdx.x == 0, 0);
   // these few waves are the critical path of the iteration; the noise of the NEXT
@@ -505,11 +495,10 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
   __builtin_amdgcn_s_setprio(3);
   const int T = P.n_steps, N = P.n_local;
   // batched handle: all triples of a workgroup belong to one problem (host: W divides inst_tiles)
-  u = select_instance(P, u, P.inst ? (int)(blockIdx.x * (blockDim.x / 192)) / P.inst_tiles : 0);
+  u = select_instance(P, u, P.inst ? (int)(blockIdx.x * W) / P.inst_tiles : 0);
   float2* us = reinterpret_cast<float2*>(uos + T);
   uint16_t* lds_map = reinterpret_cast<uint16_t*>(uos + T + (T + 1) / 2);
   char* ring_base = reinterpret_cast<char*>(lds_map) + map_bytes;
-  const int W = blockDim.x / 192;  // triples per workgroup
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int role = wave / W;  // 0 state, 1 cost, 2 producer
   const int triple = wave - role * W;
@@ -705,6 +694,29 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
     if (tile * 64 < N) emit_tile_weights(cost, live, P.lambda, n, tile, w_rel, tile_beta);
     MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 42);
   }
+}
+
+template <int C, bool POW2RES, bool CC_LDS>
+__global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16,
+                               const float2* __restrict__ noise, const float2* __restrict__ u,
+                               float* __restrict__ costs, float* __restrict__ w_rel,
+                               float* __restrict__ tile_beta, double* __restrict__ cc_scratch, int map_bytes,
+                               int n_rollout_blocks, NoiseJob next_noise) {
+  if ((int)blockIdx.x >= n_rollout_blocks) {
+    // spare workgroups: the noise of the NEXT iteration, into the other noise buffer.
+    // (Also giving every rollout group a fourth, noise-generating wave was measured: the
+    // extra waves on the rollout CUs cost the critical waves more than they saved.)
+    MPPI_STAMP(threadIdx.x == 0 && ((int)blockIdx.x == n_rollout_blocks || blockIdx.x == gridDim.x - 1),
+               (int)blockIdx.x == n_rollout_blocks ? 16 : 18);
+    if (next_noise.out)
+      noise_generate(next_noise, (blockIdx.x - n_rollout_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6),
+                     (gridDim.x - n_rollout_blocks) * (blockDim.x >> 6));
+    MPPI_STAMP(threadIdx.x == 0 && ((int)blockIdx.x == n_rollout_blocks || blockIdx.x == gridDim.x - 1),
+               (int)blockIdx.x == n_rollout_blocks ? 17 : 19);
+    return;
+  }
+  pipe_tile_body<C, POW2RES, CC_LDS>(P, cells16, noise, u, costs, w_rel, tile_beta, cc_scratch, map_bytes,
+                                     (int)blockDim.x / 192);
 }
 
 // Bitonic sort of the workgroup's LDS array sc[0..m_pow2), descending (mppi.py:716-741 sorts

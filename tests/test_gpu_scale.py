@@ -44,7 +44,7 @@ def oracle_costs(w, params, lin, ang, noise, u):
 
 
 # which rollout kernel each BASELINE configuration must take (bench.py runs the same objects)
-EXPECTED_KERNEL = {"c2": "k_rollout_spec", "c3": "k_rollout_tdm_fast", "c4": "k_rollout_fused"}
+EXPECTED_KERNEL = {"c2": "k_rollout_deep", "c3": "k_rollout_tdm_fast", "c4": "k_rollout_fused"}
 U_MARGINS = {}  # workload -> achieved max |du| / control range (printed by the last test of the file)
 
 
@@ -310,36 +310,53 @@ def custom_world(rows, cols, res, seed):
     return pmf, obstacle, unknown, td
 
 
-@pytest.mark.parametrize("label,rows,cols,res,n,t_steps,x0,pad_speed,expect", [
-    ("non power-of-two resolution: exact floor division", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0,
-     ["k_rollout_spec", "pow2res=0"]),
-    ("resolution 0.1: cell borders every few float32 ulps", 200, 200, 0.1, 2048, 80, (7.33, 8.21, -2.0), 3.0,
-     ["k_rollout_spec", "pow2res=0", "cc_lds=0"]),  # 86 KiB window + 60 KiB of rings: the products go to global
-    ("two tiles per workgroup", 256, 256, 0.25, 32768, 40, (20.0, 30.0, 0.3), 5.0,
+# (label, rows, cols, res, N, T, x0, padding speed, debug flags, tokens expected in the kernel description)
+NO_SPEC_KERNEL, NO_SPECULATION, NO_DEEP, CC_GLOBAL = 1, 2, 4, 8
+@pytest.mark.parametrize("label,rows,cols,res,n,t_steps,x0,pad_speed,flags,expect", [
+    # one tile per CU: the 11-wave speculative pipeline (random PMF worlds: the vote fails at once and the
+    # tile is re-executed on the exact schedule -- the speculation itself is exercised by
+    # test_speculation_holds_then_fails_same_bits)
+    ("deep: non power-of-two resolution", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0, 0,
+     ["k_rollout_deep", "pow2res=0", "cc_lds=1"]),
+    ("deep: resolution 0.1, 86 KiB window: chunks of 4", 200, 200, 0.1, 2048, 80, (7.33, 8.21, -2.0), 3.0, 0,
+     ["k_rollout_deep", "pow2res=0", "chunk=4", "cc_lds=1"]),
+    ("deep: products in global scratch", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0, CC_GLOBAL,
+     ["k_rollout_deep", "cc_lds=0"]),
+    ("spec: products in global scratch", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0, CC_GLOBAL | NO_DEEP,
+     ["k_rollout_spec", "cc_lds=0"]),
+    ("deep: exact schedule from the first step", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0, NO_SPECULATION,
+     ["k_rollout_deep", "speculate=0"]),
+    ("whole-map window too large for the deep kernel's rings: 4-wave speculative kernel", 270, 250, 0.25, 2048, 200,
+     (30.0, 33.0, 0.0), 5.0, 0, ["k_rollout_spec", "cc_lds=0", "window=274x"]),
+    # the 4-wave speculative kernel (two tiles per CU, or forced)
+    ("spec: non power-of-two resolution", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0, NO_DEEP,
+     ["k_rollout_spec", "pow2res=0", "tiles_per_wg=1"]),
+    ("spec: resolution 0.1: cell borders every few float32 ulps", 200, 200, 0.1, 2048, 80, (7.33, 8.21, -2.0), 3.0, NO_DEEP,
+     ["k_rollout_spec", "pow2res=0", "cc_lds=0"]),
+    ("spec: two tiles per workgroup", 256, 256, 0.25, 32768, 40, (20.0, 30.0, 0.3), 5.0, 0,
      ["k_rollout_spec", "tiles_per_wg=2"]),
-    ("three tiles per CU, ragged last tile: the pipelined kernel", 256, 256, 0.25, 49152 - 37, 40, (20.0, 30.0, 0.3), 5.0,
+    ("spec: exact schedule, non power-of-two resolution", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0,
+     NO_DEEP | NO_SPECULATION, ["k_rollout_spec", "pow2res=0", "speculate=0"]),
+    ("spec: exact schedule, two tiles per workgroup, ragged last tile", 256, 256, 0.25, 32768 - 37, 40,
+     (20.0, 30.0, 0.3), 5.0, NO_SPECULATION, ["k_rollout_spec", "tiles_per_wg=2", "speculate=0"]),
+    # the 3-wave pipelined kernel (three tiles per CU, or forced)
+    ("pipe: three tiles per CU, ragged last tile", 256, 256, 0.25, 49152 - 37, 40, (20.0, 30.0, 0.3), 5.0, 0,
      ["k_rollout_pipe", "triples_per_wg=3"]),
-    ("throughput regime: fused kernel on the LDS window, 4 waves per CU", 256, 256, 0.25, 65536, 40,
-     (20.0, 30.0, 0.3), 5.0, ["k_rollout_fused", "waves_per_wg=4"]),
-    ("throughput regime, long horizon: whole-map window, 8 waves per CU", 256, 256, 0.25, 131072, 120,
-     (30.0, 30.0, 0.3), 5.0, ["k_rollout_fused", "waves_per_wg=8", "window=260x264"]),
-    ("reach window larger than LDS: global 32-bit cell path", 700, 700, 0.05, 2048, 100, (17.0, 18.0, 1.0), 3.0,
-     ["k_rollout_map det global_cells"]),
-    ("whole-map window, control-cost products in global scratch", 270, 250, 0.25, 2048, 200, (30.0, 33.0, 0.0), 5.0,
-     ["k_rollout_spec", "cc_lds=0", "window=274x"]),
-    # the same regimes on the exact schedule of the speculative kernel and on its predecessor
-    ("no speculation: non power-of-two resolution", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0,
-     ["k_rollout_spec", "pow2res=0", "speculate=0"]),
-    ("no speculation: two tiles per workgroup, ragged last tile", 256, 256, 0.25, 32768 - 37, 40, (20.0, 30.0, 0.3), 5.0,
-     ["k_rollout_spec", "tiles_per_wg=2", "speculate=0"]),
-    ("pipelined kernel: non power-of-two resolution", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0,
+    ("pipe: non power-of-two resolution", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0, NO_SPEC_KERNEL,
      ["k_rollout_pipe", "pow2res=0"]),
-    ("pipelined kernel: two wave triples per workgroup", 256, 256, 0.25, 32768, 40, (20.0, 30.0, 0.3), 5.0,
+    ("pipe: two wave triples per workgroup", 256, 256, 0.25, 32768, 40, (20.0, 30.0, 0.3), 5.0, NO_SPEC_KERNEL,
      ["k_rollout_pipe", "triples_per_wg=2"]),
-    ("pipelined kernel: whole-map window, control-cost products in global scratch", 270, 250, 0.25, 2048, 200,
-     (30.0, 33.0, 0.0), 5.0, ["k_rollout_pipe", "cc_lds=0", "window=274x"]),
+    ("pipe: whole-map window, control-cost products in global scratch", 270, 250, 0.25, 2048, 200,
+     (30.0, 33.0, 0.0), 5.0, NO_SPEC_KERNEL, ["k_rollout_pipe", "cc_lds=0", "window=274x"]),
+    # throughput regime and general fallbacks
+    ("throughput regime: fused kernel on the LDS window, 4 waves per CU", 256, 256, 0.25, 65536, 40,
+     (20.0, 30.0, 0.3), 5.0, 0, ["k_rollout_fused", "waves_per_wg=4"]),
+    ("throughput regime, long horizon: whole-map window, 8 waves per CU", 256, 256, 0.25, 131072, 120,
+     (30.0, 30.0, 0.3), 5.0, 0, ["k_rollout_fused", "waves_per_wg=8", "window=260x264"]),
+    ("reach window larger than LDS: global 32-bit cell path", 700, 700, 0.05, 2048, 100, (17.0, 18.0, 1.0), 3.0, 0,
+     ["k_rollout_map det global_cells"]),
 ])
-def test_det_rollout_variants_vs_oracle(label, rows, cols, res, n, t_steps, x0, pad_speed, expect):
+def test_det_rollout_variants_vs_oracle(label, rows, cols, res, n, t_steps, x0, pad_speed, flags, expect):
     """Every code path of the deterministic rollout (pipelined / fused, LDS window kinds,
     chunk sizes, exact floor division) against the oracle on random PMF worlds."""
     from mppi_numba_amd.config import Config
@@ -355,9 +372,7 @@ def test_det_rollout_variants_vs_oracle(label, rows, cols, res, n, t_steps, x0, 
     lin.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)
     ang.set_TDM_from_PMF_grid(pmf[:, ::-1].copy(), td, obstacle, unknown)
     planner = MPPI_Numba(cfg)
-    from mppi_numba_amd import _lib
-    planner.set_debug_flags((_lib.DEBUG_NO_SPEC_KERNEL if "k_rollout_pipe" in expect else 0) |
-                            (_lib.DEBUG_NO_SPECULATION if "speculate=0" in expect else 0))
+    planner.set_debug_flags(flags)
     params = bench.make_params("c2")
     params.update(x0=np.array(x0), xgoal=np.array([x0[0] + 3.0, x0[1] + 2.0]), lambda_weight=5.0)
     planner.setup(params, lin, ang)
@@ -398,6 +413,8 @@ def patch_world(rows, cols, res, kind, seed):
         ang_which[outside & (xx > cols / 2)] = 7
     elif kind == "stripes":
         which[(xx // int(2.0 / res)) % 2 == 1] = 4
+    # "ring": uniform traction, but the start is 1.5 m from the map border: many rollouts end in the
+    # zero-traction padding ring, where the speculative kernels freeze them instead of giving up
     pmf = np.zeros((bins, rows, cols), dtype=np.int8)
     ang_pmf = np.zeros((bins, rows, cols), dtype=np.int8)
     np.put_along_axis(pmf, which[None], 100, axis=0)
@@ -409,9 +426,10 @@ def patch_world(rows, cols, res, kind, seed):
     return pmf, ang_pmf, obstacle, unknown, td
 
 
-@pytest.mark.parametrize("flags", [0, 2, 1])
+@pytest.mark.parametrize("flags", [0, 4, 2, 6, 1, 8, 12])
 @pytest.mark.parametrize("kind,t_steps,n", [("uniform", 100, 8192), ("far", 100, 8192), ("near", 100, 4096),
-                                            ("stripes", 60, 8192), ("far", 37, 2048 + 5), ("far", 200, 16384 + 64)])
+                                            ("stripes", 60, 8192), ("far", 37, 2048 + 5), ("far", 200, 16384 - 64),
+                                            ("far", 50, 32768 - 64), ("ring", 100, 8192), ("ring", 26, 1024)])
 def test_speculation_holds_then_fails_same_bits(kind, t_steps, n, flags):
     """k_rollout_spec assumes the start cell's traction bytes everywhere and falls back, per tile
     and from the start of the offending chunk, when a lookup says otherwise: costs must be those
@@ -433,6 +451,8 @@ def test_speculation_holds_then_fails_same_bits(kind, t_steps, n, flags):
     planner.set_debug_flags(flags)
     params = bench.make_params("c2")
     params.update(x0=np.array([25.1, 24.9, 0.7]), xgoal=np.array([40.0, 38.0]), lambda_weight=5.0)
+    if kind == "ring":
+        params.update(x0=np.array([1.6, 48.4, 2.5]), xgoal=np.array([20.0, 30.0]))
     planner.setup(params, lin, ang)
     planner.solve()
     planner.iterate_async(2)
@@ -441,9 +461,12 @@ def test_speculation_holds_then_fails_same_bits(kind, t_steps, n, flags):
     noise, u_in = planner.noise_samples_d.copy_to_host(), planner.u_cur_d.copy_to_host()
     planner.rollout()
     kernel = planner.last_rollout_kernel()
-    assert ("k_rollout_pipe" if flags == 1 else "k_rollout_spec speculate=%d" % (0 if flags else 1)).split()[0] in kernel
-    if flags != 1:
-        assert "speculate=%d" % (0 if flags else 1) in kernel, kernel
+    tiles = -(-n // 64)
+    want_kernel = ("k_rollout_pipe" if flags & 1 else
+                   "k_rollout_deep" if tiles <= 256 and not flags & 4 else "k_rollout_spec")
+    assert kernel.startswith(want_kernel), kernel
+    if not flags & 1:
+        assert "speculate=%d" % (0 if flags & 2 else 1) in kernel, kernel
     got = planner.costs_d.copy_to_host()
     want = oracle_costs(dict(m=1), params, lin, ang, noise, u_in)
     ulps = ulp_diff_f32(got, want)
@@ -557,7 +580,7 @@ def test_update_from_costs_has_the_bits_of_the_epilogue_path():
     a.sample_noise()
     noise = a.noise_samples_d.copy_to_host()
     a.rollout()
-    assert "k_rollout_spec" in a.last_rollout_kernel()
+    assert "k_rollout_deep" in a.last_rollout_kernel()
     costs = a.costs_d.copy_to_host()
     a.update()
     b.set_u(u_in)

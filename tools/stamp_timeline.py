@@ -47,6 +47,31 @@ def main():
     t0 = st[0]
     rel = lambda v: int(v - t0) if v else None
     out = {"rollout": {}, "update": {}, "noise_wg": {}}
+    if "k_rollout_deep" in planner.last_rollout_kernel():
+        names = ["P", "H", "S", "C", "V"]
+        print("k_rollout_deep, workgroup 5: per wave [before first barrier, after it, arrival at the barrier of "
+              "intervals 0.., (C) tail begin, tail end]; cycles from the workgroup's first stamp")
+        arr = {}
+        for w, name in enumerate(names):
+            row = st[64 + 32 * w: 64 + 32 * w + 32]
+            vals = [rel(v) for v in row]
+            out["rollout"][name] = vals
+            arr[name] = [v for v in vals[2:26] if v is not None]
+            print("  %-2s" % name, vals)
+        n_iv = min(len(a) for a in arr.values())
+        release = [max(arr[nm][i] for nm in names) for i in range(n_iv)]
+        print("  barrier releases:", release)
+        print("  interval lengths:", [b - a for a, b in zip(release[:-1], release[1:])])
+        for nm in names:
+            print("  work of %-2s per interval (arrival - previous release):" % nm,
+                  [arr[nm][i] - release[i - 1] for i in range(1, n_iv)])
+        u = st[512:520]
+        out["update"] = [int(v - u[0]) if v else None for v in u]
+        print("update kernel (middle WG) phases, cycles from its entry:", out["update"])
+        if args.json:
+            with open(args.json, "w") as fh:
+                json.dump(out, fh)
+        return
     names = sorted({int(i) // 64 for i in np.flatnonzero(st[64:512]) + 64})
     for r in names:
         base = 64 * r
