@@ -212,7 +212,8 @@ int mppi_planner_set_disc_obstacles(mppi_planner* p, const float* positions, con
  * handle given the same noise.  Array shapes with B > 1: u (B,T,2), costs and
  * weights (B,N_local), noise (B*N_local,T,2), packets B*(2T+2) doubles per rank.
  * Needs N/world_size to be a multiple of 64; not available in MPPI_MODE_BAREBONE.
- * x0: (count,3) float32, xgoal: (count,2) float32; count must equal B. */
+ * x0: (count,3) float32, xgoal: (count,2) float32; count must equal B.  A handle with B = 1
+ * also takes count = 0 (x0, xgoal ignored): back to the start / goal of mppi_params. */
 int mppi_planner_set_instances(mppi_planner* p, int count, const float* x0, const float* xgoal);
 
 /* mppi.py:539-542 shift_optimal_control_sequence / mppi.py:305,375 copy_to_host */
@@ -296,6 +297,43 @@ int mppi_planner_graph_stats(mppi_planner* p, long* captures, long* replays);
  * times each.  Replays reuse the captured arguments: a measurement, not a way to plan. */
 int mppi_planner_graph_probe(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int iterations, int replays,
                              float* us_direct, float* us_graph);
+
+/* ---- the simulated world of the closed-loop demo, on the device ------
+ * mppi_world replaces TractionGrid (terrain.py:750-785): float64 (rows, cols) grids of linear and
+ * angular traction, resolution and lower limits as in its constructor (terrain.py:754-773).
+ *   create            TractionGrid.__init__; lin / ang may be NULL (zeros) when the grids are drawn
+ *                     on the device afterwards
+ *   get               TractionGrid.get (terrain.py:776-782) for `count` points xy[count][2]:
+ *                     the cell's (lin, ang), (0, 0) outside the grid; Python's float // rule
+ *   get_grids         TractionGrid.get_grids (terrain.py:784-785)
+ *   sample_true_dist  TDM_Numba.sample_grids_true_dist (terrain.py:586-608): every cell draws from
+ *                     the densities of its terrain type, linear and angular independently.  The
+ *                     densities are host objects; the device draws uniformly (Philox4x32-10 keyed by
+ *                     seed, counter = cell index and call number) from the pools of samples every
+ *                     Terrain keeps (terrain.py:44-46): lin_pool / ang_pool [n_terrains][pool_len],
+ *                     terrain_of_cell [rows*cols] = row of the pools for each cell.               */
+typedef struct mppi_world mppi_world;
+int mppi_world_create(int device, int rows, int cols, double res, double xlo, double ylo, const double* lin,
+                      const double* ang, mppi_world** out);
+int mppi_world_destroy(mppi_world* w);
+int mppi_world_get(mppi_world* w, const double* xy, int count, double* lin_out, double* ang_out);
+int mppi_world_get_grids(mppi_world* w, double* lin, double* ang);
+int mppi_world_sample_true_dist(mppi_world* w, const int32_t* terrain_of_cell, int n_terrains, const double* lin_pool,
+                                const double* ang_pool, int pool_len, uint64_t seed);
+/* The notebooks' closed loop (test.ipynb cell 4: solve -> TractionGrid.get -> float64 Euler step ->
+ * shift_and_update(x_new, useq, 1) -> goal check) for every problem of a batched handle
+ * (set_instances, count >= 1), max_steps times or until every problem is within goal_tolerance of
+ * its goal, without a host round trip per control step: the new start state, the LDS window
+ * origin and the shifted control sequence are written by a kernel on the planner's stream.
+ *   dt     the world's Euler step (cfg.dt as the notebook uses it, float64); <= 0: params.dt
+ *   x_init [B][3] float64 start states (NULL: the instances' float32 start states)
+ *   xhist  [B][max_steps+1][3] float64, row 0 = start, rows never reached = NaN
+ *   uhist  [B][max_steps][2]   float32, the control applied at every step (NaN likewise)
+ *   steps_taken [B]            steps until the goal test passed (or the number of steps run)
+ * Afterwards the handle is where the notebook's loop would have left it (start states, shifted u). */
+int mppi_planner_closed_loop(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, mppi_world* w, int max_steps,
+                             double dt, double goal_tolerance, const double* x_init, double* xhist, float* uhist,
+                             int* steps_taken);
 
 /* ---- multi-GPU: N sharded over ranks, one RCCL all-gather of (2T+2) floats
  *      per iteration (not in the reference) ------------------------------------ */

@@ -23,6 +23,7 @@
 #include "rollout_deep_kernel.h"
 #include "map_kernels.h"
 #include "update_kernels.h"
+#include "world_kernels.h"
 
 using namespace mppi;
 
@@ -665,6 +666,14 @@ struct mppi_planner {
   int last_iterations = 0;
   // comm
   ncclComm_t comm = nullptr;
+  // closed loop on the device (mppi_planner_closed_loop): world state, trajectory log
+  double* loop_state = nullptr;   // [B][3]
+  double* loop_xhist = nullptr;   // [B][loop_capacity + 1][3]
+  float2* loop_uhist = nullptr;   // [B][loop_capacity]
+  int* loop_done = nullptr;       // [B]
+  int* loop_done_count = nullptr;      // pinned, device-mapped
+  int* loop_done_count_dev = nullptr;  // device view of the same int
+  int loop_capacity = 0;
 };
 
 static void drop_graphs(mppi_planner* p) {
@@ -705,6 +714,11 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   dev_free(p->obs_pos);
   dev_free(p->obs_r);
   dev_free(p->state_rollout);
+  dev_free(p->loop_state);
+  dev_free(p->loop_xhist);
+  dev_free(p->loop_uhist);
+  dev_free(p->loop_done);
+  if (p->loop_done_count) (void)hipHostFree(p->loop_done_count);
   if (p->ev_begin) (void)hipEventDestroy(p->ev_begin);
   if (p->ev_end) (void)hipEventDestroy(p->ev_end);
   for (auto& e : p->ev_stage)
@@ -929,7 +943,14 @@ extern "C" int mppi_planner_shift_u(mppi_planner* p, int k) {
 // shared through mppi_params).  With count == 1 a single-problem handle takes the same
 // kernel path as a batch (the parity tests compare the two).
 extern "C" int mppi_planner_set_instances(mppi_planner* p, int count, const float* x0, const float* xgoal) {
-  REQUIRE(p && x0 && xgoal, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(p, MPPI_ERR_INVALID, "NULL argument");
+  if (count == 0 && p->B == 1) {  // a single-problem handle goes back to the start / goal of mppi_params
+    if (p->inst_set) drop_graphs(p);
+    p->inst_set = false;
+    p->inst_dirty = false;
+    return MPPI_OK;
+  }
+  REQUIRE(x0 && xgoal, MPPI_ERR_INVALID, "NULL argument");
   REQUIRE(count == p->B, MPPI_ERR_INVALID, "count %d != num_instances %d of this handle", count, p->B);
   REQUIRE(p->cfg.mode != MPPI_MODE_BAREBONE, MPPI_ERR_INVALID, "no instances in the barebone mode");
   for (int b = 0; b < count; ++b) {
@@ -1935,29 +1956,258 @@ extern "C" int mppi_planner_synchronize(mppi_planner* p) {
   return finish_timing(p);
 }
 
+// grids are sampled once per solve(), not per optimisation iteration
+// (mppi.py:247-248, 321-322, 391-394); the deterministic modes pass alpha_dyn = 1
+static int sample_for_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang) {
+  if (p->cfg.mode == MPPI_MODE_BAREBONE) return MPPI_OK;
+  double alpha = (p->cfg.mode == MPPI_MODE_TDM) ? p->params.alpha_dyn : 1.0;
+  int rc = MPPI_OK;
+  if (sample_into_cells(p, lin, ang, alpha, &rc)) return rc;
+  TRY(tdm_sample_on(lin, alpha, p->stream));
+  TRY(tdm_sample_on(ang, alpha, p->stream));
+  return MPPI_OK;
+}
+
 extern "C" int mppi_planner_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, float* u_out) {
   REQUIRE(p && u_out, MPPI_ERR_INVALID, "NULL argument");
   REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
   HIP_TRY(hipSetDevice(p->cfg.device));
   TRY(check_tdms(p, lin, ang));
-  if (p->cfg.mode != MPPI_MODE_BAREBONE) {
-    // grids are sampled once per solve(), not per optimisation iteration
-    // (mppi.py:247-248, 321-322, 391-394); the deterministic modes pass alpha_dyn = 1
-    double alpha = (p->cfg.mode == MPPI_MODE_TDM) ? p->params.alpha_dyn : 1.0;
-    int rc = MPPI_OK;
-    if (sample_into_cells(p, lin, ang, alpha, &rc)) {
-      TRY(rc);
-    } else {
-      TRY(tdm_sample_on(lin, alpha, p->stream));
-      TRY(tdm_sample_on(ang, alpha, p->stream));
-    }
-  }
+  TRY(sample_for_solve(p, lin, ang));
   TRY(run_iterations(p, lin, ang, p->params.num_opt, /*timed=*/false));
   const size_t u_bytes = sizeof(float2) * (size_t)p->B * (size_t)p->cfg.num_steps;
   // with at least one iteration the last update kernel has written the host-mapped mirror
   if (p->params.num_opt < 1) HIP_TRY(hipMemcpyAsync(p->u_host, p->u, u_bytes, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   memcpy(u_out, p->u_host, u_bytes);
+  return finish_timing(p);
+}
+
+// ---- the simulated world on the device (terrain.py:586-608, 750-785) -------
+struct mppi_world {
+  int device = 0;
+  int rows = 0, cols = 0;
+  double res = 1.0, xlo = 0.0, ylo = 0.0;
+  double* lin = nullptr;
+  double* ang = nullptr;
+  uint64_t draws = 0;  // sample_true_dist calls so far (Philox counter word)
+};
+
+static WorldGrid world_grid(const mppi_world* w) {
+  WorldGrid g;
+  g.lin = w->lin; g.ang = w->ang; g.rows = w->rows; g.cols = w->cols;
+  g.res = w->res; g.xlo = w->xlo; g.ylo = w->ylo;
+  return g;
+}
+
+extern "C" int mppi_world_destroy(mppi_world* w) {
+  if (!w) return MPPI_OK;
+  (void)hipSetDevice(w->device);
+  dev_free(w->lin);
+  dev_free(w->ang);
+  delete w;
+  return MPPI_OK;
+}
+
+extern "C" int mppi_world_create(int device, int rows, int cols, double res, double xlo, double ylo,
+                                 const double* lin, const double* ang, mppi_world** out) {
+  REQUIRE(out, MPPI_ERR_INVALID, "NULL out");
+  REQUIRE(rows > 0 && cols > 0 && (long)rows * cols < (1L << 30), MPPI_ERR_INVALID, "bad grid shape %d x %d", rows, cols);
+  REQUIRE(res > 0.0 && std::isfinite(res) && std::isfinite(xlo) && std::isfinite(ylo), MPPI_ERR_INVALID,
+          "bad resolution / limits");
+  int count = 0;
+  TRY(mppi_device_count(&count));
+  REQUIRE(device >= 0 && device < count, MPPI_ERR_NO_DEVICE, "device %d of %d", device, count);
+  HIP_TRY(hipSetDevice(device));
+  mppi_world* w = new mppi_world();
+  w->device = device; w->rows = rows; w->cols = cols; w->res = res; w->xlo = xlo; w->ylo = ylo;
+  const size_t cells = (size_t)rows * cols;
+  int rc = dev_alloc(&w->lin, cells);
+  if (rc == MPPI_OK) rc = dev_alloc(&w->ang, cells);
+  if (rc != MPPI_OK) { mppi_world_destroy(w); return rc; }
+  hipError_t e = hipSuccess;
+  if (lin) e = hipMemcpy(w->lin, lin, cells * sizeof(double), hipMemcpyHostToDevice);
+  else e = hipMemset(w->lin, 0, cells * sizeof(double));
+  if (e == hipSuccess) {
+    if (ang) e = hipMemcpy(w->ang, ang, cells * sizeof(double), hipMemcpyHostToDevice);
+    else e = hipMemset(w->ang, 0, cells * sizeof(double));
+  }
+  if (e != hipSuccess) { mppi_world_destroy(w); HIP_TRY(e); }
+  *out = w;
+  return MPPI_OK;
+}
+
+extern "C" int mppi_world_get_grids(mppi_world* w, double* lin, double* ang) {
+  REQUIRE(w && lin && ang, MPPI_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t bytes = (size_t)w->rows * w->cols * sizeof(double);
+  HIP_TRY(hipMemcpy(lin, w->lin, bytes, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(ang, w->ang, bytes, hipMemcpyDeviceToHost));
+  return MPPI_OK;
+}
+
+extern "C" int mppi_world_get(mppi_world* w, const double* xy, int count, double* lin_out, double* ang_out) {
+  REQUIRE(w && xy && lin_out && ang_out, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(count >= 0, MPPI_ERR_INVALID, "count < 0");
+  if (count == 0) return MPPI_OK;
+  HIP_TRY(hipSetDevice(w->device));
+  double *xy_d = nullptr, *out_d = nullptr;
+  TRY(dev_alloc(&xy_d, (size_t)2 * count));
+  int rc = dev_alloc(&out_d, (size_t)2 * count);
+  if (rc != MPPI_OK) { dev_free(xy_d); return rc; }
+  hipError_t e = hipMemcpy(xy_d, xy, sizeof(double) * 2 * (size_t)count, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_world_get, dim3(ceil_div(count, 256)), dim3(256), 0, 0, world_grid(w), xy_d, count, out_d,
+                       out_d + count);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(lin_out, out_d, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(ang_out, out_d + count, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost);
+  dev_free(xy_d);
+  dev_free(out_d);
+  HIP_TRY(e);
+  return MPPI_OK;
+}
+
+extern "C" int mppi_world_sample_true_dist(mppi_world* w, const int32_t* terrain_of_cell, int n_terrains,
+                                           const double* lin_pool, const double* ang_pool, int pool_len,
+                                           uint64_t seed) {
+  REQUIRE(w && terrain_of_cell && lin_pool && ang_pool, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(n_terrains > 0 && pool_len > 0, MPPI_ERR_INVALID, "empty terrain table");
+  HIP_TRY(hipSetDevice(w->device));
+  const int cells = w->rows * w->cols;
+  int32_t* ids = nullptr;
+  double* pools = nullptr;
+  const size_t pool_count = (size_t)n_terrains * pool_len;
+  TRY(dev_alloc(&ids, (size_t)cells));
+  int rc = dev_alloc(&pools, 2 * pool_count);
+  if (rc != MPPI_OK) { dev_free(ids); return rc; }
+  hipError_t e = hipMemcpy(ids, terrain_of_cell, sizeof(int32_t) * (size_t)cells, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(pools, lin_pool, sizeof(double) * pool_count, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(pools + pool_count, ang_pool, sizeof(double) * pool_count, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_world_sample, dim3(ceil_div(cells, 256)), dim3(256), 0, 0, ids, cells, n_terrains, pools,
+                       pools + pool_count, pool_len, seed, w->draws, w->lin, w->ang);
+    e = hipGetLastError();
+    ++w->draws;
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  dev_free(ids);
+  dev_free(pools);
+  HIP_TRY(e);
+  return MPPI_OK;
+}
+
+// The notebooks' closed loop (test.ipynb cell 4) for every problem of a batched handle, without a
+// host round trip per control step: {sample grids, num_opt iterations, k_world_step} x max_steps,
+// all on the planner's stream.  The host looks at a device-mapped counter every `check_every`
+// steps and stops once every problem has reached its goal.
+extern "C" int mppi_planner_closed_loop(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, mppi_world* w, int max_steps,
+                                        double dt, double goal_tolerance, const double* x_init, double* xhist, float* uhist,
+                                        int* steps_taken) {
+  REQUIRE(p && w && xhist && uhist && steps_taken, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
+  REQUIRE(p->inst_set, MPPI_ERR_STATE, "closed_loop needs per-problem start states (mppi_planner_set_instances)");
+  REQUIRE(p->cfg.world_size == 1, MPPI_ERR_STATE, "closed_loop drives an unsharded handle");
+  REQUIRE(w->device == p->cfg.device, MPPI_ERR_INVALID, "world on device %d, planner on %d", w->device, p->cfg.device);
+  REQUIRE(max_steps >= 1 && max_steps <= (1 << 20), MPPI_ERR_INVALID, "max_steps %d", max_steps);
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  TRY(check_tdms(p, lin, ang));
+  const int B = p->B, T = p->cfg.num_steps;
+  if (!p->loop_done_count) {
+    HIP_TRY(hipHostMalloc((void**)&p->loop_done_count, sizeof(int), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void**)&p->loop_done_count_dev, p->loop_done_count, 0));
+    TRY(dev_alloc(&p->loop_state, (size_t)3 * B));
+    TRY(dev_alloc(&p->loop_done, (size_t)B));
+  }
+  if (max_steps > p->loop_capacity) {
+    dev_free(p->loop_xhist);
+    dev_free(p->loop_uhist);
+    p->loop_capacity = 0;
+    TRY(dev_alloc(&p->loop_xhist, (size_t)3 * B * ((size_t)max_steps + 1)));
+    TRY(dev_alloc(&p->loop_uhist, (size_t)B * (size_t)max_steps));
+    p->loop_capacity = max_steps;
+  }
+  // initial state and log (rows never reached stay NaN, as in the notebook's np.zeros(...)*np.nan)
+  const size_t rows = (size_t)max_steps + 1;
+  std::vector<double> x0((size_t)3 * B);
+  for (int b = 0; b < B; ++b)
+    for (int k = 0; k < 3; ++k)
+      x0[(size_t)3 * b + k] = x_init ? x_init[3 * b + k]
+                                     : (double)(k == 0 ? p->inst_host[b].x0 : (k == 1 ? p->inst_host[b].y0 : p->inst_host[b].th0));
+  if (x_init) {  // the planner sees the float32 of the float64 state (mppi.py:214-234)
+    for (int b = 0; b < B; ++b) {
+      p->inst_host[b].x0 = (float)x_init[3 * b]; p->inst_host[b].y0 = (float)x_init[3 * b + 1];
+      p->inst_host[b].th0 = (float)x_init[3 * b + 2];
+    }
+    p->inst_dirty = true;
+  }
+  const double nan = std::nan("");
+  for (size_t i = 0; i < (size_t)B * rows * 3; ++i) xhist[i] = nan;
+  for (size_t i = 0; i < (size_t)B * max_steps * 2; ++i) uhist[i] = std::nanf("");
+  for (int b = 0; b < B; ++b) memcpy(xhist + (size_t)b * rows * 3, &x0[(size_t)3 * b], 3 * sizeof(double));
+  HIP_TRY(hipMemcpyAsync(p->loop_xhist, xhist, sizeof(double) * 3 * B * rows, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->loop_uhist, uhist, sizeof(float2) * (size_t)B * max_steps, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemcpyAsync(p->loop_state, x0.data(), sizeof(double) * 3 * B, hipMemcpyHostToDevice, p->stream));
+  HIP_TRY(hipMemsetAsync(p->loop_done, 0, sizeof(int) * (size_t)B, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  *p->loop_done_count = 0;
+  WorldLoop L;
+  memset(&L, 0, sizeof(L));
+  auto plan_loop = [&]() -> int {
+    // the window plan the host would make for every new start state, handed to the step kernel
+    TRY(ensure_packed(p, lin, ang));
+    DevParams plan = make_dev_params(p, lin, ang);
+    size_t lds_unused = 0;
+    const bool windowed = plan_lds_window(p, plan, &lds_unused);
+    TRY(upload_instances(p));
+    L.state = p->loop_state; L.xhist = p->loop_xhist; L.uhist = p->loop_uhist; L.done = p->loop_done;
+    L.done_count = p->loop_done_count_dev;
+    L.max_steps = max_steps;
+    L.dt = dt > 0.0 ? dt : (double)p->params.dt;
+    L.goal_tolerance = goal_tolerance;
+    L.xlo = (double)p->params.xlo; L.ylo = (double)p->params.ylo; L.res = (double)plan.res;
+    L.map_rows = plan.rows; L.map_pitch = p->pitch16;
+    L.win_rows = plan.win_rows; L.win_cols = plan.win_cols;
+    // (a window smaller than the map is a reach square: its half width is what plan_lds_window used)
+    L.win_active = windowed && (plan.win_rows < plan.rows || plan.win_cols < p->pitch16) ? 1 : 0;
+    if (L.win_active) {
+      const mppi_params& a = p->params;
+      double vmax = std::fmax(std::fabs((double)a.vrange[0]), std::fabs((double)a.vrange[1]));
+      double trmax = std::fmax(std::fabs(plan.lin_lo), std::fabs(plan.lin_lo + (double)plan.lin_max_byte * plan.lin_ratio));
+      L.reach = (int)((long)std::ceil((double)T * (double)a.dt * vmax * trmax / (double)a.res) + 2);
+    }
+    return MPPI_OK;
+  };
+  const WorldGrid G = world_grid(w);
+  const int check_every = 16;
+  HIP_TRY(hipEventRecord(p->ev_begin, p->stream));
+  int launched = 0;
+  for (int step = 0; step < max_steps; ++step) {
+    TRY(sample_for_solve(p, lin, ang));
+    if (step == 0) TRY(plan_loop());  // (needs the sampled grids packed: after the first draw)
+    TRY(run_iterations(p, lin, ang, p->params.num_opt, /*timed=*/false));
+    hipLaunchKernelGGL(k_world_step, dim3(B), dim3(256), sizeof(float2) * (size_t)T, p->stream, G, L, p->inst_dev, p->u,
+                       T, step);
+    HIP_TRY(hipGetLastError());
+    ++launched;
+    if (launched % check_every == 0) {
+      HIP_TRY(hipStreamSynchronize(p->stream));
+      if (*p->loop_done_count >= B) break;
+    }
+  }
+  HIP_TRY(hipEventRecord(p->ev_end, p->stream));
+  p->elapsed_pending = true;
+  p->last_iterations = launched * (p->params.num_opt > 0 ? p->params.num_opt : 1);
+  HIP_TRY(hipMemcpyAsync(xhist, p->loop_xhist, sizeof(double) * 3 * B * rows, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipMemcpyAsync(uhist, p->loop_uhist, sizeof(float2) * (size_t)B * max_steps, hipMemcpyDeviceToHost, p->stream));
+  std::vector<int> done((size_t)B);
+  HIP_TRY(hipMemcpyAsync(done.data(), p->loop_done, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, p->stream));
+  // the per-problem records the step kernel has been writing: bring the host mirror up to date
+  HIP_TRY(hipMemcpyAsync(p->inst_host.data(), p->inst_dev, sizeof(BatchInst) * (size_t)B, hipMemcpyDeviceToHost, p->stream));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->inst_dirty = false;
+  for (int b = 0; b < B; ++b) steps_taken[b] = done[b] ? done[b] : launched;
   return finish_timing(p);
 }
 

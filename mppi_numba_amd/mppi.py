@@ -320,6 +320,57 @@ class MPPI_Numba(object):
         self.params["x0"] = np.asarray(new_x0).copy()
         _lib.call("mppi_planner_shift_u", self._handle, int(num_shifts))
 
+    def closed_loop(self, world, max_steps, goal_tolerance=None, x_init=None):
+        """The notebooks' control loop (test.ipynb cell 4) on the device: max_steps times
+        {solve, world.get at the current state, float64 Euler step, shift_and_update, goal
+        check}, without a host round trip per control step.  `world` is a DeviceWorld, or a
+        TractionGrid (its device twin is created and cached on it).  Returns
+        (xhist (max_steps+1, 3) float64, uhist (max_steps, 2) float32, steps_taken) --
+        with a leading problem axis for a batched handle; rows never reached are NaN, as in
+        the notebook.  Afterwards params['x0'] and the device's control sequence are where
+        the loop left them (the last solution, shifted once)."""
+        from .terrain import DeviceWorld
+        if not self.check_solve_conditions():
+            print("MPPI solve condition not met. Cannot solve. Return")
+            return
+        if not isinstance(world, DeviceWorld):
+            twin = getattr(world, "device_world", None)
+            if twin is None:
+                twin = DeviceWorld.from_traction_grid(world, device=getattr(self.cfg, "device", 0))
+                world.device_world = twin
+            world = twin
+        B, single = self.num_instances, self.num_instances == 1
+        self.move_mppi_task_vars_to_device()
+        if single:
+            x0 = np.asarray(self.params["x0"], dtype=np.float64).reshape(1, 3) if x_init is None \
+                else np.asarray(x_init, dtype=np.float64).reshape(1, 3)
+            x0_f32 = np.ascontiguousarray(x0.astype(np.float32))
+            goal = np.ascontiguousarray(np.asarray(self.params["xgoal"], dtype=np.float64).astype(np.float32)).reshape(1, 2)
+            _lib.call("mppi_planner_set_instances", self._handle, 1, _lib.ptr(x0_f32, C.c_float),
+                      _lib.ptr(goal, C.c_float))
+            x_init = x0
+        tol = float(self.params["goal_tolerance"] if goal_tolerance is None else goal_tolerance)
+        xhist = np.empty((B, max_steps + 1, 3), dtype=np.float64)
+        uhist = np.empty((B, max_steps, 2), dtype=np.float32)
+        steps = np.zeros(B, dtype=np.int32)
+        xi = None
+        if x_init is not None:
+            xi = np.ascontiguousarray(np.asarray(x_init, dtype=np.float64).reshape(B, 3))
+        try:
+            _lib.call("mppi_planner_closed_loop", self._handle, self.lin_tdm._handle, self.ang_tdm._handle,
+                      world._handle, int(max_steps), float(self.cfg.dt), tol, None if xi is None else _lib.ptr(xi, C.c_double),
+                      _lib.ptr(xhist, C.c_double), _lib.ptr(uhist, C.c_float), _lib.ptr(steps, C.c_int))
+        finally:
+            if single:
+                _lib.call("mppi_planner_set_instances", self._handle, 0, None, None)
+        last = np.stack([xhist[b, steps[b]] for b in range(B)])
+        if single:
+            self.params["x0"] = last[0].copy()
+            return xhist[0], uhist[0], int(steps[0])
+        self.x0s = np.ascontiguousarray(last.astype(np.float32))
+        self.params["x0"] = last[0].copy()
+        return xhist, uhist, steps
+
     def set_u(self, u):
         u = np.ascontiguousarray(u, dtype=np.float32).reshape(self.num_instances * self.num_steps, 2)
         _lib.call("mppi_planner_set_u", self._handle, _lib.ptr(u, C.c_float))

@@ -475,6 +475,33 @@ class TDM_Numba(object):
             angs[mask] = ang_s
         return TractionGrid(lins, angs)
 
+    def sample_grids_true_dist_on_device(self, seed=None, device=None):
+        """sample_grids_true_dist with the draw made on the GPU: every cell picks, with a
+        Philox counter keyed by `seed`, one entry of the sample pool its terrain type keeps
+        (Terrain.lin_saved_samples / ang_saved_samples), linear and angular independently.
+        Returns a TractionGrid whose arrays are the device draw and whose `.device_world`
+        (DeviceWorld) is what MPPI_Numba.closed_loop steps through without host round trips."""
+        sg = np.asarray(self.semantic_grid)
+        ids = np.unique(sg)
+        pools_lin, pools_ang = [], []
+        for sid in ids:
+            terrain = self.id2terrain_fn(sid)
+            pools_lin.append(np.asarray(terrain.lin_saved_samples, dtype=np.float64).ravel())
+            pools_ang.append(np.asarray(terrain.ang_saved_samples, dtype=np.float64).ravel())
+        pool_len = min(min(len(a) for a in pools_lin), min(len(a) for a in pools_ang))
+        assert pool_len > 0, "a terrain type has no saved samples"
+        lin_pool = np.ascontiguousarray(np.stack([a[:pool_len] for a in pools_lin]))
+        ang_pool = np.ascontiguousarray(np.stack([a[:pool_len] for a in pools_ang]))
+        terrain_of_cell = np.ascontiguousarray(np.searchsorted(ids, sg).astype(np.int32))
+        dev = getattr(self.cfg, "device", 0) if device is None else device
+        world = DeviceWorld(sg.shape[0], sg.shape[1], res=1.0, device=dev)
+        world.sample_true_dist(terrain_of_cell, lin_pool, ang_pool,
+                               seed=getattr(self.cfg, "seed", 1) if seed is None else seed)
+        lins, angs = world.get_grids()
+        grid = TractionGrid(lins, angs)
+        grid.device_world = world
+        return grid
+
     def sample_grids(self, alpha_dyn=1.0):
         """Draw the traction grids from the PMF on the GPU (terrain.py:610-622);
         returns the (M or 1, rows, cols) int8 device batch."""
@@ -512,6 +539,70 @@ class TractionGrid(object):
 
     def get_grids(self):
         return self.lin_traction, self.ang_traction
+
+
+class DeviceWorld(object):
+
+    """TractionGrid on the GPU (include/mppi_hip.h: mppi_world_*): float64 (rows, cols) grids of
+    linear / angular traction, `get` for batches of points with the reference's cell rule
+    (terrain.py:776-782), the true-distribution draw (terrain.py:586-608) and the world the
+    planner's device-side closed loop steps through (MPPI_Numba.closed_loop)."""
+
+    def __init__(self, rows, cols, res=1.0, xlimits=None, ylimits=None, lin=None, ang=None, device=0):
+        self.rows, self.cols, self.res = int(rows), int(cols), float(res)
+        self.xlimits = (0, self.res * self.cols) if xlimits is None else tuple(xlimits)
+        self.ylimits = (0, self.res * self.rows) if ylimits is None else tuple(ylimits)
+        self._handle = C.c_void_p()
+        lin_p = ang_p = None
+        if lin is not None:
+            lin = np.ascontiguousarray(lin, dtype=np.float64).reshape(self.rows, self.cols)
+            ang = np.ascontiguousarray(ang, dtype=np.float64).reshape(self.rows, self.cols)
+            lin_p, ang_p = _lib.ptr(lin, C.c_double), _lib.ptr(ang, C.c_double)
+        _lib.call("mppi_world_create", int(device), self.rows, self.cols, self.res, float(self.xlimits[0]),
+                  float(self.ylimits[0]), lin_p, ang_p, C.byref(self._handle))
+
+    @classmethod
+    def from_traction_grid(cls, grid, device=0):
+        """The device twin of a host TractionGrid (same cells, limits and resolution)."""
+        return cls(grid.height, grid.width, res=grid.res, xlimits=grid.xlimits, ylimits=grid.ylimits,
+                   lin=np.asarray(grid.lin_traction, dtype=np.float64),
+                   ang=np.asarray(grid.ang_traction, dtype=np.float64), device=device)
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            try:
+                _lib.load().mppi_world_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    def get(self, x, y):
+        """(lin, ang) at world positions; scalars in -> scalars out, arrays -> arrays."""
+        xs, ys = np.broadcast_arrays(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64))
+        xy = np.ascontiguousarray(np.stack([xs.ravel(), ys.ravel()], axis=1))
+        lin = np.empty(xy.shape[0], dtype=np.float64)
+        ang = np.empty(xy.shape[0], dtype=np.float64)
+        _lib.call("mppi_world_get", self._handle, _lib.ptr(xy, C.c_double), int(xy.shape[0]),
+                  _lib.ptr(lin, C.c_double), _lib.ptr(ang, C.c_double))
+        if xs.ndim == 0:
+            return lin[0], ang[0]
+        return lin.reshape(xs.shape), ang.reshape(xs.shape)
+
+    def get_grids(self):
+        lin = np.empty((self.rows, self.cols), dtype=np.float64)
+        ang = np.empty((self.rows, self.cols), dtype=np.float64)
+        _lib.call("mppi_world_get_grids", self._handle, _lib.ptr(lin, C.c_double), _lib.ptr(ang, C.c_double))
+        return lin, ang
+
+    def sample_true_dist(self, terrain_of_cell, lin_pool, ang_pool, seed=1):
+        terrain_of_cell = np.ascontiguousarray(terrain_of_cell, dtype=np.int32).reshape(self.rows * self.cols)
+        lin_pool = np.ascontiguousarray(lin_pool, dtype=np.float64)
+        ang_pool = np.ascontiguousarray(ang_pool, dtype=np.float64)
+        assert lin_pool.ndim == 2 and lin_pool.shape == ang_pool.shape
+        _lib.call("mppi_world_sample_true_dist", self._handle, _lib.ptr(terrain_of_cell, C.c_int32),
+                  int(lin_pool.shape[0]), _lib.ptr(lin_pool, C.c_double), _lib.ptr(ang_pool, C.c_double),
+                  int(lin_pool.shape[1]), int(seed) & 0xFFFFFFFFFFFFFFFF)
 
 
 class Terrain(object):
