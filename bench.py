@@ -233,6 +233,10 @@ def main():
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "host"],
                     help="multi-GPU packet exchange: RCCL all-gather on the stream (default) or, for debugging "
                          "on a box where several ranks must share one GPU, host-staged over the rendezvous hub")
+    ap.add_argument("--shard", default="controls", choices=["controls", "samples"],
+                    help="multi-GPU c3: what the ranks split -- the N control samples (default; every rank holds all "
+                         "M traction maps) or the M traction samples (every rank rolls all N controls over its own "
+                         "M maps of a global M*gpus; one all-gather of the (N, M) per-sample costs per step)")
     ap.add_argument("--single-process", action="store_true",
                     help="--gpus N from ONE process driving N devices (mppi_group_*) instead of one process per GPU")
     args = ap.parse_args()
@@ -260,6 +264,12 @@ def main():
     n_local, t_steps, m = w["n"], w["t"], w["m"]
     problems = (args.problems or w["problems"]) if "problems" in w else 0
     n_global = n_local if problems else n_local * world  # c5: the ranks are independent
+    by_samples = args.shard == "samples" and world > 1
+    if args.shard == "samples":
+        assert args.workload == "c3" and not args.single_process, "--shard samples: the CVaR workload, one process per GPU"
+    m_global = m * world if by_samples else m  # weak scaling in M: every rank keeps its 128 maps
+    if by_samples:
+        n_global = n_local  # every rank rolls all N control samples
     device = local_rank % max(1, _lib.device_count())
     group_size = args.gpus if args.single_process else 1
     if group_size > 1:
@@ -271,14 +281,15 @@ def main():
     import io
     quiet = contextlib.redirect_stdout(io.StringIO())  # the mirror prints like the reference does
     with quiet:
-        cfg = Config(T=t_steps * 0.1, dt=0.1, num_grid_samples=m, num_control_rollouts=n_global,
+        cfg = Config(T=t_steps * 0.1, dt=0.1, num_grid_samples=m_global, num_control_rollouts=n_global,
                      max_speed_padding=5.0, num_vis_state_rollouts=1, max_map_dim=(260, 260),
                      seed=1 + (rank if problems else 0),
                      enforce_recommended_limits=False, math=args.math, device=device, **w["mode"])
         assert cfg.num_steps == t_steps, cfg.num_steps
         world_rng = np.random.default_rng(0)
         pmf, obstacle, unknown, tdm_dict = synthetic_world(args.workload, world_rng)
-        lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
+        shard = (rank, world) if by_samples else None
+        lin, ang = TDM_Numba(cfg, sample_shard=shard), TDM_Numba(cfg, sample_shard=shard)
         lin.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
         ang.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
         params = make_params(args.workload)
@@ -300,6 +311,9 @@ def main():
             group = MPPI_Group(cfgs)
             group.setup(params, lins, angs)
             planner = group.planners[0]
+        elif by_samples:
+            planner = MPPI_Numba(cfg, sample_shard=shard)
+            planner.setup(params, lin, ang)
         else:
             planner = MPPI_Numba(cfg, rank=rank, world_size=world)
             planner.setup(params, lin, ang)
@@ -326,7 +340,7 @@ def main():
             print("bench.py rank %d: %s" % (rank, exchange_note), file=sys.stderr)
             if err == "" and uid is not None:
                 # this rank did create a communicator the others lack: never use it
-                planner = MPPI_Numba(cfg, rank=rank, world_size=world)
+                planner = MPPI_Numba(cfg, sample_shard=shard) if by_samples else MPPI_Numba(cfg, rank=rank, world_size=world)
                 planner.setup(params, lin, ang)
 
     if world > 1 and args.exchange == "host" and not problems:
@@ -334,7 +348,11 @@ def main():
             for _ in range(k):
                 planner.sample_noise()
                 planner.rollout()
-                planner.update_apply(np.stack(hub.all_gather(planner.update_local())))
+                if by_samples:  # the (N, M/G) per-sample cost slabs; the update is then local
+                    planner.sample_costs_apply(np.stack(hub.all_gather(planner.sample_costs_local())))
+                    planner.update()
+                else:
+                    planner.update_apply(np.stack(hub.all_gather(planner.update_local())))
         def solve_staged():  # solve() = sample the traction grids once, then iterate
             lin.sample_grids(params.get("alpha_dyn", 1.0) if w["m"] > 1 else 1.0)
             ang.sample_grids(params.get("alpha_dyn", 1.0) if w["m"] > 1 else 1.0)
@@ -368,6 +386,10 @@ def main():
     elapsed = hub.all_max(elapsed)
     ms_per_step = 1e3 * elapsed / args.steps
     rollouts_per_step = (problems * n_local * world) if problems else n_global
+    if by_samples:
+        # weak scaling in M: N control samples x (M * world) traction samples per step, counted in
+        # control samples at the workload's own M (= what --shard controls counts for the same work)
+        rollouts_per_step = n_local * world
     value = rollouts_per_step * args.steps / elapsed
     rccl_ranks = planner.comm_count()
 
@@ -406,13 +428,17 @@ def main():
         if args.math == "exact" else "f32",
         "data": "synthetic",
         "config": {"workload": w["label"], "rollouts_per_gpu": n_local, "global_rollouts": n_global,
-                   "horizon_steps": t_steps, "traction_samples": m, "padded_grid": [int(rp), int(cp)],
+                   "horizon_steps": t_steps, "traction_samples": m_global, "traction_samples_per_gpu": m,
+                   "padded_grid": [int(rp), int(cp)],
                    "rng": "Philox4x32-10 counters (rocRAND-identical engine) + hardware Box-Muller", "math": args.math,
                    "problems_per_gpu": problems or 1,
                    "graph_replay_iterations": args.graph if world == 1 else 0,
                    "rollout_kernel": planner.last_rollout_kernel(),
                    "sharding": "independent problems over ranks, no exchange" if problems else
-                               "control samples over ranks, 1 all-gather of (2T+2) f64 per step",
+                               ("traction samples over ranks: every rank rolls all N controls over its M maps, 1 all-gather "
+                                "of the (N, M) f32 per-sample costs per step, CVaR + update replicated; value counts "
+                                "N x (M_global / M) control samples" if by_samples else
+                                "control samples over ranks, 1 all-gather of (2T+2) f64 per step"),
                    "exchange": "none" if ((world == 1 and group_size == 1) or problems) else
                                ("RCCL all-gather on the planner's stream" if args.exchange == "rccl" else
                                 (exchange_note or "host-staged through the rendezvous hub (--exchange host)")),

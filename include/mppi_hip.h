@@ -353,6 +353,21 @@ int mppi_group_iterate_async(mppi_planner** planners, mppi_tdm** lins, mppi_tdm*
  * caller, e.g. over gloo): packet = {beta, den, num[T][2]} of the local shard,
  * 2T+2 doubles; update_apply takes the packets of all ranks in rank order */
 int mppi_planner_packet_len(mppi_planner* p, int* doubles);
+/* ---- multi-GPU, CVaR mode: the M traction-map samples sharded over ranks ------
+ * Rank r of G rolls ALL N control samples (rollout_numba, mppi.py:613-755) over traction samples
+ * [r*M/G, (r+1)*M/G): its TDMs draw exactly those samples of the unsharded set
+ * (mppi_tdm_set_sample_shard: first sample, even; Philox generator), its planner is created with
+ * num_grid_samples = M/G, world_size = 1 and told its place (mppi_planner_set_sample_sharding,
+ * before comm_init).  Per iteration ONE RCCL all-gather of the (N, M/G) float32 per-sample costs
+ * (N*M*4 bytes in total); every rank then sorts / averages all M costs of every control sample
+ * (the reference's order, mppi.py:716-755: costs have the bits of the unsharded launch) and runs
+ * the control update locally -- all ranks hold the same u without a second collective.
+ * sample_costs_local / sample_costs_apply are the host-staged form of the exchange (after
+ * mppi_planner_rollout; slabs: (G, N, M/G) in rank order), followed by mppi_planner_update. */
+int mppi_tdm_set_sample_shard(mppi_tdm* t, int first_sample);
+int mppi_planner_set_sample_sharding(mppi_planner* p, int rank, int count);
+int mppi_planner_sample_costs_local(mppi_planner* p, float* slab);
+int mppi_planner_sample_costs_apply(mppi_planner* p, const float* slabs, int count);
 int mppi_planner_update_local(mppi_planner* p, double* packet);
 int mppi_planner_update_apply(mppi_planner* p, const double* packets, int count);
 

@@ -130,6 +130,10 @@ SIGNATURES = {
     "mppi_world_get_grids": [_vp, _f64p, _f64p],
     "mppi_world_sample_true_dist": [_vp, C.POINTER(C.c_int32), C.c_int, _f64p, _f64p, C.c_int, C.c_uint64],
     "mppi_planner_closed_loop": [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_double, _f64p, _f64p, _f32p, C.POINTER(C.c_int)],
+    "mppi_tdm_set_sample_shard": [_vp, C.c_int],
+    "mppi_planner_set_sample_sharding": [_vp, C.c_int, C.c_int],
+    "mppi_planner_sample_costs_local": [_vp, _f32p],
+    "mppi_planner_sample_costs_apply": [_vp, _f32p, C.c_int],
     "mppi_comm_unique_id": [C.c_char_p],
     "mppi_planner_comm_init": [_vp, C.c_char_p],
     "mppi_planner_comm_count": [_vp, C.POINTER(C.c_int)],

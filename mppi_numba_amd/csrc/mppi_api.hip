@@ -157,6 +157,9 @@ struct mppi_tdm {
   uint64_t sampled_epoch = 0;   // Philox epoch of the current draws
   bool injected = false;  // grids came from mppi_tdm_set_sampled_grids
   int8_t injected_max = 0, injected_min = 0;
+  // samples sharded over GPUs (mppi_tdm_set_sample_shard): this handle's G grids are samples
+  // [first_sample, first_sample + G) of the unsharded set; even, a Philox block serves a pair
+  int first_sample = 0;
 };
 
 extern "C" int mppi_tdm_destroy(mppi_tdm* t) {
@@ -414,7 +417,8 @@ static int tdm_launch_philox(mppi_tdm* t, double alpha_dyn, uint64_t epoch, hipS
       dim3 grid((unsigned)ceil_div(cell_groups, 256), (unsigned)ceil_div(G, g_chunk));
 #define MPPI_SAMPLE(MAXB)                                                                                       \
   hipLaunchKernelGGL(k_sample_grids_philox_cols<MAXB>, grid, dim3(256), 0, stream, t->pmf, t->bins, t->rows, t->cols, \
-                     t->table, alpha_dyn, t->cfg.seed, epoch, G, g_chunk, t->grid, t->cfg.max_rows, t->cfg.max_cols)
+                     t->table, alpha_dyn, t->cfg.seed, epoch, G, g_chunk, t->grid, t->cfg.max_rows, t->cfg.max_cols, \
+                     (uint64_t)(t->first_sample >> 1) * (uint64_t)cell_groups)
       if (t->bins <= 8) MPPI_SAMPLE(8);
       else if (t->bins <= 16) MPPI_SAMPLE(16);
       else if (t->bins <= 32) MPPI_SAMPLE(32);
@@ -424,7 +428,7 @@ static int tdm_launch_philox(mppi_tdm* t, double alpha_dyn, uint64_t epoch, hipS
       long total = (long)G * cell_groups;
       hipLaunchKernelGGL(k_sample_grids_philox, dim3(ceil_div(total, 256)), dim3(256), 0, stream, t->pmf, t->bins,
                          t->rows, t->cols, t->table, alpha_dyn, t->cfg.seed, epoch, G, t->grid,
-                         t->cfg.max_rows, t->cfg.max_cols);
+                         t->cfg.max_rows, t->cfg.max_cols, (uint64_t)t->first_sample * (uint64_t)cell_groups);
     }
   }
   HIP_TRY(hipGetLastError());
@@ -460,6 +464,19 @@ static int tdm_sample_on(mppi_tdm* t, double alpha_dyn, hipStream_t stream) {
   t->sampled_alpha = alpha_dyn;
   ++t->grid_version;
   t->injected = false;
+  return MPPI_OK;
+}
+
+extern "C" int mppi_tdm_set_sample_shard(mppi_tdm* t, int first_sample) {
+  REQUIRE(t, MPPI_ERR_INVALID, "NULL tdm");
+  REQUIRE(first_sample >= 0 && (first_sample & 1) == 0, MPPI_ERR_INVALID,
+          "first_sample %d: must be even and >= 0 (a Philox block serves a pair of samples)", first_sample);
+  REQUIRE(first_sample == 0 || t->cfg.rng == MPPI_RNG_PHILOX, MPPI_ERR_INVALID,
+          "sample shards need the counter-based generator (MPPI_RNG_PHILOX)");
+  if (first_sample != t->first_sample) {
+    t->first_sample = first_sample;
+    t->sampled_maps_version = ~0ULL;  // (a one-hot PMF is re-sampled too: cheap, and keeps the rule simple)
+  }
   return MPPI_OK;
 }
 
@@ -666,6 +683,11 @@ struct mppi_planner {
   int last_iterations = 0;
   // comm
   ncclComm_t comm = nullptr;
+  // CVaR mode with the M traction samples sharded over GPUs (mppi_planner_set_sample_sharding):
+  // this handle rolls ALL N control samples over its cfg.num_grid_samples grids; the per-(n, m)
+  // costs of all shards are all-gathered and every rank forms the CVaR of every control sample
+  int m_rank = 0, m_count = 1;
+  float* slabs = nullptr;  // [m_count][n_local][M_local]
   // closed loop on the device (mppi_planner_closed_loop): world state, trajectory log
   double* loop_state = nullptr;   // [B][3]
   double* loop_xhist = nullptr;   // [B][loop_capacity + 1][3]
@@ -714,6 +736,7 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   dev_free(p->obs_pos);
   dev_free(p->obs_r);
   dev_free(p->state_rollout);
+  dev_free(p->slabs);
   dev_free(p->loop_state);
   dev_free(p->loop_xhist);
   dev_free(p->loop_uhist);
@@ -1009,6 +1032,7 @@ static DevParams make_dev_params(const mppi_planner* p, const mppi_tdm* lin, con
   d.numel = (int)std::ceil((double)p->cfg.num_grid_samples * (double)a.cvar_alpha);
   if (d.numel < 1) d.numel = 1;
   if (d.numel > p->cfg.num_grid_samples) d.numel = p->cfg.num_grid_samples;
+  // (samples sharded over GPUs: the local kernel's own reduction is not used; cvar_numel())
   d.dist_weight = a.dist_weight;
   d.v_post_den = (double)a.v_post_rollout + 1e-6;
   if (lin) { d.lin_lo = lin->lo; d.lin_ratio = lin->ratio; d.rows = lin->rows; d.cols = lin->cols; }
@@ -1052,6 +1076,7 @@ static bool sample_into_cells(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, dou
   if (disabled || p->cfg.mode != MPPI_MODE_TDM || lin == ang) return false;
   if (lin->cfg.rng != MPPI_RNG_PHILOX || ang->cfg.rng != MPPI_RNG_PHILOX) return false;
   if (lin->bins > 64 || ang->bins > 64 || !(alpha_dyn > 0.0)) return false;
+  if (lin->first_sample != ang->first_sample) return false;
   const int M = p->cfg.num_grid_samples;
   // a wave of this kernel sets up the thresholds of its 4 cells for M/64 rounds of draws: measured
   // against sample + sample + transpose, 65 vs 61 us at M = 128 and 192 vs 363 us at M = 1024
@@ -1063,7 +1088,8 @@ static bool sample_into_cells(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, dou
 #define MPPI_SAMPLE_CELLS(MAXB)                                                                                    \
   hipLaunchKernelGGL(k_sample_cellsM_philox<MAXB>, grid, dim3(256), 0, p->stream, lin->pmf, lin->bins, lin->table, \
                      lin->cfg.seed, lin->epoch, ang->pmf, ang->bins, ang->table, ang->cfg.seed, ang->epoch,        \
-                     lin->obs, lin->unk, lin->rows, lin->cols, alpha_dyn, M, p->cells)
+                     lin->obs, lin->unk, lin->rows, lin->cols, alpha_dyn, M, p->cells,                            \
+                     (uint64_t)(lin->first_sample >> 1) * (uint64_t)cell_groups)
   if (bins <= 8) MPPI_SAMPLE_CELLS(8);
   else if (bins <= 16) MPPI_SAMPLE_CELLS(16);
   else if (bins <= 32) MPPI_SAMPLE_CELLS(32);
@@ -1623,7 +1649,11 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
       if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_tdm<EXACT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      if (p->want_sample_costs && !p->sample_costs) TRY(dev_alloc(&p->sample_costs, (size_t)N * M));
+      if (p->want_sample_costs && !p->sample_costs && p->m_count == 1) TRY(dev_alloc(&p->sample_costs, (size_t)N * M));
+      if (p->m_count > 1 && !p->slabs) TRY(dev_alloc(&p->slabs, (size_t)p->m_count * N * M));
+      // sharded samples: the per-sample costs go into this rank's slab of the gather buffer
+      float* const sc_dst = p->m_count > 1 ? p->slabs + (size_t)p->m_rank * N * M
+                                           : (p->want_sample_costs ? p->sample_costs : nullptr);
       p->tile_packets_fresh = false;
       TRY(upload_instances(p));
       {
@@ -1635,7 +1665,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         if (EXACT && BOUNDED && std::isfinite(dmax) && dmax <= 0.36 && T <= 2000 && lds_fast <= 64 * 1024) {
           int res_exp = 0;
           const bool pow2res = std::frexp((double)a.res, &res_exp) == 0.5;
-          float* sc_out = p->want_sample_costs ? p->sample_costs : nullptr;
+          float* sc_out = sc_dst;
           if (pow2res)
             hipLaunchKernelGGL((k_rollout_tdm_fast<true>), dim3(N), dim3(threads), lds_fast, p->stream, d, p->cells,
                                p->noise, p->u, p->costs, sc_out, mp2);
@@ -1647,7 +1677,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         }
       }
       hipLaunchKernelGGL((k_rollout_tdm<EXACT>), dim3(N), dim3(threads), lds, p->stream, d, p->cells, p->noise,
-                         p->u, p->costs, p->want_sample_costs ? p->sample_costs : nullptr, mp2);
+                         p->u, p->costs, sc_dst, mp2);
       p->last_rollout = "k_rollout_tdm exact=" + std::to_string((int)EXACT);
       break;
     }
@@ -1689,6 +1719,39 @@ static int launch_rollout(mppi_planner* p, const DevParams& d) {
 // tile-relative weights (unless the rollout kernel just emitted them) + the row kernel:
 // applies the update on a single GPU; with several GPUs leaves this rank's packet in
 // packets[rank] for the exchange
+// ---- CVaR mode, samples sharded over GPUs: all-gather of the (N, M/G) cost slabs, then every
+//      rank reduces all N control samples over all M costs ---------------
+static int cvar_numel(const mppi_planner* p) {
+  const int M = p->cfg.num_grid_samples * p->m_count;
+  int numel = (int)std::ceil((double)M * (double)p->params.cvar_alpha);  // mppi.py:716-717 over all M samples
+  return numel < 1 ? 1 : (numel > M ? M : numel);
+}
+
+static int launch_cvar_reduce(mppi_planner* p) {
+  const int N = p->n_local, Ml = p->cfg.num_grid_samples, M = Ml * p->m_count;
+  const int mp2 = next_pow2(M);
+  const int threads = mp2 > 1024 ? 1024 : (mp2 < 64 ? 64 : mp2);  // one element per thread when it fits
+  const size_t lds = sizeof(float) * (size_t)mp2;
+  REQUIRE(lds <= 64 * 1024, MPPI_ERR_INVALID, "M = %d samples over all shards: too many for the CVaR reduction", M);
+  if (p->want_sample_costs && p->sample_costs == nullptr) TRY(dev_alloc(&p->sample_costs, (size_t)N * M));
+  hipLaunchKernelGGL(k_cvar_reduce, dim3(N), dim3(threads), lds, p->stream, p->slabs, p->m_count, N, Ml, cvar_numel(p),
+                     p->params.cvar_alpha, p->costs, p->want_sample_costs ? p->sample_costs : (float*)nullptr, mp2);
+  HIP_TRY(hipGetLastError());
+  p->tile_packets_fresh = false;
+  return MPPI_OK;
+}
+
+// inside the iteration loop: RCCL all-gather of the slabs on the planner's stream, then the reduction
+static int exchange_sample_costs(mppi_planner* p) {
+  if (p->m_count <= 1) return MPPI_OK;
+  REQUIRE(p->comm, MPPI_ERR_STATE,
+          "samples sharded over %d ranks but no communicator: call mppi_planner_comm_init "
+          "(or drive rollout / sample_costs_local / sample_costs_apply / update yourself)", p->m_count);
+  const size_t len = (size_t)p->n_local * p->cfg.num_grid_samples;
+  RCCL_TRY(g_rccl.AllGather(p->slabs + (size_t)p->m_rank * len, p->slabs, len, ncclFloat, p->comm, p->stream));
+  return launch_cvar_reduce(p);
+}
+
 static int launch_update_local(mppi_planner* p, bool apply_here) {
   const int N = p->n_local, T = p->cfg.num_steps;
   const mppi_params& a = p->params;
@@ -1740,7 +1803,8 @@ static int launch_apply(mppi_planner* p) {
 static int launch_update(mppi_planner* p, bool prof, bool defer_exchange = false) {
   if (defer_exchange) return launch_update_local(p, false);
   // (a communicator on a single rank is honoured too: it exercises the same path as N ranks)
-  if (p->cfg.world_size == 1 && !p->comm) {
+  // (samples sharded: every rank holds all N costs and all the noise -- the update is local)
+  if ((p->cfg.world_size == 1 && !p->comm) || p->m_count > 1) {
     TRY(launch_update_local(p, true));
     if (prof) {
       HIP_TRY(hipEventRecord(p->ev_stage[3], p->stream));
@@ -1787,6 +1851,7 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
   // the other noise buffer was last read by the previous update, which is behind us on this stream
   if (want_next && side_stream_pays) HIP_TRY(hipEventRecord(p->ev_buf_free, p->stream));
   TRY(launch_rollout(p, d));
+  TRY(exchange_sample_costs(p));
   have_noise = p->next_noise_done;
   if (want_next && !have_noise && side_stream_pays) {
     HIP_TRY(hipStreamWaitEvent(p->noise_stream, p->ev_buf_free, 0));
@@ -2290,7 +2355,54 @@ extern "C" int mppi_planner_get_sample_costs(mppi_planner* p, float* costs) {
     return MPPI_OK;
   }
   REQUIRE(p->sample_costs, MPPI_ERR_STATE, "call once with NULL before the rollout to arm recording");
-  return copy_out(p, costs, p->sample_costs, sizeof(float) * (size_t)p->n_local * p->cfg.num_grid_samples);
+  // (samples sharded over GPUs: all M = count * num_grid_samples costs, gathered)
+  return copy_out(p, costs, p->sample_costs,
+                  sizeof(float) * (size_t)p->n_local * p->cfg.num_grid_samples * (size_t)p->m_count);
+}
+
+// ---- CVaR mode with the traction samples sharded over GPUs -------------
+extern "C" int mppi_planner_set_sample_sharding(mppi_planner* p, int rank, int count) {
+  REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
+  REQUIRE(count >= 1 && rank >= 0 && rank < count, MPPI_ERR_INVALID, "bad sample shard %d of %d", rank, count);
+  REQUIRE(count == 1 || p->cfg.mode == MPPI_MODE_TDM, MPPI_ERR_INVALID, "only MPPI_MODE_TDM has samples to shard");
+  REQUIRE(count == 1 || p->cfg.world_size == 1, MPPI_ERR_INVALID,
+          "a handle shards either its control samples (world_size %d) or its traction samples, not both",
+          p->cfg.world_size);
+  REQUIRE(count == 1 || (p->cfg.num_grid_samples & 1) == 0, MPPI_ERR_INVALID,
+          "num_grid_samples per shard (%d) must be even", p->cfg.num_grid_samples);
+  REQUIRE(!p->comm || (rank == p->m_rank && count == p->m_count), MPPI_ERR_STATE,
+          "the communicator was created for another shard layout");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  if (count != p->m_count) {
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    dev_free(p->slabs);
+    dev_free(p->sample_costs);
+    drop_graphs(p);
+  }
+  p->m_rank = rank;
+  p->m_count = count;
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_sample_costs_local(mppi_planner* p, float* slab) {
+  REQUIRE(p && slab, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(p->m_count > 1, MPPI_ERR_STATE, "samples are not sharded (mppi_planner_set_sample_sharding)");
+  REQUIRE(p->slabs, MPPI_ERR_STATE, "no rollout yet");
+  const size_t len = (size_t)p->n_local * p->cfg.num_grid_samples;
+  return copy_out(p, slab, p->slabs + (size_t)p->m_rank * len, sizeof(float) * len);
+}
+
+extern "C" int mppi_planner_sample_costs_apply(mppi_planner* p, const float* slabs, int count) {
+  REQUIRE(p && slabs, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(p->m_count > 1 && count == p->m_count, MPPI_ERR_INVALID, "expected the slabs of %d shards, got %d",
+          p->m_count, count);
+  REQUIRE(p->slabs && p->params_set, MPPI_ERR_STATE, "no rollout yet");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  const size_t len = (size_t)p->n_local * p->cfg.num_grid_samples;
+  HIP_TRY(hipMemcpyAsync(p->slabs, slabs, sizeof(float) * len * (size_t)count, hipMemcpyHostToDevice, p->stream));
+  TRY(launch_cvar_reduce(p));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return MPPI_OK;
 }
 
 extern "C" int mppi_planner_update(mppi_planner* p) {
@@ -2650,6 +2762,8 @@ extern "C" int mppi_planner_comm_init(mppi_planner* p, const char id[MPPI_COMM_I
   HIP_TRY(hipSetDevice(p->cfg.device));
   ncclUniqueId uid;
   memcpy(&uid, id, sizeof(uid));
-  RCCL_TRY(g_rccl.CommInitRank(&p->comm, p->cfg.world_size, uid, p->cfg.rank));
+  // (one communicator per handle: over the ranks that share its control samples, or its traction samples)
+  if (p->m_count > 1) RCCL_TRY(g_rccl.CommInitRank(&p->comm, p->m_count, uid, p->m_rank));
+  else RCCL_TRY(g_rccl.CommInitRank(&p->comm, p->cfg.world_size, uid, p->cfg.rank));
   return MPPI_OK;
 }

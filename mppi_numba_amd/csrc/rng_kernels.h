@@ -205,7 +205,9 @@ __global__ __launch_bounds__(256) void k_sample_grids_philox(const int8_t* __res
                                                              int cols, const int8_t* __restrict__ table,
                                                              double alpha_dyn, uint64_t seed, uint64_t epoch,
                                                              int n_grids, int8_t* __restrict__ out, int out_rows,
-                                                             int out_stride) {
+                                                             int out_stride, uint64_t item_base) {
+  // item_base: this handle's samples are [g0, g0 + n_grids) of a larger set (samples sharded over
+  // GPUs): g0 * rows * groups, so that the draws are those of the unsharded handle
   const int groups = (cols + 3) / 4;
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   size_t total = (size_t)n_grids * rows * groups;
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void k_sample_grids_philox(const int8_t* __res
   int r = (int)((i / groups) % rows);
   int g = (int)(i / ((size_t)groups * rows));
   rocrand_state_philox4x32_10 st;
-  rocrand_init(seed, (uint64_t)i, 4ULL * epoch, &st);
+  rocrand_init(seed, (uint64_t)i + item_base, 4ULL * epoch, &st);
   float4 uu = rocrand_uniform4(&st);  // (0, 1]
   float uv[4] = {uu.x, uu.y, uu.z, uu.w};
   const size_t plane = (size_t)rows * cols;
@@ -312,7 +314,8 @@ __global__ __launch_bounds__(256) void k_sample_grids_philox_cols(const int8_t* 
                                                                   int cols, const int8_t* __restrict__ table,
                                                                   double alpha_dyn, uint64_t seed, uint64_t epoch,
                                                                   int n_grids, int g_chunk, int8_t* __restrict__ out,
-                                                                  int out_rows, int out_stride) {
+                                                                  int out_rows, int out_stride, uint64_t pair_base) {
+  // pair_base: (first sample of this handle / 2) * rows * groups (samples sharded over GPUs)
   const int groups = (cols + 3) / 4;
   const int cgid = blockIdx.x * 256 + threadIdx.x;
   if (cgid >= rows * groups) return;
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(256) void k_sample_grids_philox_cols(const int8_t* 
     }
   };
   for (int g = g0; g < g1; g += 2) {
-    const uint64_t pair_index = (uint64_t)(g >> 1) * (uint64_t)(rows * groups) + (uint64_t)cgid;
+    const uint64_t pair_index = pair_base + (uint64_t)(g >> 1) * (uint64_t)(rows * groups) + (uint64_t)cgid;
     uint32_t p0, p1;
     draw_packed_pair<MAXB>(cum, val, bins, last, seed, epoch, pair_index, scale, p0, p1);
     store(g, p0);
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256) void k_sample_cellsM_philox(
     const int8_t* __restrict__ lin_pmf, int lin_bins, const int8_t* __restrict__ lin_table, uint64_t lin_seed,
     uint64_t lin_epoch, const int8_t* __restrict__ ang_pmf, int ang_bins, const int8_t* __restrict__ ang_table,
     uint64_t ang_seed, uint64_t ang_epoch, const int8_t* __restrict__ obs, const int8_t* __restrict__ unk,
-    int rows, int cols, double alpha_dyn, int n_grids, uint32_t* __restrict__ cells) {
+    int rows, int cols, double alpha_dyn, int n_grids, uint32_t* __restrict__ cells, uint64_t pair_base) {
   const int groups = (cols + 3) / 4;
   const int cgid = blockIdx.x * 4 + (threadIdx.x >> 6);  // one cell group per wave
   if (cgid >= rows * groups) return;
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(256) void k_sample_cellsM_philox(
   const double scale = 100.0 * alpha_dyn;
   const bool pair_store = (n_grids & 1) == 0;  // rows of cellsM are 8-byte aligned
   for (int pr = lane; 2 * pr < n_grids; pr += 64) {
-    const uint64_t pair_index = (uint64_t)pr * (uint64_t)(rows * groups) + (uint64_t)cgid;
+    const uint64_t pair_index = pair_base + (uint64_t)pr * (uint64_t)(rows * groups) + (uint64_t)cgid;
     uint32_t l0, l1, a0, a1;
     draw_packed_pair<MAXB>(lcum, lval, lin_bins, llast, lin_seed, lin_epoch, pair_index, scale, l0, l1);
     draw_packed_pair<MAXB>(acum, aval, ang_bins, alast, ang_seed, ang_epoch, pair_index, scale, a0, a1);

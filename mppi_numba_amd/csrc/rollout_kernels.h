@@ -945,6 +945,37 @@ __global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cel
 }
 
 // -------------------------------------------------------------------------
+// CVaR of control sample n over ALL M = count * m_local traction samples when the samples are
+// sharded over GPUs: slabs[r][n][l] is the cost of (n, sample r*m_local + l)
+// as rank r's k_rollout_tdm* wrote it, all-gathered.  Same sort, same strided float32 tree, same
+// float64 division as the tail of k_rollout_tdm (mppi.py:716-755): the result has the bits of
+// the unsharded launch.
+// -------------------------------------------------------------------------
+__global__ void k_cvar_reduce(const float* __restrict__ slabs, int count, int n_total, int m_local, int numel,
+                              float cvar_alpha, float* __restrict__ costs, float* __restrict__ sample_costs,
+                              int m_pow2) {
+  extern __shared__ float sc_red[];
+  const int n = blockIdx.x, M = count * m_local;
+  for (int m = threadIdx.x; m < m_pow2; m += blockDim.x) {
+    float v = -__builtin_inff();  // padding sorts to the tail
+    if (m < M) {
+      const int r = m / m_local, l = m - r * m_local;
+      v = slabs[((size_t)r * n_total + n) * m_local + l];
+      if (sample_costs) sample_costs[(size_t)n * M + m] = v;
+    }
+    sc_red[m] = v;
+  }
+  __syncthreads();
+  if (cvar_alpha < 1.0f) bitonic_sort_desc(sc_red, m_pow2);
+  for (int st = 1; st < numel; st <<= 1) {
+    for (int i = threadIdx.x; i < M; i += blockDim.x)
+      if ((i % (2 * st) == 0) && (i + st < numel)) sc_red[i] = sc_red[i] + sc_red[i + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) costs[n] = (float)((double)sc_red[0] / (double)numel);
+}
+
+// -------------------------------------------------------------------------
 // barebone notebook rollout: nominal unicycle, quadratic distance cost, disc
 // obstacles tested at the post-step position.
 // -------------------------------------------------------------------------

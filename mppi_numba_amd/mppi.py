@@ -48,7 +48,7 @@ class MPPI_Numba(object):
       7. repeat from 2 when the traction maps change
     """
 
-    def __init__(self, cfg, rank=0, world_size=1):
+    def __init__(self, cfg, rank=0, world_size=1, sample_shard=None):
         self.cfg = cfg
         for name in ("T", "dt", "num_steps", "num_grid_samples", "num_control_rollouts",
                      "max_speed_padding", "tdm_sample_thread_dim", "num_vis_state_rollouts",
@@ -61,6 +61,13 @@ class MPPI_Numba(object):
         # multi-GPU extension: this object owns rollouts [rank*N/world, (rank+1)*N/world)
         self.rank = int(rank)
         self.world_size = int(world_size)
+        # ... or, in the CVaR mode, all N rollouts over traction samples [r*M/G, (r+1)*M/G): sample_shard
+        # = (r, G), with TDM_Numba(cfg, sample_shard=(r, G)) maps; one all-gather of the (N, M/G)
+        # per-sample costs per iteration, every rank then holds all costs and updates locally
+        self.sample_shard = (0, 1) if sample_shard is None else (int(sample_shard[0]), int(sample_shard[1]))
+        if self.sample_shard[1] > 1:
+            assert cfg.use_tdm and self.world_size == 1, "sample shards: use_tdm, and no control-sample shards"
+            assert cfg.num_grid_samples % (2 * self.sample_shard[1]) == 0
         # batched multi-query extension (batch.py): problems solved by this handle
         self.num_instances = int(getattr(self, "num_instances", 1))
 
@@ -121,7 +128,7 @@ class MPPI_Numba(object):
         cfg = _lib.PlannerCfg(
             device=getattr(self.cfg, "device", 0), mode=self._mode(),
             num_control_rollouts=int(self.num_control_rollouts), num_steps=int(self.num_steps),
-            num_grid_samples=int(self.num_grid_samples) if self.use_tdm else 1,
+            num_grid_samples=int(self.num_grid_samples) // self.sample_shard[1] if self.use_tdm else 1,
             num_vis_state_rollouts=int(self.num_vis_state_rollouts),
             rng=_lib.RNG_XOROSHIRO if getattr(self.cfg, "rng", "philox") == "xoroshiro" else _lib.RNG_PHILOX,
             math=_lib.MATH_FAST if getattr(self.cfg, "math", "exact") == "fast" else _lib.MATH_EXACT,
@@ -130,6 +137,8 @@ class MPPI_Numba(object):
         handle = C.c_void_p()
         _lib.call("mppi_planner_create", C.byref(cfg), C.byref(handle))
         self._handle = handle
+        if self.sample_shard[1] > 1:
+            _lib.call("mppi_planner_set_sample_sharding", handle, self.sample_shard[0], self.sample_shard[1])
         # per-GPU rollouts; a batched handle stacks its problems: (B*n_per_problem, ...)
         self.num_local_rollouts = self.num_instances * (self.num_control_rollouts // self.world_size)
         n, t, v = self.num_local_rollouts, self.num_steps, self.num_vis_state_rollouts
@@ -402,6 +411,7 @@ class MPPI_Numba(object):
         _lib.call("mppi_planner_get_sample_costs", self._handle, None)
 
     def sample_costs(self):
+        # (sample shards: all M costs of every control sample, gathered from the shards)
         out = np.empty((self.num_local_rollouts, self.num_grid_samples), dtype=np.float32)
         _lib.call("mppi_planner_get_sample_costs", self._handle, _lib.ptr(out, C.c_float))
         return out
@@ -465,6 +475,20 @@ class MPPI_Numba(object):
         self.move_mppi_task_vars_to_device()
         _lib.call("mppi_planner_update_local", self._handle, _lib.ptr(packet, C.c_double))
         return packet
+
+    # multi-GPU, CVaR mode: M sharded over ranks (sample_shard), host-staged form of the exchange
+    def sample_costs_local(self):
+        """This shard's (N, M/G) per-sample costs of the last rollout()."""
+        out = np.empty((self.num_local_rollouts, self.num_grid_samples // self.sample_shard[1]), dtype=np.float32)
+        _lib.call("mppi_planner_sample_costs_local", self._handle, _lib.ptr(out, C.c_float))
+        return out
+
+    def sample_costs_apply(self, slabs):
+        """The slabs of all G shards in rank order (G, N, M/G) -> costs_d (CVaR over all M)."""
+        slabs = np.ascontiguousarray(slabs, dtype=np.float32)
+        assert slabs.shape == (self.sample_shard[1], self.num_local_rollouts,
+                               self.num_grid_samples // self.sample_shard[1])
+        _lib.call("mppi_planner_sample_costs_apply", self._handle, _lib.ptr(slabs, C.c_float), int(slabs.shape[0]))
 
     def update_apply(self, packets):
         packets = np.ascontiguousarray(packets, dtype=np.float64)

@@ -44,7 +44,7 @@ class TDM_Numba(object):
         5. repeat from 2 when the map changes
     """
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, sample_shard=None):
         self.cfg = cfg
         for name in ("T", "dt", "num_steps", "num_grid_samples", "num_control_rollouts",
                      "max_speed_padding", "tdm_sample_thread_dim", "num_vis_state_rollouts",
@@ -52,6 +52,14 @@ class TDM_Numba(object):
                      "use_nom_dynamics_with_speed_map", "use_costmap"):
             setattr(self, name, getattr(cfg, name))
         self.det_dyn = self.use_det_dynamics or self.use_nom_dynamics_with_speed_map or self.use_costmap
+        # multi-GPU extension (CVaR mode): this object draws samples [rank*M/count, (rank+1)*M/count)
+        # of the M = cfg.num_grid_samples traction maps -- the very draws an unsharded TDM makes
+        self.sample_shard = (0, 1) if sample_shard is None else (int(sample_shard[0]), int(sample_shard[1]))
+        assert 0 <= self.sample_shard[0] < self.sample_shard[1]
+        if self.sample_shard[1] > 1:
+            assert not self.det_dyn, "only use_tdm has samples to shard"
+            assert self.num_grid_samples % (2 * self.sample_shard[1]) == 0, \
+                "num_grid_samples must be a multiple of 2 * shard count"
 
         self.thread_dim = self.tdm_sample_thread_dim
         self.block_dim = (1, self.num_grid_samples)
@@ -123,7 +131,7 @@ class TDM_Numba(object):
             return
         t0 = time.time()
         rows, cols = self.max_map_dim
-        self._num_grids = 1 if self.det_dyn else self.num_grid_samples
+        self._num_grids = 1 if self.det_dyn else self.num_grid_samples // self.sample_shard[1]
         cfg = _lib.TdmCfg(
             device=getattr(self.cfg, "device", 0), num_grids=self._num_grids,
             max_rows=int(rows), max_cols=int(cols),
@@ -133,6 +141,8 @@ class TDM_Numba(object):
         handle = C.c_void_p()
         _lib.call("mppi_tdm_create", C.byref(cfg), C.byref(handle))
         self._handle = handle
+        if self.sample_shard[1] > 1:
+            _lib.call("mppi_tdm_set_sample_shard", handle, self.sample_shard[0] * self._num_grids)
         self.sample_grid_batch_d = DeviceArray((self._num_grids, rows, cols), np.int8,
                                                self._fetch_sampled_grids)
         self.rng_states_d = DeviceArray((self._rng_state_count(), 2), np.uint64, self._fetch_rng_states)

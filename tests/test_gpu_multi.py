@@ -38,6 +38,17 @@ def test_bench_self_launches_two_ranks_on_one_device():
     assert res["value"] > 0 and res["scaling"] == "weak"
 
 
+def test_bench_two_ranks_sharding_the_traction_samples():
+    """north_star's other split: the M traction-map samples of the CVaR workload over the ranks
+    (two processes on this box's one GPU, slabs exchanged through the host hub)."""
+    res, err = run_bench("--gpus", "2", "--workload", "c3", "--shard", "samples", "--steps", "4", "--warmup", "1",
+                         "--n", "256", "--no-cpu-baseline", "--exchange", "host")
+    cfg = res["config"]
+    assert res["n_gpus"] == 2 and cfg["traction_samples"] == 256 and cfg["traction_samples_per_gpu"] == 128
+    assert cfg["global_rollouts"] == 256 and "traction samples over ranks" in cfg["sharding"]
+    assert "k_rollout_tdm" in cfg["rollout_kernel"] and res["value"] > 0
+
+
 def test_bench_under_an_external_launcher_environment():
     """The contract's launch line exports RANK / LOCAL_RANK / WORLD_SIZE: with world 1 that must
     simply be the single-GPU run, with the JSON's rccl rank count reported."""
@@ -80,3 +91,73 @@ def test_graph_replay_captures_the_rccl_all_gather(workload, n):
     assert stats["captures"] >= 1 and stats["replays"] >= 3, stats
     assert np.array_equal(direct.u_cur_d.copy_to_host(), graph.u_cur_d.copy_to_host())
     assert np.array_equal(direct.costs_d.copy_to_host(), graph.costs_d.copy_to_host())
+
+
+def _cvar_build(n, m, shard=None, seed=1):
+    """C3-shaped CVaR problem (bench.py's world) with the traction samples optionally sharded."""
+    import bench
+    from mppi_numba_amd.config import Config
+    from mppi_numba_amd.mppi import MPPI_Numba
+    from mppi_numba_amd.terrain import TDM_Numba
+    w = dict(bench.WORKLOADS["c3"])
+    cfg = Config(T=w["t"] * 0.1, dt=0.1, num_grid_samples=m, num_control_rollouts=n, max_speed_padding=5.0,
+                 num_vis_state_rollouts=1, max_map_dim=(260, 260), seed=seed, enforce_recommended_limits=False,
+                 **w["mode"])
+    pmf, obstacle, unknown, tdm_dict = bench.synthetic_world("c3", np.random.default_rng(0))
+    lin, ang = TDM_Numba(cfg, sample_shard=shard), TDM_Numba(cfg, sample_shard=shard)
+    lin.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
+    ang.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
+    planner = MPPI_Numba(cfg, sample_shard=shard)
+    params = bench.make_params("c3")
+    planner.setup(params, lin, ang)
+    return lin, ang, planner, params
+
+
+@pytest.mark.parametrize("n,m,shards", [(256, 128, 2), (256, 128, 4), (128, 1024, 8), (64, 24, 2), (64, 4096, 2)])
+def test_sample_sharded_cvar_has_the_bits_of_the_unsharded_launch(n, m, shards):
+    """SURVEY.md 8e / north_star: the M traction samples sharded over G ranks (here G handles on one
+    GPU, the all-gather done by hand): the shards' grids are the unsharded draws, the gathered
+    per-sample costs are the unsharded ones, and every rank's CVaR costs and control update have
+    the BITS of the single-GPU launch -- over several iterations."""
+    lin, ang, full, params = _cvar_build(n, m)
+    parts = [_cvar_build(n, m, shard=(r, shards)) for r in range(shards)]
+    u0 = np.zeros((full.num_steps, 2), dtype=np.float32)
+    full.record_sample_costs()
+    for _, _, p, _ in parts:
+        p.record_sample_costs()
+    for step in range(3):
+        handles = [(lin, ang, full)] + [(a, b, c) for a, b, c, _ in parts]
+        for tl, ta, p in handles:
+            if step == 0:
+                p.set_u(u0)
+            tl.sample_grids(params["alpha_dyn"])  # (solve() does this once per call)
+            ta.sample_grids(params["alpha_dyn"])
+            p.sample_noise()
+            p.rollout()
+        ml = m // shards
+        want_grid = lin.sample_grid_batch_d.copy_to_host()
+        for r, (tl, ta, p, _) in enumerate(parts):
+            np.testing.assert_array_equal(tl.sample_grid_batch_d.copy_to_host(), want_grid[r * ml:(r + 1) * ml])
+            np.testing.assert_array_equal(p.noise_samples_d.copy_to_host(), full.noise_samples_d.copy_to_host())
+        slabs = np.stack([p.sample_costs_local() for _, _, p, _ in parts])
+        assert slabs.shape == (shards, n, ml)
+        want_sc = full.sample_costs()
+        np.testing.assert_array_equal(np.concatenate(list(slabs), axis=1), want_sc)
+        full.update()
+        for _, _, p, _ in parts:
+            p.sample_costs_apply(slabs)
+            np.testing.assert_array_equal(p.costs_d.copy_to_host(), full.costs_d.copy_to_host())
+            np.testing.assert_array_equal(p.sample_costs(), want_sc)
+            p.update()
+            np.testing.assert_array_equal(p.u_cur_d.copy_to_host(), full.u_cur_d.copy_to_host())
+    assert np.abs(full.u_cur_d.copy_to_host()).max() > 0
+
+
+def test_sample_sharded_loop_needs_a_communicator_and_runs_with_one():
+    """solve() of a sample-sharded handle refuses to run without RCCL; with a communicator of its
+    own size (1 rank here is all one GPU offers: a degenerate shard layout cannot be declared, so
+    the error path is what this box can show) the message names the way out."""
+    from mppi_numba_amd._lib import MppiError
+    lin, ang, p, params = _cvar_build(64, 8, shard=(0, 2))
+    with pytest.raises(MppiError, match="no communicator"):
+        p.solve()

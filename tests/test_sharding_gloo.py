@@ -94,6 +94,81 @@ def test_sharded_update_over_gloo_world2():
         assert worst <= 1e-5 * np.pi, (rank, worst)
 
 
+def cvar_of_all_samples(per_sample, alpha):
+    """mppi.py:716-755 on the gathered (N, M) per-sample costs: sort descending when alpha < 1,
+    float32 strided tree over the first ceil(M*alpha), float64 division (what k_cvar_reduce does)."""
+    n, m = per_sample.shape
+    numel = min(m, max(1, int(np.ceil(m * float(np.float32(alpha))))))
+    sc = per_sample.astype(np.float32).copy()
+    if np.float32(alpha) < 1.0:
+        sc = -np.sort(-sc, axis=1)
+    s = 1
+    while s < numel:
+        for i in range(0, m, 2 * s):
+            if i + s < numel:
+                sc[:, i] = sc[:, i] + sc[:, i + s]
+        s *= 2
+    return (sc[:, 0].astype(np.float64) / numel).astype(np.float32)
+
+
+def _sample_worker(rank, world, port, q):
+    """The M traction samples sharded over the ranks: every rank rolls all N controls
+    over ITS grids, one all-gather of the (N, M/G) cost slabs, every rank reduces all M."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from helpers import golden, iterations, params_from_golden
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        checked = 0
+        for name in ("tdm_cvar", "tdm_cvar_odd", "tdm_mean_alpha_dyn", "tdm_odd_units"):
+            g = golden(name)
+            P = params_from_golden(g)
+            p = O.make_params(dict(P, x0=g["solve0_x0"]), g["lin_res"], g["lin_padded_xlimits"], g["lin_padded_ylimits"],
+                              g["lin_bin_values_bounds"], g["ang_bin_values_bounds"])
+            it = iterations(g)[0]
+            lin, ang = g["solve0_lin_sample_grid"], g["solve0_ang_sample_grid"]
+            m = lin.shape[0]
+            if m % world:
+                continue
+            lo, hi = rank * m // world, (rank + 1) * m // world
+            _, slab = O.rollout_tdm(p, lin[lo:hi], ang[lo:hi], g["lin_obstacle_map_padded"], g["lin_unknown_map_padded"],
+                                    it["noise"], it["u_in"], want_per_sample=True)
+            gathered = [torch.zeros(slab.shape, dtype=torch.float32) for _ in range(world)]
+            dist.all_gather(gathered, torch.from_numpy(np.ascontiguousarray(slab)))
+            per_sample = np.concatenate([t.numpy() for t in gathered], axis=1)
+            costs = cvar_of_all_samples(per_sample, P["cvar_alpha"])
+            np.testing.assert_array_equal(costs, it["costs"])  # the REFERENCE's costs, bit for bit
+            _, u, _ = O.update_useq(P["lambda_weight"], costs, it["noise"], P["vrange"], P["wrange"], it["u_in"])
+            _, want, _ = O.update_useq(P["lambda_weight"], it["costs"], it["noise"], P["vrange"], P["wrange"], it["u_in"])
+            np.testing.assert_array_equal(u, want)
+            checked += 1
+        q.put((rank, checked))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sample_sharded_cvar_over_gloo_world2():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sample_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(checked >= 2 for _, checked in results), results
+
+
 def test_shard_ranges_cover_all_rollouts():
     for n, world in ((8192, 1), (8192, 8), (65536, 4)):
         seen = np.zeros(n, dtype=int)
