@@ -263,6 +263,11 @@ int mppi_planner_stage_times(mppi_planner* p, float ms[4]);
  * last solve too while profiling is enabled; solve() does not time itself otherwise) */
 int mppi_planner_last_elapsed_ms(mppi_planner* p, float* ms);
 
+/* tracing hook: with MPPI_ROCTX=1 in the environment the library brackets solve / sample_grids /
+ * noise / rollout / exchange / update / closed_loop with roctx ranges (names "mppi:...") for
+ * `rocprofv3 --marker-trace --kernel-trace`; returns 1 when the ranges are live, else 0 */
+int mppi_trace_ranges_enabled(void);
+
 /* diagnostic: which rollout kernel variant (and its launch geometry) the last rollout used */
 int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity);
 

@@ -76,6 +76,7 @@ _vp = C.c_void_p
 # name -> argtypes; every entry point of include/mppi_hip.h (restype int unless noted)
 SIGNATURES = {
     "mppi_abi_version": [],
+    "mppi_trace_ranges_enabled": [],
     "mppi_device_count": [C.POINTER(C.c_int)],
     "mppi_device_props_get": [C.c_int, C.POINTER(DeviceProps)],
     "mppi_tdm_create": [C.POINTER(TdmCfg), C.POINTER(_vp)],

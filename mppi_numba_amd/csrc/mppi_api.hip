@@ -532,6 +532,54 @@ extern "C" int mppi_tdm_rng_states(mppi_tdm* t, uint64_t* out, long capacity, lo
 }
 
 // ---------------------------------------------------------------------------
+// roctx ranges (tracing hook): MPPI_ROCTX=1 marks, on the host thread that
+// enqueues them, solve / sample_grids / noise / rollout / exchange / update / closed_loop, for
+// `rocprofv3 --marker-trace --kernel-trace`.  The library is looked up at run time; without the
+// variable (or the library) a range costs one predictable branch.
+// ---------------------------------------------------------------------------
+struct RoctxApi {
+  bool tried = false;
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+};
+static RoctxApi g_roctx;
+
+static void roctx_load() {
+  g_roctx.tried = true;
+  const char* on = getenv("MPPI_ROCTX");
+  if (!on || !*on || *on == '0') return;
+  const char* names[] = {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so",
+                         "libroctx64.so.4", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "/opt/rocm/lib/libroctx64.so"};
+  for (const char* n : names) {
+    void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) continue;
+    g_roctx.push = (decltype(g_roctx.push))dlsym(h, "roctxRangePushA");
+    g_roctx.pop = (decltype(g_roctx.pop))dlsym(h, "roctxRangePop");
+    if (g_roctx.push && g_roctx.pop) return;
+    g_roctx.push = nullptr;
+    g_roctx.pop = nullptr;
+  }
+}
+
+struct TraceRange {
+  bool open = false;
+  explicit TraceRange(const char* name) {
+    if (!g_roctx.tried) roctx_load();
+    if (g_roctx.push) { g_roctx.push(name); open = true; }
+  }
+  ~TraceRange() {
+    if (open) g_roctx.pop();
+  }
+  TraceRange(const TraceRange&) = delete;
+  TraceRange& operator=(const TraceRange&) = delete;
+};
+
+extern "C" int mppi_trace_ranges_enabled(void) {
+  if (!g_roctx.tried) roctx_load();
+  return g_roctx.push ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
 // RCCL, loaded on first use so that single-GPU users never touch it
 // ---------------------------------------------------------------------------
 struct RcclApi {
@@ -1819,6 +1867,7 @@ static int launch_update(mppi_planner* p, bool prof, bool defer_exchange = false
   const int len = p->B * packet_len(p->cfg.num_steps);
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[3], p->stream));
   // one all-gather of (2T+2) doubles per problem and iteration, in place
+  TraceRange tr("mppi:all_gather_packets");
   RCCL_TRY(g_rccl.AllGather(p->packets + (size_t)p->cfg.rank * len, p->packets, (size_t)len, ncclDouble, p->comm,
                             p->stream));
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[4], p->stream));
@@ -1842,6 +1891,7 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
     if (p->noise_on_side_stream) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_noise_ready, 0));
     p->noise_on_side_stream = false;
   } else {
+    TraceRange tr("mppi:noise");
     TRY(launch_noise(p, p->noise_buf[p->noise_cur]));
   }
   p->noise = p->noise_buf[p->noise_cur];
@@ -1850,11 +1900,18 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[1], p->stream));
   // the other noise buffer was last read by the previous update, which is behind us on this stream
   if (want_next && side_stream_pays) HIP_TRY(hipEventRecord(p->ev_buf_free, p->stream));
-  TRY(launch_rollout(p, d));
-  TRY(exchange_sample_costs(p));
+  {
+    TraceRange tr("mppi:rollout");
+    TRY(launch_rollout(p, d));
+  }
+  if (p->m_count > 1) {
+    TraceRange tr("mppi:exchange_sample_costs");
+    TRY(exchange_sample_costs(p));
+  }
   have_noise = p->next_noise_done;
   if (want_next && !have_noise && side_stream_pays) {
     HIP_TRY(hipStreamWaitEvent(p->noise_stream, p->ev_buf_free, 0));
+    TraceRange tr("mppi:noise_ahead");
     TRY(launch_noise(p, p->noise_buf[p->noise_cur ^ 1], p->noise_stream));
     HIP_TRY(hipEventRecord(p->ev_noise_ready, p->noise_stream));
     have_noise = p->noise_on_side_stream = true;
@@ -1867,6 +1924,7 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
   }
   p->next_noise_wanted = false;
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[2], p->stream));
+  TraceRange tr_update("mppi:update");
   TRY(launch_update(p, prof, defer_exchange));
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[5], p->stream));
   return MPPI_OK;
@@ -2025,6 +2083,7 @@ extern "C" int mppi_planner_synchronize(mppi_planner* p) {
 // (mppi.py:247-248, 321-322, 391-394); the deterministic modes pass alpha_dyn = 1
 static int sample_for_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang) {
   if (p->cfg.mode == MPPI_MODE_BAREBONE) return MPPI_OK;
+  TraceRange tr("mppi:sample_grids");
   double alpha = (p->cfg.mode == MPPI_MODE_TDM) ? p->params.alpha_dyn : 1.0;
   int rc = MPPI_OK;
   if (sample_into_cells(p, lin, ang, alpha, &rc)) return rc;
@@ -2037,6 +2096,7 @@ extern "C" int mppi_planner_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang,
   REQUIRE(p && u_out, MPPI_ERR_INVALID, "NULL argument");
   REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
   HIP_TRY(hipSetDevice(p->cfg.device));
+  TraceRange tr("mppi:solve");
   TRY(check_tdms(p, lin, ang));
   TRY(sample_for_solve(p, lin, ang));
   TRY(run_iterations(p, lin, ang, p->params.num_opt, /*timed=*/false));
@@ -2177,6 +2237,7 @@ extern "C" int mppi_planner_closed_loop(mppi_planner* p, mppi_tdm* lin, mppi_tdm
   REQUIRE(w->device == p->cfg.device, MPPI_ERR_INVALID, "world on device %d, planner on %d", w->device, p->cfg.device);
   REQUIRE(max_steps >= 1 && max_steps <= (1 << 20), MPPI_ERR_INVALID, "max_steps %d", max_steps);
   HIP_TRY(hipSetDevice(p->cfg.device));
+  TraceRange tr("mppi:closed_loop");
   TRY(check_tdms(p, lin, ang));
   const int B = p->B, T = p->cfg.num_steps;
   if (!p->loop_done_count) {
@@ -2257,6 +2318,7 @@ extern "C" int mppi_planner_closed_loop(mppi_planner* p, mppi_tdm* lin, mppi_tdm
     HIP_TRY(hipGetLastError());
     ++launched;
     if (launched % check_every == 0) {
+      TraceRange tr_wait("mppi:closed_loop_check");
       HIP_TRY(hipStreamSynchronize(p->stream));
       if (*p->loop_done_count >= B) break;
     }

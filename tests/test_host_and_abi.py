@@ -222,3 +222,17 @@ def test_mean_risk_map_scales_like_the_reference_for_any_bounds():
         other_order = np.reshape(100 * np.asarray((weighted[-1] - bounds[0]) / traction_range), (1, rows, cols)).astype(np.int8)
         differing += int((other_order != want_mean).sum())
     assert differing > 0  # the sweep does exercise the distinction
+
+
+def test_roctx_ranges_are_opt_in():
+    """SURVEY.md section 5 tracing hook: MPPI_ROCTX=1 turns the roctx ranges on (the marker library
+    ships with ROCm), nothing is loaded otherwise."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from mppi_numba_amd import _lib; "
+            "print(_lib.load().mppi_trace_ranges_enabled())" % ROOT)
+    env = dict(os.environ)
+    env.pop("MPPI_ROCTX", None)
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout.strip() == "0"
+    env["MPPI_ROCTX"] = "1"
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout.strip() == "1"
