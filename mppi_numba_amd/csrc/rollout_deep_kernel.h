@@ -125,7 +125,13 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
 #pragma unroll
       for (int j = 0; j < CH; ++j) dst[j] = at[j * 64];
     };
+    // (the first two runs of 64 controls are requested BEFORE the noise: loads come back in order,
+    //  and behind 32 noise loads each of the two dependent trips of the staging loop below cost
+    //  ~2k cycles of the prologue)
+    float2 u_first[2];
     if (wave == kP) {
+      u_first[0] = uq[min(lane, T - 1)];
+      u_first[1] = uq[min(lane + 64, T - 1)];
       load_noise(e[0], 0);
       load_noise(e[1], 1);
       load_noise(e[2], 2);
@@ -180,7 +186,16 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
         reinterpret_cast<u32x4*>(lds_map)[i] = src[source_of(i)];
     }
     if (wave == kP) {
-      for (int t = lane; t < Tp; t += 64) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int t = lane + 64 * r;
+        if (t < Tp) {
+          const float2 ut = t < T ? u_first[r] : make_float2(0.0f, 0.0f);
+          us[t] = ut;
+          uos[t] = make_double2((double)ut.x / Q.s0sq, (double)ut.y / Q.s1sq);
+        }
+      }
+      for (int t = lane + 128; t < Tp; t += 64) {
         const float2 ut = t < T ? uq[t] : make_float2(0.0f, 0.0f);
         us[t] = ut;
         uos[t] = make_double2((double)ut.x / Q.s0sq, (double)ut.y / Q.s1sq);

@@ -110,6 +110,29 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
   [[maybe_unused]] const bool stamp_wg = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0;
   MPPI_STAMP(stamp_wg, 512);
   const double neg_inv_lambda = -1.0 / (double)lambda;
+  // rows past the horizon (last workgroup) are clamped for the loads and never written
+  size_t row_off[TC];
+#pragma unroll
+  for (int j = 0; j < TC; ++j) row_off[j] = (size_t)min(t0 + j, n_steps - 1) * 64;
+  constexpr int UN = TC == 1 ? 8 : 2;  // independent loads in flight per thread: UN * (TC + 1)
+  // The first batch of this thread's weights and noise is requested before the minimum / scale
+  // prologue below, which needs ~2k cycles of its own: the stream's first round trip hides behind it.
+  // (loads return in order: the tile minima the prologue waits for go first)
+  float tb0 = __builtin_inff();
+  if (!FROM_COSTS && (int)threadIdx.x < n_tiles) tb0 = tile_beta[threadIdx.x];
+  float wr0[UN];
+  float2 e0[UN][TC];
+  const bool have0 = (int)threadIdx.x + (UN - 1) * kRowThreads < n;
+  if (have0) {
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      const int idx = threadIdx.x + k * kRowThreads;
+      wr0[k] = w_rel[idx];
+      const float2* tile = noise + (size_t)(idx >> 6) * n_steps * 64 + (idx & 63);
+#pragma unroll
+      for (int j = 0; j < TC; ++j) e0[k][j] = tile[row_off[j]];
+    }
+  }
   float* tb_sh = scale_sh + n_tiles;  // FROM_COSTS: [n_tiles] tile minima
   if (FROM_COSTS) {
     for (int g = wave; g < n_tiles; g += kRowThreads / 64) {
@@ -120,27 +143,41 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
     __syncthreads();
     tile_beta = tb_sh;
   }
-  float b = __builtin_inff();
-  for (int g = threadIdx.x; g < n_tiles; g += kRowThreads) b = fminf(b, tile_beta[g]);
+  float b = tb0;
+  for (int g = threadIdx.x + (FROM_COSTS ? 0 : kRowThreads); g < n_tiles; g += kRowThreads) b = fminf(b, tile_beta[g]);
   b = wave_min_f32(b);
   if (lane == 0) redf[wave] = b;
   __syncthreads();
   MPPI_STAMP(stamp_wg, 513);
   float beta = redf[0];
   for (int k = 1; k < kRowThreads / 64; ++k) beta = fminf(beta, redf[k]);
-  for (int g = threadIdx.x; g < n_tiles; g += kRowThreads)
+  if (!FROM_COSTS && (int)threadIdx.x < n_tiles) scale_sh[threadIdx.x] = (float)exp(neg_inv_lambda * (double)(tb0 - beta));
+  for (int g = threadIdx.x + (FROM_COSTS ? 0 : kRowThreads); g < n_tiles; g += kRowThreads)
     scale_sh[g] = (float)exp(neg_inv_lambda * (double)(tile_beta[g] - beta));
   __syncthreads();
   MPPI_STAMP(stamp_wg, 514);
   double den = 0.0, nx[TC], ny[TC];
 #pragma unroll
   for (int j = 0; j < TC; ++j) nx[j] = ny[j] = 0.0;
-  // rows past the horizon (last workgroup) are clamped for the loads and never written
-  size_t row_off[TC];
-#pragma unroll
-  for (int j = 0; j < TC; ++j) row_off[j] = (size_t)min(t0 + j, n_steps - 1) * 64;
-  constexpr int UN = TC == 1 ? 8 : 2;  // independent loads in flight per thread: UN * (TC + 1)
   int i = threadIdx.x;                 // kRowThreads is a multiple of 64: i>>6 is the tile, i&63 the lane
+  auto consume = [&](int at, float (&wr)[UN], float2 (&e)[UN][TC]) {
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      const int tile = (at + k * kRowThreads) >> 6;
+      if (FROM_COSTS) wr[k] = (float)exp(neg_inv_lambda * (double)(wr[k] - tb_sh[tile]));  // emit_tile_weights
+      double w = (double)scale_sh[tile] * (double)wr[k];
+      den += w;
+#pragma unroll
+      for (int j = 0; j < TC; ++j) {
+        nx[j] = fma(w, (double)e[k][j].x, nx[j]);
+        ny[j] = fma(w, (double)e[k][j].y, ny[j]);
+      }
+    }
+  };
+  if (have0) {
+    consume(i, wr0, e0);
+    i += UN * kRowThreads;
+  }
   for (; i + (UN - 1) * kRowThreads < n; i += UN * kRowThreads) {
     float wr[UN];
     float2 e[UN][TC];
@@ -152,18 +189,7 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
 #pragma unroll
       for (int j = 0; j < TC; ++j) e[k][j] = tile[row_off[j]];
     }
-#pragma unroll
-    for (int k = 0; k < UN; ++k) {
-      const int tile = (i + k * kRowThreads) >> 6;
-      if (FROM_COSTS) wr[k] = (float)exp(neg_inv_lambda * (double)(wr[k] - tb_sh[tile]));  // emit_tile_weights
-      double w = (double)scale_sh[tile] * (double)wr[k];
-      den += w;
-#pragma unroll
-      for (int j = 0; j < TC; ++j) {
-        nx[j] = fma(w, (double)e[k][j].x, nx[j]);
-        ny[j] = fma(w, (double)e[k][j].y, ny[j]);
-      }
-    }
+    consume(i, wr, e);
   }
   for (; i < n; i += kRowThreads) {
     float wr1 = w_rel[i];
