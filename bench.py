@@ -403,6 +403,12 @@ def main():
         for k, v in planner.stage_times_ms().items():
             stage[k] += v / reps
     planner.set_profiling(False)
+    # the dominant kernels inside the ordinary loop: every launch carries its own start / stop HIP
+    # events, which the runtime fills with the dispatch's begin / end timestamps (what rocprofv3
+    # --kernel-trace reports); nothing is inserted between the kernels
+    kernel_us = None
+    if world == 1 and group_size == 1 and not args.graph:
+        kernel_us = planner.time_kernels(200)
 
     if rank != 0:
         barrier()
@@ -418,7 +424,7 @@ def main():
             traffic = json.load(fh).get(args.workload, {}).get("dominant_kernel_hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
-    roll_s = stage["rollout"] * 1e-3
+    roll_s = kernel_us[0] * 1e-6 if kernel_us else stage["rollout"] * 1e-3
     achieved = bytes_roll / roll_s / 1e9 if roll_s > 0 else 0.0
     out = {
         "metric": "rollouts/sec (MPPI iteration = noise + rollout + update)",
@@ -451,7 +457,12 @@ def main():
         "kernel_ms": stage,
         "kernel_ms_note": "each stage of ONE iteration bracketed by its own HIP events on the planner's stream; every "
                           "bracket adds ~3 us of event overhead, so the stages sum to more than ms_per_step (which has "
-                          "no events inside the loop); rocprofv3 durations of the same kernels: profiles/",
+                          "no events inside the loop); kernel_us_in_loop has no such overhead",
+        "kernel_us_in_loop": None if not kernel_us else
+            {"rollout": kernel_us[0], "update": kernel_us[1],
+             "how": "200 ordinary iterations; every rollout / update launch carries its own start / stop HIP events "
+                    "(hipExtLaunchKernelGGL: the dispatch's begin / end timestamps, as rocprofv3 --kernel-trace "
+                    "reports them; averages agree with profiles/)"},
         "roofline": {"bound": "hbm",
                      "kernel": kernel_name + (" (rollout + next iteration's noise)" if kernel_name in ("k_rollout_pipe", "k_rollout_spec", "k_rollout_deep") else ""),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -459,7 +470,8 @@ def main():
                      "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                        "kernel on this workload (committed; not re-measured in this run)",
                      "algorithmic_bytes_per_launch": bytes_roll,
-                     "kernel_ms": stage["rollout"]},
+                     "kernel_ms": roll_s * 1e3,
+                     "duration_source": "kernel_us_in_loop.rollout" if kernel_us else "kernel_ms.rollout (event bracket)"},
         "roofline_iteration": {"bound": "hbm", "achieved": bytes_iter / (ms_per_step * 1e-3) / 1e9,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": bytes_iter / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -259,6 +259,13 @@ int mppi_planner_rng_states(mppi_planner* p, uint64_t* out, long capacity, long*
  * [0] noise  [1] rollout  [2] update (weights + weighted sum + apply)  [3] collective */
 int mppi_planner_set_profiling(mppi_planner* p, int enabled);
 int mppi_planner_stage_times(mppi_planner* p, float ms[4]);
+/* (new; measurement) average duration in microseconds of the rollout launch and of the update
+ * launch over `reps` ordinary iterations of the loop (iterate_async): every launch carries its
+ * own start / stop events, filled by the runtime with the dispatch's begin / end timestamps --
+ * the durations rocprofv3 --kernel-trace reports -- with nothing inserted between the kernels
+ * (bench.py's roofline figures). */
+int mppi_planner_time_kernels(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int reps, float* us_rollout,
+                              float* us_update);
 /* GPU time (ms, hipEvents on the planner's stream) of the last iterate_async call (of the
  * last solve too while profiling is enabled; solve() does not time itself otherwise) */
 int mppi_planner_last_elapsed_ms(mppi_planner* p, float* ms);

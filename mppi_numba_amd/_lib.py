@@ -118,6 +118,7 @@ SIGNATURES = {
     "mppi_planner_set_profiling": [_vp, C.c_int],
     "mppi_planner_stage_times": [_vp, _f32p],
     "mppi_planner_last_elapsed_ms": [_vp, _f32p],
+    "mppi_planner_time_kernels": [_vp, _vp, _vp, C.c_int, _f32p, _f32p],
     "mppi_planner_describe_last_rollout": [_vp, C.c_char_p, C.c_int],
     "mppi_planner_set_debug_flags": [_vp, C.c_int],
     "mppi_selftest_philox": [C.c_int, C.POINTER(C.c_int)],

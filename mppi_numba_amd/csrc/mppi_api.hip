@@ -5,6 +5,7 @@
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -729,6 +730,11 @@ struct mppi_planner {
   float last_elapsed_ms = 0.f;
   bool elapsed_pending = false;
   int last_iterations = 0;
+  // mppi_planner_time_kernels: dispatch begin / end of the rollout and update launches of the
+  // iterations it runs (4 events per iteration), picked up by MPPI_KLAUNCH
+  hipEvent_t kev_start = nullptr, kev_stop = nullptr;
+  std::vector<hipEvent_t> ktime_events;
+  int ktime_index = -1;
   // comm
   ncclComm_t comm = nullptr;
   // CVaR mode with the M traction samples sharded over GPUs (mppi_planner_set_sample_sharding):
@@ -785,6 +791,8 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   dev_free(p->obs_r);
   dev_free(p->state_rollout);
   dev_free(p->slabs);
+  for (hipEvent_t e : p->ktime_events)
+    if (e) (void)hipEventDestroy(e);
   dev_free(p->loop_state);
   dev_free(p->loop_xhist);
   dev_free(p->loop_uhist);
@@ -1361,6 +1369,12 @@ static int upload_instances(mppi_planner* p) {
   return MPPI_OK;
 }
 
+// Rollout and update launches go through the extended launch call: with p->kev_start / kev_stop
+// set (mppi_planner_time_kernels) the runtime stamps the dispatch's own begin / end -- what
+// rocprofv3 reads -- into those events; with both null it is an ordinary launch.
+#define MPPI_KLAUNCH(kernel, grid, block, lds, stream, ...) \
+  hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, p->kev_start, p->kev_stop, 0, __VA_ARGS__)
+
 template <bool EXACT, bool BOUNDED>
 static int launch_rollout_t(mppi_planner* p, DevParams d) {
   const int N = p->n_local, T = p->cfg.num_steps, M = p->cfg.num_grid_samples;
@@ -1400,8 +1414,9 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         auto ring_size = [](int c) {
           return c == 8 ? (size_t)DeepRing<8>::kBytes : c == 4 ? (size_t)DeepRing<4>::kBytes : (size_t)DeepRing<2>::kBytes;
         };
+        static const int forced_chunk = getenv("MPPI_DEEP_CHUNK") ? atoi(getenv("MPPI_DEEP_CHUNK")) : 0;  // developer switch
         for (int cnd : {8, 4, 2})
-          if (head + map_bytes + ring_size(cnd) <= budget) { chunk = cnd; break; }
+          if (head + map_bytes + ring_size(cnd) <= budget && (!forced_chunk || cnd <= forced_chunk)) { chunk = cnd; break; }
         // (chunks of 8 with the control-cost products in LDS, else of 4 with them in LDS, else as found)
         if (chunk == 8 && head + map_bytes + ring_size(8) + cc_bytes > budget &&
             head + map_bytes + ring_size(4) + cc_bytes <= budget)
@@ -1431,7 +1446,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
     if (lds_total > 64 * 1024)                                                                        \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));       \
-    hipLaunchKernelGGL(kern, dim3(grid + extra), dim3(64 * kDeepWaves), lds_total, p->stream, d,      \
+    MPPI_KLAUNCH(kern, dim3(grid + extra), dim3(64 * kDeepWaves), lds_total, p->stream, d,      \
                        p->cells16, p->noise, p->u, p->costs, p->w_rel, p->tile_beta, p->cc_scratch,   \
                        (int)map_bytes, grid, speculate, next_job);                                     \
   } while (0)
@@ -1508,7 +1523,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
     if (lds_total > 64 * 1024)                                                                        \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));       \
-    hipLaunchKernelGGL(kern, dim3(grid + extra), dim3(block), lds_total, p->stream, d, p->cells16,    \
+    MPPI_KLAUNCH(kern, dim3(grid + extra), dim3(block), lds_total, p->stream, d, p->cells16,    \
                        p->noise, p->u, p->costs, p->w_rel, p->tile_beta, p->cc_scratch,                \
                        (int)map_bytes, grid, speculate, next_job);                                     \
   } while (0)
@@ -1584,7 +1599,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
     if (lds_total > 64 * 1024)                                                                        \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));       \
-    hipLaunchKernelGGL(kern, dim3(grid + extra), dim3(block), lds_total, p->stream, d, p->cells16,    \
+    MPPI_KLAUNCH(kern, dim3(grid + extra), dim3(block), lds_total, p->stream, d, p->cells16,    \
                        p->noise, p->u, p->costs, p->w_rel, p->tile_beta, p->cc_scratch,                \
                        (int)map_bytes, grid, next_job);                                                \
   } while (0)
@@ -1626,7 +1641,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
           if (lds_win > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fused),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
-          hipLaunchKernelGGL(fused, dim3(ceil_div(N, block)), dim3(block), lds_win, p->stream, d, p->cells16,
+          MPPI_KLAUNCH(fused, dim3(ceil_div(N, block)), dim3(block), lds_win, p->stream, d, p->cells16,
                              p->noise, p->u, p->costs, p->w_rel, p->tile_beta);
           char buf[200];
           snprintf(buf, sizeof(buf), "k_rollout_fused pow2res=%d waves_per_wg=%d window=%dx%d problems=%d",
@@ -1639,7 +1654,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         if (lds_win > 64 * 1024)
           HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
-        hipLaunchKernelGGL(kern, dim3(ceil_div(N, block)), dim3(block), lds_win, p->stream, d, p->cells,
+        MPPI_KLAUNCH(kern, dim3(ceil_div(N, block)), dim3(block), lds_win, p->stream, d, p->cells,
                            p->cells16, (const int8_t*)nullptr, p->noise, p->u, p->costs);
         {
           char buf[200];
@@ -1648,7 +1663,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
           p->last_rollout = buf;
         }
       } else {
-        hipLaunchKernelGGL((k_rollout_map<MAP_DET, EXACT, BOUNDED, false>), dim3(ceil_div(N, 64)), dim3(64),
+        MPPI_KLAUNCH((k_rollout_map<MAP_DET, EXACT, BOUNDED, false>), dim3(ceil_div(N, 64)), dim3(64),
                            lds_map, p->stream, d, p->cells, (const uint16_t*)nullptr, (const int8_t*)nullptr,
                            p->noise, p->u, p->costs);
         p->last_rollout = "k_rollout_map det global_cells exact=" + std::to_string((int)EXACT);
@@ -1673,7 +1688,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         if (lds_win > 64 * 1024)
           HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fused),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
-        hipLaunchKernelGGL(fused, dim3(ceil_div(N, 64 * waves)), dim3(64 * waves), lds_win, p->stream, d, p->cells16,
+        MPPI_KLAUNCH(fused, dim3(ceil_div(N, 64 * waves)), dim3(64 * waves), lds_win, p->stream, d, p->cells16,
                            p->noise, p->u, p->costs, p->w_rel, p->tile_beta);
         char buf[200];
         snprintf(buf, sizeof(buf), "k_rollout_fused speed_map pow2res=%d waves_per_wg=%d window=%dx%d problems=%d",
@@ -1682,7 +1697,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         p->tile_packets_fresh = true;
         break;
       }
-      hipLaunchKernelGGL((k_rollout_map<MAP_SPEED, EXACT, BOUNDED, false>), dim3(ceil_div(N, 64)), dim3(64),
+      MPPI_KLAUNCH((k_rollout_map<MAP_SPEED, EXACT, BOUNDED, false>), dim3(ceil_div(N, 64)), dim3(64),
                          lds_map, p->stream, d, p->cells, (const uint16_t*)nullptr, (const int8_t*)p->risk_ref,
                          p->noise, p->u, p->costs);
       p->last_rollout = "k_rollout_map speed_map global_cells exact=" + std::to_string((int)EXACT);
@@ -1715,23 +1730,23 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
           const bool pow2res = std::frexp((double)a.res, &res_exp) == 0.5;
           float* sc_out = sc_dst;
           if (pow2res)
-            hipLaunchKernelGGL((k_rollout_tdm_fast<true>), dim3(N), dim3(threads), lds_fast, p->stream, d, p->cells,
+            MPPI_KLAUNCH((k_rollout_tdm_fast<true>), dim3(N), dim3(threads), lds_fast, p->stream, d, p->cells,
                                p->noise, p->u, p->costs, sc_out, mp2);
           else
-            hipLaunchKernelGGL((k_rollout_tdm_fast<false>), dim3(N), dim3(threads), lds_fast, p->stream, d, p->cells,
+            MPPI_KLAUNCH((k_rollout_tdm_fast<false>), dim3(N), dim3(threads), lds_fast, p->stream, d, p->cells,
                                p->noise, p->u, p->costs, sc_out, mp2);
           p->last_rollout = std::string("k_rollout_tdm_fast pow2res=") + (pow2res ? "1" : "0");
           break;
         }
       }
-      hipLaunchKernelGGL((k_rollout_tdm<EXACT>), dim3(N), dim3(threads), lds, p->stream, d, p->cells, p->noise,
+      MPPI_KLAUNCH((k_rollout_tdm<EXACT>), dim3(N), dim3(threads), lds, p->stream, d, p->cells, p->noise,
                          p->u, p->costs, sc_dst, mp2);
       p->last_rollout = "k_rollout_tdm exact=" + std::to_string((int)EXACT);
       break;
     }
     case MPPI_MODE_BAREBONE:
       p->tile_packets_fresh = false;
-      hipLaunchKernelGGL((k_rollout_barebone<EXACT>), dim3(ceil_div(N, 64)), dim3(64), lds, p->stream, d,
+      MPPI_KLAUNCH((k_rollout_barebone<EXACT>), dim3(ceil_div(N, 64)), dim3(64), lds, p->stream, d,
                          p->obs_pos, p->obs_r, p->noise, p->u, p->costs);
       p->last_rollout = "k_rollout_barebone exact=" + std::to_string((int)EXACT);
       break;
@@ -1808,7 +1823,7 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
   // from the costs (same bits) unless there are too many tiles for its LDS arrays
   const bool from_costs = !p->tile_packets_fresh && 2 * sizeof(float) * (size_t)p->inst_tiles <= 60 * 1024;
   if (!p->tile_packets_fresh && !from_costs)
-    hipLaunchKernelGGL(k_tile_weights, dim3(p->n_tiles), dim3(64), 0, p->stream, p->costs, N, a.lambda_weight,
+    MPPI_KLAUNCH(k_tile_weights, dim3(p->n_tiles), dim3(64), 0, p->stream, p->costs, N, a.lambda_weight,
                        p->w_rel, p->tile_beta);
   p->tile_packets_fresh = false;
   const size_t lds = sizeof(float) * (size_t)p->inst_tiles * (from_costs ? 2 : 1);
@@ -1817,7 +1832,7 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
   const bool many_rows = (long)T * p->B >= 2048;
   const dim3 grid(many_rows ? ceil_div(T, 4) : T, p->B);
 #define MPPI_LAUNCH_ROWS(APPLY, TC, FC)                                                                         \
-  hipLaunchKernelGGL((k_update_rows<APPLY, TC, FC>), grid, dim3(kRowThreads), lds, p->stream,                   \
+  MPPI_KLAUNCH((k_update_rows<APPLY, TC, FC>), grid, dim3(kRowThreads), lds, p->stream,                   \
                      FC ? p->costs : p->w_rel, p->tile_beta, p->n_inst, p->inst_tiles, p->noise, T,             \
                      a.lambda_weight, my_packet, p->u, p->u_prev, p->u_host_dev, a.vrange[0], a.vrange[1],      \
                      a.wrange[0], a.wrange[1], p->stats, p->graph_on ? p->gen_dev : (unsigned long long*)nullptr)
@@ -1902,7 +1917,13 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
   if (want_next && side_stream_pays) HIP_TRY(hipEventRecord(p->ev_buf_free, p->stream));
   {
     TraceRange tr("mppi:rollout");
-    TRY(launch_rollout(p, d));
+    if (p->ktime_index >= 0) {
+      p->kev_start = p->ktime_events[4 * (size_t)p->ktime_index];
+      p->kev_stop = p->ktime_events[4 * (size_t)p->ktime_index + 1];
+    }
+    const int rc = launch_rollout(p, d);
+    p->kev_start = p->kev_stop = nullptr;
+    TRY(rc);
   }
   if (p->m_count > 1) {
     TraceRange tr("mppi:exchange_sample_costs");
@@ -1925,7 +1946,16 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
   p->next_noise_wanted = false;
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[2], p->stream));
   TraceRange tr_update("mppi:update");
-  TRY(launch_update(p, prof, defer_exchange));
+  if (p->ktime_index >= 0) {
+    p->kev_start = p->ktime_events[4 * (size_t)p->ktime_index + 2];
+    p->kev_stop = p->ktime_events[4 * (size_t)p->ktime_index + 3];
+    ++p->ktime_index;
+  }
+  {
+    const int rc = launch_update(p, prof, defer_exchange);
+    p->kev_start = p->kev_stop = nullptr;
+    TRY(rc);
+  }
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[5], p->stream));
   return MPPI_OK;
 }
@@ -2580,6 +2610,43 @@ extern "C" int mppi_planner_stage_times(mppi_planner* p, float ms[4]) {
   REQUIRE(p && ms, MPPI_ERR_INVALID, "NULL argument");
   TRY(finish_timing(p));
   memcpy(ms, p->stage_ms, sizeof(p->stage_ms));
+  return MPPI_OK;
+}
+
+// Average duration of the rollout launch and of the update launch over `reps` ordinary iterations
+// of the loop: every launch carries its own start / stop events (hipExtLaunchKernelGGL), which the
+// runtime fills with the dispatch's begin / end timestamps -- the figures rocprofv3 --kernel-trace
+// reports -- so nothing is inserted between the kernels and nothing is synchronised until the end.
+// (A mode whose rollout or update is more than one launch reports the LAST launch of each.)
+extern "C" int mppi_planner_time_kernels(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int reps, float* us_rollout,
+                                         float* us_update) {
+  REQUIRE(p && us_rollout && us_update, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(reps >= 1 && reps <= 4096, MPPI_ERR_INVALID, "reps %d", reps);
+  REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
+  REQUIRE(!p->graph_on, MPPI_ERR_STATE, "switch graph replay off for kernel timing");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  TRY(check_tdms(p, lin, ang));
+  while (p->ktime_events.size() < 4 * (size_t)reps) {
+    hipEvent_t e = nullptr;
+    HIP_TRY(hipEventCreate(&e));
+    p->ktime_events.push_back(e);
+  }
+  TRY(run_iterations(p, lin, ang, 2, /*timed=*/false));  // steady state first
+  p->ktime_index = 0;
+  const int rc = run_iterations(p, lin, ang, reps, /*timed=*/false);
+  p->ktime_index = -1;
+  p->kev_start = p->kev_stop = nullptr;
+  TRY(rc);
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  double sum[2] = {0.0, 0.0};
+  for (int r = 0; r < reps; ++r)
+    for (int k = 0; k < 2; ++k) {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, p->ktime_events[4 * (size_t)r + 2 * k], p->ktime_events[4 * (size_t)r + 2 * k + 1]));
+      sum[k] += (double)ms;
+    }
+  *us_rollout = (float)(1e3 * sum[0] / reps);
+  *us_update = (float)(1e3 * sum[1] / reps);
   return MPPI_OK;
 }
 

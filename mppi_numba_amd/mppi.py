@@ -416,6 +416,14 @@ class MPPI_Numba(object):
         _lib.call("mppi_planner_get_sample_costs", self._handle, _lib.ptr(out, C.c_float))
         return out
 
+    def time_kernels(self, reps=200):
+        """(us per rollout launch, us per update launch) over `reps` ordinary iterations: the
+        dispatch's own begin / end timestamps of every launch (include/mppi_hip.h)."""
+        a, b = C.c_float(0), C.c_float(0)
+        _lib.call("mppi_planner_time_kernels", self._handle, self.lin_tdm._handle, self.ang_tdm._handle,
+                  int(reps), C.byref(a), C.byref(b))
+        return float(a.value), float(b.value)
+
     def iterate_async(self, iterations):
         """Enqueue `iterations` x {noise, rollout, update} without sampling the TDMs
         and without copying u back; pair with synchronize()."""
