@@ -1399,7 +1399,19 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         pow2res = std::frexp((double)a.res, &res_exp) == 0.5;  // res == 2^k exactly
       }
       static const bool no_deep = getenv("MPPI_NO_DEEP") != nullptr;  // developer switch (ablation)
-      if (have_window && rot_ok && !no_pipe && !no_deep &&
+      // MPPI_MATH_FAST: the same five-stage pipeline in float32 (hardware sin / cos: |theta| must stay
+      // inside v_sin_f32's +-256 revolutions)
+      bool fast_deep_ok = false;
+      if (!EXACT) {
+        const mppi_params& a = p->params;
+        double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
+        double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
+        double th0_max = std::fabs((double)a.x0[2]);
+        if (p->inst_set) for (const BatchInst& I : p->inst_host) th0_max = std::fmax(th0_max, std::fabs((double)I.th0));
+        const double bound = th0_max + (double)T * (double)a.dt * wmax * trmax;
+        fast_deep_ok = std::isfinite(bound) && bound < 1500.0 && T <= 2000;
+      }
+      if (have_window && (EXACT ? rot_ok : fast_deep_ok) && !no_pipe && !no_deep &&
           !(p->debug_flags & (MPPI_DEBUG_NO_SPEC_KERNEL | MPPI_DEBUG_NO_DEEP_KERNEL)) &&
           ceil_div(N, 64) <= p->num_cus) {
         // five-stage speculative pipeline, one tile per CU (rollout_deep_kernel.h)
@@ -1442,7 +1454,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
           const int speculate = (p->debug_flags & MPPI_DEBUG_NO_SPECULATION) ? 0 : 1;
 #define MPPI_LAUNCH_DEEP(CH, P2, CL)                                                                   \
   do {                                                                                                \
-    auto kern = k_rollout_deep<CH, P2, CL>;                                                           \
+    auto kern = k_rollout_deep<CH, P2, CL, !EXACT>;                                                   \
     if (lds_total > 64 * 1024)                                                                        \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));       \
@@ -1464,9 +1476,9 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
 #undef MPPI_LAUNCH_DEEP
           char buf[320];
           snprintf(buf, sizeof(buf),
-                   "k_rollout_deep chunk=%d pow2res=%d cc_lds=%d speculate=%d window=%dx%d@(%d,%d) lds=%zu "
+                   "k_rollout_deep%s chunk=%d pow2res=%d cc_lds=%d speculate=%d window=%dx%d@(%d,%d) lds=%zu "
                    "noise_blocks=%d problems=%d",
-                   chunk, (int)pow2res, (int)cc_lds, speculate, d.win_rows, d.win_cols, d.win_r0, d.win_c0, lds_total,
+                   EXACT ? "" : "<f32>", chunk, (int)pow2res, (int)cc_lds, speculate, d.win_rows, d.win_cols, d.win_r0, d.win_c0, lds_total,
                    extra, p->inst_set ? p->B : 0);
           p->last_rollout = buf;
           p->tile_packets_fresh = true;

@@ -43,6 +43,7 @@
 // LDS: [Tp] double2 ratios | [Tp] float2 u | map window | rings (DeepRing) | 2 fail flags |
 //      (CC_LDS) [Tp][64] double control-cost products          (Tp = T rounded up to 8)
 #pragma once
+#include <type_traits>
 #include "rollout_spec_kernel.h"
 
 namespace mppi {
@@ -62,7 +63,13 @@ struct DeepRing {
 
 enum DeepRole { kP = 0, kH, kS, kC, kV, kDeepWaves };  // (wave 4 shares its SIMD with wave 0: the lightest role)
 
-template <int CH, bool POW2RES, bool CC_LDS>
+// F32 (MPPI_MATH_FAST): the same pipeline in float32 -- no float64 intermediates, hardware sin / cos
+// of the heading instead of the exact-increment rotation, hardware sqrt.  Costs then follow the
+// reference to ~1e-6 relative instead of bit for bit (a rollout that grazes a cell border may
+// land on the other side); it exists to MEASURE what the reference's rounding points cost in
+// this design and as an opt-in for users who want the latency.  A failed
+// vote still re-executes the tile on the exact float64 schedule.
+template <int CH, bool POW2RES, bool CC_LDS, bool F32 = false>
 __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
     DevParams P, const uint16_t* __restrict__ cells16, const float2* __restrict__ noise,
     const float2* __restrict__ u, float* __restrict__ costs, float* __restrict__ w_rel,
@@ -192,19 +199,24 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
         if (t < Tp) {
           const float2 ut = t < T ? u_first[r] : make_float2(0.0f, 0.0f);
           us[t] = ut;
-          uos[t] = make_double2((double)ut.x / Q.s0sq, (double)ut.y / Q.s1sq);
+          if (F32) reinterpret_cast<float2*>(uos)[t] = make_float2(ut.x / (float)Q.s0sq, ut.y / (float)Q.s1sq);
+          else uos[t] = make_double2((double)ut.x / Q.s0sq, (double)ut.y / Q.s1sq);
         }
       }
       for (int t = lane + 128; t < Tp; t += 64) {
         const float2 ut = t < T ? uq[t] : make_float2(0.0f, 0.0f);
         us[t] = ut;
-        uos[t] = make_double2((double)ut.x / Q.s0sq, (double)ut.y / Q.s1sq);
+        if (F32) reinterpret_cast<float2*>(uos)[t] = make_float2(ut.x / (float)Q.s0sq, ut.y / (float)Q.s1sq);
+        else uos[t] = make_double2((double)ut.x / Q.s0sq, (double)ut.y / Q.s1sq);
       }
       if (lane < 2) fail[lane] = 0;  // (visible to the others after the first barrier; nobody reads before)
     }
     MPPI_STAMP(stamp_wg, stamp_base + 0);
     const double vtr0 = fma(Q.lin_ratio, (double)(int)(ref & 127u), Q.lin_lo);
     const double wtr0 = fma(Q.ang_ratio, (double)(int)((ref >> 7) & 127u), Q.ang_lo);
+    [[maybe_unused]] const float vtr0f = (float)vtr0, wtr0f = (float)wtr0;
+    using real = std::conditional_t<F32, float, double>;
+    using real2 = std::conditional_t<F32, float2, double2>;
     MPPI_STAMP(stamp_wg, stamp_base + 1);
     // stored by waves 2..4 at the end of interval 1 (called from their loops below)
     auto store_window = [&]() {
@@ -241,31 +253,36 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
       //  earlier, three younger groups of CH loads may stay in flight -- is written out by hand with
       //  the registers as operands: hipcc's own vmcnt bookkeeping across the inline-asm barriers of
       //  the unrolled loop waits either for the newest loads or not at all.)
-      double* my_cc = CC_LDS ? cc_lds + lane : cc_scratch + tile_base;
+      real* my_cc = CC_LDS ? reinterpret_cast<real*>(cc_lds) + lane : reinterpret_cast<real*>(cc_scratch) + tile_base;
       auto step = [&](auto ph, int k) -> int {
         constexpr int PH = decltype(ph)::value;  // == k & 3
+        MPPI_STAMP(stamp_wg && k == 5, 1100);
         const int flag = read_flag(k);
         const int kk = min(k, K - 1);
         const float2* us_c = us + kk * CH;
-        const double2* uos_c = uos + kk * CH;
+        const real2* uos_c = reinterpret_cast<const real2*>(uos) + kk * CH;
         float2 vw[CH];
-        double cc[CH];
+        real cc[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j)
           asm volatile("s_waitcnt vmcnt(%2)" : "+v"(e[PH][j].x), "+v"(e[PH][j].y) : "n"(3 * CH));
+        MPPI_STAMP(stamp_wg && k == 5, 1101);
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
           const float2 ut = us_c[j];  // steps past the horizon: zero controls, produced and ignored
           vw[j] = make_float2(clip_f32(ut.x + e[PH][j].x, Q.v_lo, Q.v_hi), clip_f32(ut.y + e[PH][j].y, Q.w_lo, Q.w_hi));
-          cc[j] = control_cost(Q, uos_c[j], e[PH][j]);
+          if constexpr (F32) cc[j] = Q.lambda * fmaf(uos_c[j].x, e[PH][j].x, uos_c[j].y * e[PH][j].y);
+          else cc[j] = control_cost(Q, uos_c[j], e[PH][j]);
         }
         // the last use of this register set comes before its reload (results as operands of the
         // fence): the set then keeps its physical registers around the loop, and hipcc has no
         // copies of in-flight registers -- each behind an s_waitcnt vmcnt(0) -- to make at the latch
 #pragma unroll
         for (int j = 0; j < CH; ++j) asm volatile("" : : "v"(vw[j].x), "v"(vw[j].y), "v"(cc[j]) : "memory");
+        MPPI_STAMP(stamp_wg && k == 5, 1102);
         load_noise(e[PH], k + 4);
         pin_memory_order();
+        MPPI_STAMP(stamp_wg && k == 5, 1103);
         if (k < K) {
           float2* out = ring_vw + (k & 1) * E;
 #pragma unroll
@@ -274,6 +291,7 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
             if (tile_ok && k * CH + j < T) my_cc[(size_t)(k * CH + j) * 64] = cc[j];
           }
         }
+        MPPI_STAMP(stamp_wg && k == 5, 1104);
         return interval_end(k, flag);
       };
       // (two rounds of the four register sets per loop iteration: at the loop header hipcc still
@@ -315,6 +333,22 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
 #pragma unroll
           for (int j = 0; j < CH; ++j) vw[j] = in[j * 64 + lane];
           pin_memory_order();
+          if constexpr (F32) {
+            // heading in float32, hardware sin / cos of every heading (no rotation chain to drift)
+            float2 ppf[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+              const float qx = Q.dt * vw[j].x, qy = Q.dt * vw[j].y;
+              ppf[j] = make_float2(qx * __cosf(th), qx * __sinf(th));
+              th = fmaf(wtr0f, qy, th);
+            }
+            pin_memory_order();
+            float2* outf = reinterpret_cast<float2*>(ring_pp) + (c & 1) * E;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) outf[j * 64 + lane] = ppf[j];
+            if ((outcome = interval_end(k, flag))) break;
+            continue;
+          }
 #pragma unroll
           for (int j = 0; j < CH; ++j)  // dt*v, dt*w: exact products of float32 factors
             qd[j] = make_double2(dt64 * (double)vw[j].x, dt64 * (double)vw[j].y);
@@ -348,8 +382,8 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
       for (int k = 0;; ++k) {
         const int flag = read_flag(k), c = k - 2;
         if (c >= 0 && c < K) {
-          const double2* in = ring_pp + (c & 1) * E;
-          double2 pp[CH];
+          const real2* in = reinterpret_cast<const real2*>(ring_pp) + (c & 1) * E;
+          real2 pp[CH];
           float xa[CH + 1], ya[CH + 1];
           uint32_t cl[CH];
 #pragma unroll
@@ -358,11 +392,16 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
           xa[0] = x;
           ya[0] = y;
 #pragma unroll
-          for (int j = 0; j < CH; ++j) {  // (a 3-instruction chain per axis)
-            x = (float)fma(vtr0, pp[j].x, x64);
-            y = (float)fma(vtr0, pp[j].y, y64);
-            x64 = (double)x;
-            y64 = (double)y;
+          for (int j = 0; j < CH; ++j) {  // (a 3-instruction chain per axis; one fma in float32)
+            if constexpr (F32) {
+              x = fmaf(vtr0f, pp[j].x, x);
+              y = fmaf(vtr0f, pp[j].y, y);
+            } else {
+              x = (float)fma(vtr0, pp[j].x, x64);
+              y = (float)fma(vtr0, pp[j].y, y64);
+              x64 = (double)x;
+              y64 = (double)y;
+            }
             xa[j + 1] = x;
             ya[j + 1] = y;
           }
@@ -393,7 +432,7 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
           const uint32_t* in_cl = ring_cl + (c & 1) * E;
           float2 xy[CH];
           uint32_t cl[CH];
-          double n2[CH];
+          real n2[CH];
 #pragma unroll
           for (int j = 0; j < CH; ++j) {
             xy[j] = in_xy[j * 64 + lane];
@@ -411,11 +450,16 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
             ecell = cell;
             ex = stuck ? ex : xy[j].x;
             ey = stuck ? ey : xy[j].y;
-            const double dx = (double)(Q.xg - ex), dy = (double)(Q.yg - ey);
-            n2[j] = fma(dx, dx, dy * dy);
+            if constexpr (F32) {
+              const float dx = Q.xg - ex, dy = Q.yg - ey;
+              n2[j] = fmaf(dx, dx, dy * dy);
+            } else {
+              const double dx = (double)(Q.xg - ex), dy = (double)(Q.yg - ey);
+              n2[j] = fma(dx, dx, dy * dy);
+            }
           }
           pin_memory_order();
-          double* out = ring_n2 + (c & 1) * E;
+          real* out = reinterpret_cast<real*>(ring_n2) + (c & 1) * E;
 #pragma unroll
           for (int j = 0; j < CH; ++j) out[j * 64 + lane] = n2[j];
           ring_fl[(c & 1) * 64 + lane] = fl;
@@ -426,26 +470,32 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
       }
     } else {
       // -------------------------------------------------------------- stage 4: stage costs, accumulation
-      const double gt2 = (double)Q.gt2, dt64 = (double)Q.dt;
+      const real gt2 = (real)Q.gt2, dt64 = (real)Q.dt;
+      [[maybe_unused]] const float dist_weight_f = (float)Q.dist_weight;
       float cost = 0.0f;
-      double d2 = 1e9;
+      real d2 = (real)1e9;
       bool done = false, reached = false;
       for (int k = 0;; ++k) {
         const int flag = read_flag(k), c = k - 4;
         if (c >= 0 && c < K) {
-          const double* in = ring_n2 + (c & 1) * E;
-          double n2[CH], sg[CH];
+          const real* in = reinterpret_cast<const real*>(ring_n2) + (c & 1) * E;
+          real n2[CH], sg[CH];
 #pragma unroll
           for (int j = 0; j < CH; ++j) n2[j] = in[j * 64 + lane];
           const uint32_t fl = ring_fl[(c & 1) * 64 + lane];
           pin_memory_order();
           // (a) the square roots of all steps side by side, (b) the accumulation chain
 #pragma unroll
-          for (int j = 0; j < CH; ++j) sg[j] = fma(Q.dist_weight, sqrt_newton_nz_f64(n2[j]), dt64);
+          for (int j = 0; j < CH; ++j) {
+            if constexpr (F32) sg[j] = fmaf(dist_weight_f, __builtin_amdgcn_sqrtf(n2[j]), dt64);  // v_sqrt_f32, 1 ulp
+            else sg[j] = fma(Q.dist_weight, sqrt_newton_nz_f64(n2[j]), dt64);
+          }
           const int count = min(CH, T - c * CH);
 #pragma unroll
           for (int j = 0; j < CH; ++j) {
-            float c1 = (float)((double)cost + sg[j]);
+            float c1;
+            if constexpr (F32) c1 = cost + sg[j];
+            else c1 = (float)((double)cost + sg[j]);
             // bits of the cell the step STARTED in (mppi.py:971-998): penalty or +0.0, selected by the
             // sign-extended flag bit (v_bfe_i32 + v_and_b32)
             c1 = c1 + __int_as_float(__float_as_int(Q.obs_cost) & __builtin_amdgcn_sbfe((int)fl, 2 * j, 1));
@@ -463,6 +513,20 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
       if (outcome == 2) {
         MPPI_STAMP(stamp_wg, stamp_base + 30);
         // terminal cost, then the control cost of all T steps (mppi.py:1005-1009)
+        if constexpr (F32) {
+          cost = cost + (reached ? 0.0f : 1.0f) * __builtin_amdgcn_sqrtf(d2) / (float)Q.v_post_den;
+          const float* my_ccf = CC_LDS ? reinterpret_cast<const float*>(cc_lds) + lane
+                                       : reinterpret_cast<const float*>(cc_scratch) + (live ? tile_base : (size_t)lane);
+          if (!CC_LDS) __threadfence_block();
+          for (int t0 = 0; t0 < T; t0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = my_ccf[(size_t)min(t0 + j, T - 1) * 64];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (t0 + j < T) cost = cost + v[j];
+          }
+        } else {
         const double term = (reached ? 0.0 : 1.0) * sqrt(d2) / Q.v_post_den;
         cost = (float)((double)cost + term);
         if (CC_LDS) {
@@ -499,6 +563,7 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
               if (t0 + j < T) cost = (float)((double)cost + v[j]);
           }
         }
+        }  // (exact float64 tail)
         MPPI_STAMP(stamp_wg, stamp_base + 31);
         if (live) costs[n] = cost;
         // first half of the control update (update_kernels.h): weights relative to the tile's minimum

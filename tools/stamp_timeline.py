@@ -30,7 +30,7 @@ def main():
     from mppi_numba_amd import _lib
     with contextlib.redirect_stdout(io.StringIO()):
         from test_gpu_scale import build
-        w, cfg, lin, ang, planner, params = build(args.workload, args.n)
+        w, cfg, lin, ang, planner, params = build(args.workload, args.n, math=os.environ.get("MPPI_MATH", "exact"))
         planner.solve()
         planner.iterate_async(20)
         planner.synchronize()
@@ -68,6 +68,10 @@ def main():
         u = st[512:520]
         out["update"] = [int(v - u[0]) if v else None for v in u]
         print("update kernel (middle WG) phases, cycles from its entry:", out["update"])
+        sub = st[1100:1108]
+        if sub[0]:
+            print("P inside interval 5 (top, noise waited for, computed, next loads issued, LDS stores issued), "
+                  "cycles from the top:", [int(v - sub[0]) if v else None for v in sub[:5]])
         if args.json:
             with open(args.json, "w") as fh:
                 json.dump(out, fh)
