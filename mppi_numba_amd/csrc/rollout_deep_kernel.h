@@ -16,8 +16,10 @@
 // constant; over maps of nominal dynamics (the reference's own use_det_dynamics recipe,
 // README.md:136-151) or large terrain patches the assumption holds for the whole horizon -- and
 // the chain falls apart into stages that no longer wait for each other:
-//   stage 0  P  noise -> clipped controls {dt*v, dt*w} (float64), control-cost products
-//   stage 1  H  heading theta' = float32(theta + wtr0*dt*w), (cos, sin) by the exact-increment
+//   stage 0  P  streams the noise four chunks ahead, hands it on, control-cost products
+//   stage 1  H  clipped controls v, w = clip(u + noise) (moved here from P: that wave shares its
+//               SIMD with V and was the longest pole, 2170 -> 1940 cycles per interval);
+//               heading theta' = float32(theta + wtr0*dt*w), (cos, sin) by the exact-increment
 //               rotation, the products dt*v*cos, dt*v*sin            (no lookup needed)
 //   stage 2  V  position x' = float32(x + vtr0*dt*v*cos) (3 instructions per axis), and -- off that
 //               chain -- the LDS map lookup of every position
@@ -51,7 +53,7 @@ namespace mppi {
 template <int CH>
 struct DeepRing {
   static constexpr int kE = CH * 64;             // entries per chunk
-  static constexpr int oVw = 0;                  // vw[2][kE] float2  clipped controls {v, w}  P -> H
+  static constexpr int oVw = 0;                  // vw[2][kE] float2  control noise (H adds u and clips)  P -> H
   static constexpr int oPp = oVw + 2 * kE * 8;   // pp[2][kE] double2 dt*v*{cos, sin}         H -> V
   static constexpr int oXy = oPp + 2 * kE * 16;  // xy[2][kE] float2  position after step     V -> S
   static constexpr int oCl = oXy + 2 * kE * 8;   // cl[2][kE] uint32  16-bit map cell         V -> S
@@ -261,16 +263,17 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
         const int kk = min(k, K - 1);
         const float2* us_c = us + kk * CH;
         const real2* uos_c = reinterpret_cast<const real2*>(uos) + kk * CH;
-        float2 vw[CH];
+        float2 vw[CH];  // (the raw noise: the heading wave adds and clips the controls itself -- it has
+                        //  issue slots to spare, this wave shares its SIMD with the position wave)
         real cc[CH];
+        (void)us_c;
 #pragma unroll
         for (int j = 0; j < CH; ++j)
           asm volatile("s_waitcnt vmcnt(%2)" : "+v"(e[PH][j].x), "+v"(e[PH][j].y) : "n"(3 * CH));
         MPPI_STAMP(stamp_wg && k == 5, 1101);
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-          const float2 ut = us_c[j];  // steps past the horizon: zero controls, produced and ignored
-          vw[j] = make_float2(clip_f32(ut.x + e[PH][j].x, Q.v_lo, Q.v_hi), clip_f32(ut.y + e[PH][j].y, Q.w_lo, Q.w_hi));
+          vw[j] = e[PH][j];
           if constexpr (F32) cc[j] = Q.lambda * fmaf(uos_c[j].x, e[PH][j].x, uos_c[j].y * e[PH][j].y);
           else cc[j] = control_cost(Q, uos_c[j], e[PH][j]);
         }
@@ -330,8 +333,12 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
           float2 vw[CH];
           double2 qd[CH], pp[CH];
           double sd[CH], cd[CH];
+          const float2* us_c = us + c * CH;  // (staged by the producer before the first barrier; padded to Tp)
 #pragma unroll
-          for (int j = 0; j < CH; ++j) vw[j] = in[j * 64 + lane];
+          for (int j = 0; j < CH; ++j) {
+            const float2 e = in[j * 64 + lane], ut = us_c[j];
+            vw[j] = make_float2(clip_f32(ut.x + e.x, Q.v_lo, Q.v_hi), clip_f32(ut.y + e.y, Q.w_lo, Q.w_hi));
+          }
           pin_memory_order();
           if constexpr (F32) {
             // heading in float32, hardware sin / cos of every heading (no rotation chain to drift)
