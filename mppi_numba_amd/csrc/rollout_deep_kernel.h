@@ -16,7 +16,8 @@
 // constant; over maps of nominal dynamics (the reference's own use_det_dynamics recipe,
 // README.md:136-151) or large terrain patches the assumption holds for the whole horizon -- and
 // the chain falls apart into stages that no longer wait for each other:
-//   stage 0  P  streams the noise four chunks ahead, hands it on, control-cost products
+//   stage 0  P  streams the noise three chunks ahead and hands each chunk on the moment it is there;
+//               the control-cost products (needed only by the tail) follow one interval later
 //   stage 1  H  clipped controls v, w = clip(u + noise) (moved here from P: that wave shares its
 //               SIMD with V and was the longest pole, 2170 -> 1940 cycles per interval);
 //               heading theta' = float32(theta + wtr0*dt*w), (cos, sin) by the exact-increment
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
       load_noise(e[0], 0);
       load_noise(e[1], 1);
       load_noise(e[2], 2);
-      load_noise(e[3], 3);
+      load_noise(e[3], 2);  // (a defined value for the set the first interval "finishes": its products are not stored)
     }
     const float win_c0f = (float)Q.win_c0, win_r0f = (float)Q.win_r0;
     const float win_last_col = (float)(Q.win_cols - 1), win_last_row = (float)(Q.win_rows - 1);
@@ -251,48 +252,53 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
     if (wave == kP) {
       // -------------------------------------------------------------- stage 0: controls and control costs
       // (loop unrolled by 4: static register sets.  The noise loads are issued in EVERY interval,
-      //  also past the horizon, and the wait for the set consumed now -- requested four intervals
-      //  earlier, three younger groups of CH loads may stay in flight -- is written out by hand with
+      //  also past the horizon, and the wait for the set consumed now -- requested three intervals
+      //  earlier, two younger groups of CH loads may stay in flight -- is written out by hand with
       //  the registers as operands: hipcc's own vmcnt bookkeeping across the inline-asm barriers of
       //  the unrolled loop waits either for the newest loads or not at all.)
       real* my_cc = CC_LDS ? reinterpret_cast<real*>(cc_lds) + lane : reinterpret_cast<real*>(cc_scratch) + tile_base;
       auto step = [&](auto ph, int k) -> int {
-        constexpr int PH = decltype(ph)::value;  // == k & 3
+        constexpr int PH = decltype(ph)::value;  // == k & 3: the register set holding chunk k
+        constexpr int PM = (PH + 3) & 3;         // the set holding chunk k - 1
         MPPI_STAMP(stamp_wg && k == 5, 1100);
         const int flag = read_flag(k);
-        const int kk = min(k, K - 1);
-        const float2* us_c = us + kk * CH;
-        const real2* uos_c = reinterpret_cast<const real2*>(uos) + kk * CH;
-        float2 vw[CH];  // (the raw noise: the heading wave adds and clips the controls itself -- it has
-                        //  issue slots to spare, this wave shares its SIMD with the position wave)
-        real cc[CH];
-        (void)us_c;
+        // (a) chunk k's noise goes to the heading wave (which adds and clips the controls: it has issue
+        //     slots to spare, this wave shares its SIMD with the position wave) as soon as it is there;
+        //     nothing else in this interval is on anybody's critical path -- the first interval is one
+        //     memory round trip plus eight stores instead of also a chunk of control-cost arithmetic
 #pragma unroll
         for (int j = 0; j < CH; ++j)
-          asm volatile("s_waitcnt vmcnt(%2)" : "+v"(e[PH][j].x), "+v"(e[PH][j].y) : "n"(3 * CH));
+          asm volatile("s_waitcnt vmcnt(%2)" : "+v"(e[PH][j].x), "+v"(e[PH][j].y) : "n"(2 * CH));
         MPPI_STAMP(stamp_wg && k == 5, 1101);
+        if (k < K) {
+          float2* out = ring_vw + (k & 1) * E;
+#pragma unroll
+          for (int j = 0; j < CH; ++j) out[j * 64 + lane] = e[PH][j];
+        }
+        MPPI_STAMP(stamp_wg && k == 5, 1102);
+        // (b) the control-cost products of chunk k - 1 (needed only by the cost wave's tail), then that
+        //     register set is reloaded with chunk k + 3
+        const int c1 = min(max(k - 1, 0), K - 1);
+        const real2* uos_c = reinterpret_cast<const real2*>(uos) + c1 * CH;
+        real cc[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-          vw[j] = e[PH][j];
-          if constexpr (F32) cc[j] = Q.lambda * fmaf(uos_c[j].x, e[PH][j].x, uos_c[j].y * e[PH][j].y);
-          else cc[j] = control_cost(Q, uos_c[j], e[PH][j]);
+          if constexpr (F32) cc[j] = Q.lambda * fmaf(uos_c[j].x, e[PM][j].x, uos_c[j].y * e[PM][j].y);
+          else cc[j] = control_cost(Q, uos_c[j], e[PM][j]);
         }
         // the last use of this register set comes before its reload (results as operands of the
         // fence): the set then keeps its physical registers around the loop, and hipcc has no
         // copies of in-flight registers -- each behind an s_waitcnt vmcnt(0) -- to make at the latch
 #pragma unroll
-        for (int j = 0; j < CH; ++j) asm volatile("" : : "v"(vw[j].x), "v"(vw[j].y), "v"(cc[j]) : "memory");
-        MPPI_STAMP(stamp_wg && k == 5, 1102);
-        load_noise(e[PH], k + 4);
+        for (int j = 0; j < CH; ++j) asm volatile("" : : "v"(cc[j]) : "memory");
+        load_noise(e[PM], k + 3);
         pin_memory_order();
         MPPI_STAMP(stamp_wg && k == 5, 1103);
-        if (k < K) {
-          float2* out = ring_vw + (k & 1) * E;
+        if (k >= 1 && k - 1 < K) {
 #pragma unroll
-          for (int j = 0; j < CH; ++j) {
-            out[j * 64 + lane] = vw[j];
-            if (tile_ok && k * CH + j < T) my_cc[(size_t)(k * CH + j) * 64] = cc[j];
-          }
+          for (int j = 0; j < CH; ++j)
+            if (CC_LDS || (tile_ok && (k - 1) * CH + j < T))  // (the LDS array is padded to whole chunks: no predicate)
+              my_cc[(size_t)((k - 1) * CH + j) * 64] = cc[j];
         }
         MPPI_STAMP(stamp_wg && k == 5, 1104);
         return interval_end(k, flag);
