@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
     float* __restrict__ tile_beta, double* __restrict__ cc_scratch, int map_bytes, int n_rollout_blocks,
     int speculate, NoiseJob next_noise) {
   extern __shared__ double2 uos[];
+  MPPI_STAMP(threadIdx.x == 0 && blockIdx.x < 512, 2048 + 2 * blockIdx.x);  // every workgroup: entry ...
   if ((int)blockIdx.x >= n_rollout_blocks) {
     // spare workgroups: the noise of the NEXT iteration, into the other noise buffer
     MPPI_STAMP(threadIdx.x == 0 && ((int)blockIdx.x == n_rollout_blocks || blockIdx.x == gridDim.x - 1),
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
                      (gridDim.x - n_rollout_blocks) * (blockDim.x >> 6));
     MPPI_STAMP(threadIdx.x == 0 && ((int)blockIdx.x == n_rollout_blocks || blockIdx.x == gridDim.x - 1),
                (int)blockIdx.x == n_rollout_blocks ? 17 : 19);
+    MPPI_STAMP(threadIdx.x == 0 && blockIdx.x < 512, 2049 + 2 * blockIdx.x);  // ... and exit
     return;
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -131,7 +133,9 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
     float2 e[4][CH];  // producer only: e[c & 3] = noise of chunk c, requested four intervals ahead
     auto load_noise = [&](float2 (&dst)[CH], int chunk) {
       // (the noise buffers are padded: rows past the horizon are read unclamped and ignored)
-      const float2* at = col + (size_t)min(chunk, K + 4) * CH * 64;
+      // (chunks past the horizon re-read the last one: those loads only have to come back quickly --
+      //  the unrolled loop's header waits for everything in flight)
+      const float2* at = col + (size_t)min(chunk, K - 1) * CH * 64;
 #pragma unroll
       for (int j = 0; j < CH; ++j) dst[j] = at[j * 64];
     };
@@ -303,26 +307,14 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
         MPPI_STAMP(stamp_wg && k == 5, 1104);
         return interval_end(k, flag);
       };
-      // (two rounds of the four register sets per loop iteration: at the loop header hipcc still
-      //  waits for the newest loads before the first use of a set -- ~400 cycles -- so the header
-      //  should come round as rarely as the code size allows)
-      for (int k = 0;; k += 16) {
+      // (six rounds of the four register sets per loop iteration: at the loop header hipcc waits for
+      //  EVERYTHING in flight -- a full memory round trip, 3.7k cycles measured when the 17th
+      //  interval of a 100-step horizon crossed it -- so horizons up to 160 steps never get there)
+      for (int k = 0;; k += 4) {
         if ((outcome = step(PhaseTag<0>(), k))) break;
         if ((outcome = step(PhaseTag<1>(), k + 1))) break;
         if ((outcome = step(PhaseTag<2>(), k + 2))) break;
         if ((outcome = step(PhaseTag<3>(), k + 3))) break;
-        if ((outcome = step(PhaseTag<0>(), k + 4))) break;
-        if ((outcome = step(PhaseTag<1>(), k + 5))) break;
-        if ((outcome = step(PhaseTag<2>(), k + 6))) break;
-        if ((outcome = step(PhaseTag<3>(), k + 7))) break;
-        if ((outcome = step(PhaseTag<0>(), k + 8))) break;
-        if ((outcome = step(PhaseTag<1>(), k + 9))) break;
-        if ((outcome = step(PhaseTag<2>(), k + 10))) break;
-        if ((outcome = step(PhaseTag<3>(), k + 11))) break;
-        if ((outcome = step(PhaseTag<0>(), k + 12))) break;
-        if ((outcome = step(PhaseTag<1>(), k + 13))) break;
-        if ((outcome = step(PhaseTag<2>(), k + 14))) break;
-        if ((outcome = step(PhaseTag<3>(), k + 15))) break;
       }
       // products in global scratch: out before the cost wave's tail reads them
       if (!CC_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -581,6 +573,7 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
         if (live) costs[n] = cost;
         // first half of the control update (update_kernels.h): weights relative to the tile's minimum
         if (tile_ok) emit_tile_weights(cost, live, Q.lambda, n, tile, w_rel, tile_beta);
+        MPPI_STAMP(blockIdx.x < 512, 2049 + 2 * blockIdx.x);
       }
     }
     if (outcome == 2) return;  // the assumption held to the end

@@ -68,6 +68,21 @@ def main():
         u = st[512:520]
         out["update"] = [int(v - u[0]) if v else None for v in u]
         print("update kernel (middle WG) phases, cycles from its entry:", out["update"])
+        life = st[2048:2048 + 1024].reshape(512, 2)
+        ok = (life[:, 0] > 0) & (life[:, 1] > life[:, 0])
+        dur = (life[:, 1] - life[:, 0])[ok]
+        ids = np.flatnonzero(ok)
+        roll = dur[ids < 128] if ok[:128].any() else dur
+        rest = dur[ids >= 128]
+        print("workgroup lifetimes (entry -> exit, cycles): rollout tiles n=%d min %d median %d max %d | "
+              "noise workgroups n=%d min %d median %d max %d"
+              % (len(roll), roll.min(), np.median(roll), roll.max(), len(rest), rest.min() if len(rest) else 0,
+                 np.median(rest) if len(rest) else 0, rest.max() if len(rest) else 0))
+        # entry skew inside one XCD (clocks of different XCDs are not comparable): workgroups 0, 8, 16, ...
+        x0 = life[0:128:8, 0]
+        print("entry times of tiles 0, 8, 16, ... (one XCD), relative to the first:", [int(v - x0.min()) for v in x0])
+        e0 = life[0:128:8, 1]
+        print("exit times of the same, relative to the first entry:", [int(v - x0.min()) for v in e0])
         sub = st[1100:1108]
         if sub[0]:
             print("P inside interval 5 (top, noise waited for, computed, next loads issued, LDS stores issued), "
