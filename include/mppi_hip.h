@@ -286,6 +286,7 @@ int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity)
 #define MPPI_DEBUG_NO_SPECULATION 2  /* the speculative kernels on their exact schedule from the first step */
 #define MPPI_DEBUG_NO_DEEP_KERNEL 4  /* one tile per CU: k_rollout_spec instead of k_rollout_deep */
 #define MPPI_DEBUG_CC_GLOBAL 8       /* control-cost products in the global scratch array even when LDS has room */
+#define MPPI_DEBUG_KEEP_SPECULATING 16 /* keep the speculative kernels on a map where their tiles keep falling back */
 int mppi_planner_set_debug_flags(mppi_planner* p, int flags);
 int mppi_selftest_philox(int device, int* mismatches);
 /* developer instrumentation: in-kernel clock stamps of a -DMPPI_STAMPS build

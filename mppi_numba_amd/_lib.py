@@ -19,6 +19,7 @@ MATH_EXACT, MATH_FAST = 0, 1
 COMM_ID_BYTES = 128
 PREP_TDM, PREP_DET, PREP_SPEED = 0, 1, 2
 DEBUG_NO_SPEC_KERNEL, DEBUG_NO_SPECULATION, DEBUG_NO_DEEP_KERNEL, DEBUG_CC_GLOBAL = 1, 2, 4, 8
+DEBUG_KEEP_SPECULATING = 16
 ABI_VERSION = 1
 
 

@@ -730,6 +730,16 @@ struct mppi_planner {
   float last_elapsed_ms = 0.f;
   bool elapsed_pending = false;
   int last_iterations = 0;
+  // Speculative rollout kernels (k_rollout_deep / k_rollout_spec) on a map where the traction
+  // changes from cell to cell: every tile fails its vote and re-runs on the exact schedule, slower
+  // than launching k_rollout_pipe in the first place (N = 8192, T = 200 over a CVaR-bin map: 85 vs
+  // 49 us).  The kernels count failed tiles in a host-mapped word; whenever the host has
+  // synchronised anyway it compares that with the tiles launched and, past one half, stops
+  // speculating until the packed map changes.
+  unsigned int* spec_fail_host = nullptr;  // pinned, device-mapped
+  unsigned int* spec_fail_dev = nullptr;   // device view of the same word
+  uint64_t spec_tiles_launched = 0;
+  bool speculation_off = false;
   // mppi_planner_time_kernels: dispatch begin / end of the rollout and update launches of the
   // iterations it runs (4 events per iteration), picked up by MPPI_KLAUNCH
   hipEvent_t kev_start = nullptr, kev_stop = nullptr;
@@ -793,6 +803,7 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   dev_free(p->slabs);
   for (hipEvent_t e : p->ktime_events)
     if (e) (void)hipEventDestroy(e);
+  if (p->spec_fail_host) (void)hipHostFree(p->spec_fail_host);
   dev_free(p->loop_state);
   dev_free(p->loop_xhist);
   dev_free(p->loop_uhist);
@@ -816,6 +827,11 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
 }
 
 static int planner_alloc(mppi_planner* p) {
+  if (!p->spec_fail_host) {
+    HIP_TRY(hipHostMalloc((void**)&p->spec_fail_host, sizeof(unsigned int), hipHostMallocMapped));
+    *p->spec_fail_host = 0u;
+    HIP_TRY(hipHostGetDevicePointer((void**)&p->spec_fail_dev, p->spec_fail_host, 0));
+  }
   const mppi_planner_cfg& c = p->cfg;
   const size_t N = (size_t)p->n_local, T = (size_t)c.num_steps;
   HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
@@ -1107,6 +1123,7 @@ static DevParams make_dev_params(const mppi_planner* p, const mppi_tdm* lin, con
   d.inst = p->inst_set ? p->inst_dev : nullptr;
   d.inst_tiles = p->inst_tiles;
   d.n_inst = p->n_inst;
+  d.spec_failures = p->spec_fail_dev;
   return d;
 }
 
@@ -1169,6 +1186,7 @@ static bool sample_into_cells(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, dou
   p->packed_ang = ang;
   p->packed_lin_grid = lin->grid_version;
   p->packed_ang_grid = ang->grid_version;
+  if (p->packed_lin_maps != lin->maps_version) p->speculation_off = false;  // a new map: speculate again
   p->packed_lin_maps = lin->maps_version;
   return true;
 }
@@ -1230,6 +1248,7 @@ static int ensure_packed(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang) {
   p->packed_ang = ang;
   p->packed_lin_grid = lin->grid_version;
   p->packed_ang_grid = ang->grid_version;
+  if (p->packed_lin_maps != lin->maps_version) p->speculation_off = false;  // a new map: speculate again
   p->packed_lin_maps = lin->maps_version;
   return MPPI_OK;
 }
@@ -1411,7 +1430,8 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         const double bound = th0_max + (double)T * (double)a.dt * wmax * trmax;
         fast_deep_ok = std::isfinite(bound) && bound < 1500.0 && T <= 2000;
       }
-      if (have_window && (EXACT ? rot_ok : fast_deep_ok) && !no_pipe && !no_deep &&
+      const bool keep_speculating = !p->speculation_off || (p->debug_flags & MPPI_DEBUG_KEEP_SPECULATING);
+      if (have_window && (EXACT ? rot_ok : fast_deep_ok) && !no_pipe && !no_deep && keep_speculating &&
           !(p->debug_flags & (MPPI_DEBUG_NO_SPEC_KERNEL | MPPI_DEBUG_NO_DEEP_KERNEL)) &&
           ceil_div(N, 64) <= p->num_cus) {
         // five-stage speculative pipeline, one tile per CU (rollout_deep_kernel.h)
@@ -1452,6 +1472,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
           }
           if (!cc_lds && !p->cc_scratch) TRY(dev_alloc(&p->cc_scratch, (size_t)ceil_div(N, 64) * 64 * T));
           const int speculate = (p->debug_flags & MPPI_DEBUG_NO_SPECULATION) ? 0 : 1;
+          if (speculate) p->spec_tiles_launched += (uint64_t)ceil_div(N, 64);
 #define MPPI_LAUNCH_DEEP(CH, P2, CL)                                                                   \
   do {                                                                                                \
     auto kern = k_rollout_deep<CH, P2, CL, !EXACT>;                                                   \
@@ -1486,7 +1507,8 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
         }
       }
       static const bool no_spec = getenv("MPPI_NO_SPEC") != nullptr;  // developer switch (ablation)
-      if (have_window && rot_ok && !no_pipe && !no_spec && !(p->debug_flags & MPPI_DEBUG_NO_SPEC_KERNEL)) {
+      if (have_window && rot_ok && !no_pipe && !no_spec && keep_speculating &&
+          !(p->debug_flags & MPPI_DEBUG_NO_SPEC_KERNEL)) {
         // speculative 4-wave pipeline (rollout_spec_kernel.h): same regime as the pipelined kernel below
         const size_t map_bytes = lds_win - sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);
         // (this kernel pads the staged controls to a multiple of 8 steps)
@@ -1529,6 +1551,7 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
           }
           if (!cc_lds && !p->cc_scratch) TRY(dev_alloc(&p->cc_scratch, (size_t)ceil_div(N, 64) * 64 * T));
           const int speculate = (p->debug_flags & MPPI_DEBUG_NO_SPECULATION) ? 0 : 1;
+          if (speculate) p->spec_tiles_launched += (uint64_t)ceil_div(N, 64);
 #define MPPI_LAUNCH_SPEC(CH, P2, CL)                                                                   \
   do {                                                                                                \
     auto kern = tiles_wg == 1 ? k_rollout_spec<CH, P2, CL, 1> : k_rollout_spec<CH, P2, CL, 2>;        \
@@ -2001,6 +2024,15 @@ static void graph_signature(const mppi_planner* p, const DevParams& d, const mpp
 
 // `timed`: bracket the iterations with events for mppi_planner_last_elapsed_ms / stage_times
 // (iterate_async, profiling); solve() on the control path skips them
+// called where the host has just waited for the stream: did speculation pay on this map?
+static void review_speculation(mppi_planner* p) {
+  if (p->spec_tiles_launched == 0 || !p->spec_fail_host) return;
+  const uint64_t failed = *p->spec_fail_host;
+  if (2 * failed >= p->spec_tiles_launched) p->speculation_off = true;
+  *p->spec_fail_host = 0u;
+  p->spec_tiles_launched = 0;
+}
+
 static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int iterations, bool timed = true) {
   REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
   TRY(check_tdms(p, lin, ang));
@@ -2118,6 +2150,7 @@ extern "C" int mppi_planner_synchronize(mppi_planner* p) {
   REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
   HIP_TRY(hipSetDevice(p->cfg.device));
   HIP_TRY(hipStreamSynchronize(p->stream));
+  review_speculation(p);
   return finish_timing(p);
 }
 
@@ -2146,6 +2179,7 @@ extern "C" int mppi_planner_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang,
   // with at least one iteration the last update kernel has written the host-mapped mirror
   if (p->params.num_opt < 1) HIP_TRY(hipMemcpyAsync(p->u_host, p->u, u_bytes, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
+  review_speculation(p);
   memcpy(u_out, p->u_host, u_bytes);
   return finish_timing(p);
 }

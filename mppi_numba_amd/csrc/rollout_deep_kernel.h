@@ -468,7 +468,10 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
 #pragma unroll
           for (int j = 0; j < CH; ++j) out[j * 64 + lane] = n2[j];
           ring_fl[(c & 1) * 64 + lane] = fl;
-          if (__any(bad != 0) && lane == 0) fail[k & 1] = 1;  // read by everybody in interval k+1
+          if (__any(bad != 0) && lane == 0) {
+            fail[k & 1] = 1;  // read by everybody in interval k+1
+            if (Q.spec_failures) atomicAdd_system(Q.spec_failures, 1u);  // (once per tile: it leaves the pipeline)
+          }
         }
         if (k == 1) store_window();
         if ((outcome = interval_end(k, flag))) break;

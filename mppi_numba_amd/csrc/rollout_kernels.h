@@ -70,6 +70,10 @@ struct DevParams {
   const struct BatchInst* inst;
   int inst_tiles;  // tiles of 64 rollouts per problem
   int n_inst;      // rollouts per problem on this GPU
+  // speculative kernels: tiles whose assumption about the traction failed (host-mapped counter the
+  // host looks at when it synchronises anyway: a map on which speculation does not pay gets the
+  // exact pipelined kernel from then on), or nullptr
+  unsigned int* spec_failures;
 };
 
 // What differs between the problems of a batched handle (mppi_planner_set_instances).

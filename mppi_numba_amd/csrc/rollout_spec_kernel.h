@@ -494,7 +494,10 @@ __global__ __launch_bounds__(256 * W) void k_rollout_spec(DevParams P, const uin
         ring_fl[(next & 1) * 64 + lane] = fl;
         if (__any(bad != 0)) {
           // some lane met other traction bytes: nothing of this chunk may be used.  Back to its start.
-          if (lane == 0) fail_flags[tw] = next + 1;
+          if (lane == 0) {
+            fail_flags[tw] = next + 1;
+            if (P.spec_failures) atomicAdd_system(P.spec_failures, 1u);  // (once per tile: exact from here on)
+          }
           x = xs; y = ys; x64 = (double)x; y64 = (double)y;
           th = snap_th[(next & 1) * 64 + lane];
           s = snap_s[(next & 1) * 64 + lane];

@@ -406,7 +406,7 @@ def test_det_rollout_variants_vs_oracle(label, rows, cols, res, n, t_steps, x0, 
     lin.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)
     ang.set_TDM_from_PMF_grid(pmf[:, ::-1].copy(), td, obstacle, unknown)
     planner = MPPI_Numba(cfg)
-    planner.set_debug_flags(flags)
+    planner.set_debug_flags(flags | 16)  # (16: keep the speculative kernels where the planner would switch to k_rollout_pipe)
     params = bench.make_params("c2")
     params.update(x0=np.array(x0), xgoal=np.array([x0[0] + 3.0, x0[1] + 2.0]), lambda_weight=5.0)
     planner.setup(params, lin, ang)
@@ -482,7 +482,7 @@ def test_speculation_holds_then_fails_same_bits(kind, t_steps, n, flags):
     lin.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)
     ang.set_TDM_from_PMF_grid(ang_pmf, td, obstacle, unknown)
     planner = MPPI_Numba(cfg)
-    planner.set_debug_flags(flags)
+    planner.set_debug_flags(flags | 16)  # (16: keep speculating where the planner would have given up, see below)
     params = bench.make_params("c2")
     params.update(x0=np.array([25.1, 24.9, 0.7]), xgoal=np.array([40.0, 38.0]), lambda_weight=5.0)
     if kind == "ring":
@@ -506,6 +506,56 @@ def test_speculation_holds_then_fails_same_bits(kind, t_steps, n, flags):
     ulps = ulp_diff_f32(got, want)
     assert (ulps == 0).mean() >= 0.999, "%s: exact fraction %.5f, max ulp %d" % (kind, (ulps == 0).mean(), ulps.max())
     assert (np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max() < 1e-6
+
+
+def test_planner_stops_speculating_on_a_map_where_it_does_not_pay():
+    """On a map whose traction changes from cell to cell every tile of the speculative kernels fails
+    its vote and re-runs exact -- slower than k_rollout_pipe from the start (85 vs 49 us at N = 8192,
+    T = 200).  The kernels count failed tiles; at the next point where the host has synchronised
+    anyway (solve, synchronize) the planner switches, and speculates again when the map changes.
+    Costs are the oracle's before and after."""
+    from mppi_numba_amd.config import Config
+    from mppi_numba_amd.mppi import MPPI_Numba
+    from mppi_numba_amd.terrain import TDM_Numba
+    rows = cols = 200
+    res = 0.25
+    cfg = Config(T=6.0, dt=0.1, num_grid_samples=1, num_control_rollouts=8192, max_speed_padding=5.0,
+                 num_vis_state_rollouts=1, max_map_dim=(rows + 4, cols + 4), seed=5,
+                 enforce_recommended_limits=False, use_det_dynamics=True)
+    params = bench.make_params("c2")
+    params.update(x0=np.array([25.1, 24.9, 0.7]), xgoal=np.array([40.0, 38.0]), lambda_weight=5.0)
+
+    def check(planner, lin, ang, expect):
+        planner.sample_noise()
+        noise, u_in = planner.noise_samples_d.copy_to_host(), planner.u_cur_d.copy_to_host()
+        planner.rollout()
+        assert planner.last_rollout_kernel().startswith(expect), planner.last_rollout_kernel()
+        ulps = ulp_diff_f32(planner.costs_d.copy_to_host(), oracle_costs(dict(m=1), params, lin, ang, noise, u_in))
+        assert (ulps == 0).mean() >= 0.999
+
+    pmf, ang_pmf, obstacle, unknown, td = patch_world(rows, cols, res, "stripes", seed=11)
+    lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
+    lin.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)
+    ang.set_TDM_from_PMF_grid(ang_pmf, td, obstacle, unknown)
+    planner = MPPI_Numba(cfg)
+    planner.setup(params, lin, ang)
+    lin.sample_grids()  # (solve() does this; the stage-level calls do not)
+    ang.sample_grids()
+    check(planner, lin, ang, "k_rollout_deep")  # nothing known about this map yet
+    planner.solve()                             # ... the host synchronises, sees the failed tiles ...
+    check(planner, lin, ang, "k_rollout_pipe")  # ... and stops speculating
+    planner.iterate_async(3)
+    planner.synchronize()
+    check(planner, lin, ang, "k_rollout_pipe")
+    # a map of one traction value: speculation pays again
+    pmf, ang_pmf, obstacle, unknown, td = patch_world(rows, cols, res, "uniform", seed=11)
+    lin.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)
+    ang.set_TDM_from_PMF_grid(ang_pmf, td, obstacle, unknown)
+    planner.setup(params, lin, ang)
+    planner.solve()
+    check(planner, lin, ang, "k_rollout_deep")
+    planner.solve()
+    check(planner, lin, ang, "k_rollout_deep")
 
 
 def test_overlapped_noise_generation_equals_in_line_generation():
