@@ -470,7 +470,10 @@ __global__ __launch_bounds__(64 * kDeepWaves) void k_rollout_deep(
           ring_fl[(c & 1) * 64 + lane] = fl;
           if (__any(bad != 0) && lane == 0) {
             fail[k & 1] = 1;  // read by everybody in interval k+1
-            if (Q.spec_failures) atomicAdd_system(Q.spec_failures, 1u);  // (once per tile: it leaves the pipeline)
+            if (Q.spec_failures) {  // (once per tile: it leaves the pipeline)
+              atomicAdd_system(Q.spec_failures, 1u);
+              __threadfence_system();  // performed before this launch can be seen to have finished
+            }
           }
         }
         if (k == 1) store_window();

@@ -496,7 +496,10 @@ __global__ __launch_bounds__(256 * W) void k_rollout_spec(DevParams P, const uin
           // some lane met other traction bytes: nothing of this chunk may be used.  Back to its start.
           if (lane == 0) {
             fail_flags[tw] = next + 1;
-            if (P.spec_failures) atomicAdd_system(P.spec_failures, 1u);  // (once per tile: exact from here on)
+            if (P.spec_failures) {  // (once per tile: exact from here on)
+              atomicAdd_system(P.spec_failures, 1u);
+              __threadfence_system();  // performed before this launch can be seen to have finished
+            }
           }
           x = xs; y = ys; x64 = (double)x; y64 = (double)y;
           th = snap_th[(next & 1) * 64 + lane];

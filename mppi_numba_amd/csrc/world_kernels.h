@@ -135,6 +135,7 @@ __global__ void k_world_step(WorldGrid G, WorldLoop L, BatchInst* __restrict__ i
     if (sqrt(dx * dx + dy * dy) <= L.goal_tolerance) {
       L.done[b] = step + 1;
       atomicAdd_system(L.done_count, 1);
+      __threadfence_system();
     }
   }
   for (int t = threadIdx.x; t + 1 < n_steps; t += blockDim.x) ub[t] = shifted[t + 1];

@@ -1,3 +1,6 @@
+"""math="fast" against the oracle on the bench's worlds: quantiles of the relative cost error, the
+fraction within 1e-5 and the achieved |du| / range (developer tool, GPU box):
+    python tools/fast_math_check.py"""
 import sys, os, numpy as np, contextlib, io
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 from test_gpu_scale import build, oracle_costs, oracle_params
