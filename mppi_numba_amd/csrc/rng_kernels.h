@@ -127,6 +127,7 @@ struct NoiseJob {
 
 // one ROW of 64 lanes per wave iteration: Philox -> (tile, step pair), xoroshiro -> (tile, step)
 // (32-bit row arithmetic: the 64-bit divisions of a flat index cost more than the generator)
+template <bool STREAMING = false>
 __device__ __forceinline__ void noise_row(const NoiseJob& j, unsigned int row, int lane) {
   if (j.states == nullptr) {
     const unsigned int pairs = (unsigned int)(j.n_steps + 1) / 2u;
@@ -140,8 +141,22 @@ __device__ __forceinline__ void noise_row(const NoiseJob& j, unsigned int row, i
                             make_uint2((unsigned int)j.seed, (unsigned int)(j.seed >> 32)));
     float2 a = box_muller_fast(r.x, r.y), b = box_muller_fast(r.z, r.w);
     float2* o = j.out + ((size_t)tile * j.n_steps + 2 * tp) * 64 + lane;
-    o[0] = make_float2(j.std0 * a.x, j.std1 * a.y);
-    if (2 * (int)tp + 1 < j.n_steps) o[64] = make_float2(j.std0 * b.x, j.std1 * b.y);
+    if (STREAMING) {
+      // written past the caches: these are the spare workgroups of a latency-regime rollout launch, and
+      // 6.5 MB of write-allocated lines in the L2 the rollout tiles are reading through cost the
+      // launch 2.8 us at C2 (20.8 -> 18.0 us).  The standalone generator keeps ordinary stores: the
+      // throughput-regime rollout that follows it wants the noise in the L2 / infinity cache (C4: 83
+      // -> 106 us with streaming stores).
+      __builtin_nontemporal_store(j.std0 * a.x, &o[0].x);
+      __builtin_nontemporal_store(j.std1 * a.y, &o[0].y);
+      if (2 * (int)tp + 1 < j.n_steps) {
+        __builtin_nontemporal_store(j.std0 * b.x, &o[64].x);
+        __builtin_nontemporal_store(j.std1 * b.y, &o[64].y);
+      }
+    } else {
+      o[0] = make_float2(j.std0 * a.x, j.std1 * a.y);
+      if (2 * (int)tp + 1 < j.n_steps) o[64] = make_float2(j.std0 * b.x, j.std1 * b.y);
+    }
   } else {
     const unsigned int steps = (unsigned int)j.n_steps;
     const unsigned int tile = row / steps, t = row - tile * steps;
@@ -162,10 +177,12 @@ __host__ __device__ inline size_t noise_items(int n_local, int n_steps, bool phi
 }
 
 // wave `wave_id` of `n_waves` cooperating waves: rows wave_id, wave_id + n_waves, ...
+// STREAMING: nontemporal stores (see noise_row)
+template <bool STREAMING = false>
 __device__ __forceinline__ void noise_generate(const NoiseJob& j, unsigned int wave_id, unsigned int n_waves) {
   const unsigned int rows = (unsigned int)(noise_items(j.n_local, j.n_steps, j.states == nullptr) >> 6);
   const int lane = threadIdx.x & 63;
-  for (unsigned int row = wave_id; row < rows; row += n_waves) noise_row(j, row, lane);
+  for (unsigned int row = wave_id; row < rows; row += n_waves) noise_row<STREAMING>(j, row, lane);
 }
 
 __global__ __launch_bounds__(256) void k_noise(NoiseJob job) {

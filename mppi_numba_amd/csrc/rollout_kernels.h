@@ -713,7 +713,7 @@ __global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16
     MPPI_STAMP(threadIdx.x == 0 && ((int)blockIdx.x == n_rollout_blocks || blockIdx.x == gridDim.x - 1),
                (int)blockIdx.x == n_rollout_blocks ? 16 : 18);
     if (next_noise.out)
-      noise_generate(next_noise, (blockIdx.x - n_rollout_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6),
+      noise_generate<true>(next_noise, (blockIdx.x - n_rollout_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6),
                      (gridDim.x - n_rollout_blocks) * (blockDim.x >> 6));
     MPPI_STAMP(threadIdx.x == 0 && ((int)blockIdx.x == n_rollout_blocks || blockIdx.x == gridDim.x - 1),
                (int)blockIdx.x == n_rollout_blocks ? 17 : 19);
