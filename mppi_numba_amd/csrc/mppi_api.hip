@@ -2396,6 +2396,7 @@ extern "C" int mppi_planner_closed_loop(mppi_planner* p, mppi_tdm* lin, mppi_tdm
     if (launched % check_every == 0) {
       TraceRange tr_wait("mppi:closed_loop_check");
       HIP_TRY(hipStreamSynchronize(p->stream));
+      review_speculation(p);  // (the host has waited anyway: is speculating on this map paying?)
       if (*p->loop_done_count >= B) break;
     }
   }
