@@ -100,6 +100,28 @@ WORKLOADS = {
 }
 
 
+def build_planner(workload, n=None, rank=0, world=1, rng="philox", math="exact", seed=1):
+    """(workload dict, cfg, lin_tdm, ang_tdm, planner, params): the objects of a bench workload at
+    `n` control samples per GPU (tests/ and tools/ build their planners through this)."""
+    from mppi_numba_amd.config import Config
+    from mppi_numba_amd.mppi import MPPI_Numba
+    from mppi_numba_amd.terrain import TDM_Numba
+    w = dict(WORKLOADS[workload])
+    if n is not None:
+        w["n"] = n
+    cfg = Config(T=w["t"] * 0.1, dt=0.1, num_grid_samples=w["m"], num_control_rollouts=w["n"] * world,
+                 max_speed_padding=5.0, num_vis_state_rollouts=1, max_map_dim=(260, 260), seed=seed,
+                 enforce_recommended_limits=False, rng=rng, math=math, **w["mode"])
+    pmf, obstacle, unknown, tdm_dict = synthetic_world(workload, np.random.default_rng(0))
+    lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
+    lin.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
+    ang.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
+    planner = MPPI_Numba(cfg, rank=rank, world_size=world)
+    params = make_params(workload)
+    planner.setup(params, lin, ang)
+    return w, cfg, lin, ang, planner, params
+
+
 def batch_problems(count, rng):
     """Start states and goals spread over the 64 m x 64 m map (c5)."""
     x0s = np.stack([rng.uniform(2, 62, count), rng.uniform(2, 62, count), rng.uniform(-np.pi, np.pi, count)],

@@ -12,23 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def build(workload, n=None, rank=0, world=1, rng="philox", math="exact", seed=1):
-    from mppi_numba_amd.config import Config
-    from mppi_numba_amd.mppi import MPPI_Numba
-    from mppi_numba_amd.terrain import TDM_Numba
-    w = dict(bench.WORKLOADS[workload])
-    if n is not None:
-        w["n"] = n
-    cfg = Config(T=w["t"] * 0.1, dt=0.1, num_grid_samples=w["m"], num_control_rollouts=w["n"] * world,
-                 max_speed_padding=5.0, num_vis_state_rollouts=1, max_map_dim=(260, 260), seed=seed,
-                 enforce_recommended_limits=False, rng=rng, math=math, **w["mode"])
-    pmf, obstacle, unknown, tdm_dict = bench.synthetic_world(workload, np.random.default_rng(0))
-    lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
-    lin.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
-    ang.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
-    planner = MPPI_Numba(cfg, rank=rank, world_size=world)
-    params = bench.make_params(workload)
-    planner.setup(params, lin, ang)
-    return w, cfg, lin, ang, planner, params
+    return bench.build_planner(workload, n, rank=rank, world=world, rng=rng, math=math, seed=seed)
 
 
 def oracle_params(params, lin, ang):

@@ -4,7 +4,7 @@ k_update_rows<apply>.  Prints microseconds per iteration (C2 sizes) and the per-
 Developer tool (GPU box): python tools/rccl_single_rank_probe.py"""
 import sys, os, time, numpy as np, contextlib, io
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
-from test_gpu_scale import build
+from bench import build_planner as build
 from mppi_numba_amd.mppi import comm_unique_id
 with contextlib.redirect_stdout(io.StringIO()):
     w, cfg, lin, ang, planner, params = build("c2", 8192)

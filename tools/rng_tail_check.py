@@ -22,7 +22,7 @@ def main():
     from scipy import stats
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
-        from test_gpu_scale import build
+        from bench import build_planner as build
         w, cfg, lin, ang, planner, params = build("c2", 262144)
     edges = stats.norm.ppf(np.linspace(0.0, 1.0, 257)[1:-1])
     counts = np.zeros(256, dtype=np.int64)

@@ -29,7 +29,7 @@ def main():
     args = ap.parse_args()
     from mppi_numba_amd import _lib
     with contextlib.redirect_stdout(io.StringIO()):
-        from test_gpu_scale import build
+        from bench import build_planner as build
         w, cfg, lin, ang, planner, params = build(args.workload, args.n, math=os.environ.get("MPPI_MATH", "exact"))
         planner.solve()
         planner.iterate_async(20)
