@@ -161,3 +161,25 @@ def test_sample_sharded_loop_needs_a_communicator_and_runs_with_one():
     lin, ang, p, params = _cvar_build(64, 8, shard=(0, 2))
     with pytest.raises(MppiError, match="no communicator"):
         p.solve()
+
+
+def test_sample_shards_need_the_counter_based_generator_and_even_offsets():
+    """The shards' draws are the unsharded ones because a draw's Philox counter is its global sample
+    index; the numba-compatible xoroshiro streams cannot be split that way, and a Philox block
+    serves a pair of samples."""
+    import bench
+    from mppi_numba_amd import _lib
+    from mppi_numba_amd._lib import MppiError
+    from mppi_numba_amd.config import Config
+    from mppi_numba_amd.terrain import TDM_Numba
+    cfg = Config(T=1.0, dt=0.1, num_grid_samples=8, num_control_rollouts=64, max_speed_padding=5.0,
+                 num_vis_state_rollouts=1, max_map_dim=(260, 260), seed=1, enforce_recommended_limits=False,
+                 rng="xoroshiro", use_tdm=True)
+    with pytest.raises(MppiError, match="counter-based"):
+        TDM_Numba(cfg, sample_shard=(1, 2))
+    cfg.rng = "philox"
+    tdm = TDM_Numba(cfg, sample_shard=(1, 2))
+    with pytest.raises(MppiError, match="even"):
+        _lib.call("mppi_tdm_set_sample_shard", tdm._handle, 3)
+    with pytest.raises(AssertionError):
+        TDM_Numba(cfg, sample_shard=(0, 3))  # 8 samples do not split into 3 shards of whole pairs

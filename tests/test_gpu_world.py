@@ -175,3 +175,18 @@ def test_closed_loop_batched_problems_each_follow_their_own_loop():
         if n < max_steps:
             assert d1 <= params["goal_tolerance"]
     np.testing.assert_allclose(batch.x0s, np.stack([xh[b, steps[b]] for b in range(B)]).astype(np.float32))
+
+
+def test_device_world_of_an_int8_traction_grid():
+    """TractionGrid(use_int8=True) keeps 0..100 integers (terrain.py:757-759); its device twin answers
+    with the same numbers."""
+    from mppi_numba_amd.terrain import DeviceWorld, TractionGrid
+    rng = np.random.default_rng(8)
+    host = TractionGrid(rng.random((20, 30)), rng.random((20, 30)), res=0.5, use_int8=True)
+    assert host.lin_traction.dtype == np.int8
+    dev = DeviceWorld.from_traction_grid(host)
+    x, y = rng.uniform(-1, 16, 500), rng.uniform(-1, 11, 500)
+    got_l, got_a = dev.get(x, y)
+    want = np.array([host.get(a, b) for a, b in zip(x, y)], dtype=np.float64)
+    np.testing.assert_array_equal(got_l, want[:, 0])
+    np.testing.assert_array_equal(got_a, want[:, 1])
