@@ -54,7 +54,17 @@ def random_case(seed):
     return mode, rows, cols, res, dt, t_steps, n, m, pmf, obstacle, unknown, td, params, pad_speed
 
 
-@pytest.mark.parametrize("seed", range(60))
+def _seeds():
+    """60 fixed cases; MPPI_FUZZ_RANGE="a:b" swaps in other seeds for a soak run."""
+    import os
+    span = os.environ.get("MPPI_FUZZ_RANGE")
+    if span:
+        lo, hi = (int(v) for v in span.split(":"))
+        return range(lo, hi)
+    return range(60)
+
+
+@pytest.mark.parametrize("seed", _seeds())
 def test_random_configuration_matches_oracle(seed):
     from mppi_numba_amd.config import Config
     from mppi_numba_amd.mppi import MPPI_Numba
