@@ -1764,13 +1764,27 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
           int res_exp = 0;
           const bool pow2res = std::frexp((double)a.res, &res_exp) == 0.5;
           float* sc_out = sc_dst;
+          // the next iteration's noise by workgroups appended to the grid (they run in the launch's tail)
+          NoiseJob next_job;
+          memset(&next_job, 0, sizeof(next_job));
+          int extra = 0;
+          static const bool no_fused_noise = getenv("MPPI_NO_FUSED_NOISE") != nullptr;  // developer switch
+          if (p->next_noise_wanted && !no_fused_noise && p->cfg.rng == MPPI_RNG_PHILOX) {
+            const long rows = (long)(noise_items(p->n_local, T, true) >> 6);
+            extra = (int)std::min<long>(2L * p->num_cus, ceil_div(rows, (long)(threads / 64) * 4));
+            if (extra > 0) {
+              next_job = make_noise_job(p, p->noise_buf[p->noise_cur ^ 1]);
+              p->next_noise_done = true;
+            }
+          }
           if (pow2res)
-            MPPI_KLAUNCH((k_rollout_tdm_fast<true>), dim3(N), dim3(threads), lds_fast, p->stream, d, p->cells,
-                               p->noise, p->u, p->costs, sc_out, mp2);
+            MPPI_KLAUNCH((k_rollout_tdm_fast<true>), dim3(N + extra), dim3(threads), lds_fast, p->stream, d, p->cells,
+                               p->noise, p->u, p->costs, sc_out, mp2, N, next_job);
           else
-            MPPI_KLAUNCH((k_rollout_tdm_fast<false>), dim3(N), dim3(threads), lds_fast, p->stream, d, p->cells,
-                               p->noise, p->u, p->costs, sc_out, mp2);
-          p->last_rollout = std::string("k_rollout_tdm_fast pow2res=") + (pow2res ? "1" : "0");
+            MPPI_KLAUNCH((k_rollout_tdm_fast<false>), dim3(N + extra), dim3(threads), lds_fast, p->stream, d, p->cells,
+                               p->noise, p->u, p->costs, sc_out, mp2, N, next_job);
+          p->last_rollout = std::string("k_rollout_tdm_fast pow2res=") + (pow2res ? "1" : "0") +
+                            " noise_blocks=" + std::to_string(extra);
           break;
         }
       }

@@ -852,11 +852,21 @@ __global__ void k_rollout_tdm(DevParams P, const uint32_t* __restrict__ cellsM,
 // Same rounding points as k_rollout_tdm (the generic kernel stays as the fallback).
 // LDS: [T] double2 {dt*v, dt*w} | [T] double control-cost products | [Mp] float costs.
 // -------------------------------------------------------------------------
+// Workgroups past the N control samples (the end of the grid: they start as the first rollout
+// workgroups retire) generate the noise of the NEXT iteration into the other buffer, which saves
+// the stand-alone generator's launch (5.9 us of 161 at C3).
 template <bool POW2RES>
 __global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cellsM,
                                    const float2* __restrict__ noise, const float2* __restrict__ u,
-                                   float* __restrict__ costs, float* __restrict__ sample_costs, int m_pow2) {
+                                   float* __restrict__ costs, float* __restrict__ sample_costs, int m_pow2,
+                                   int n_rollout_blocks, NoiseJob next_noise) {
   extern __shared__ double2 qd_sh[];
+  if ((int)blockIdx.x >= n_rollout_blocks) {
+    if (next_noise.out)
+      noise_generate(next_noise, (blockIdx.x - n_rollout_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6),
+                     (gridDim.x - n_rollout_blocks) * (blockDim.x >> 6));
+    return;
+  }
   const int T = P.n_steps, M = P.n_grids;
   double* cc_sh = reinterpret_cast<double*>(qd_sh + T);
   float* sc = reinterpret_cast<float*>(cc_sh + T);
