@@ -249,6 +249,8 @@ def main():
     ap.add_argument("--problems", type=int, default=None, help="c5: problems per GPU (default 64)")
     ap.add_argument("--math", default="exact", choices=["exact", "fast"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-flags", type=int, default=0,
+                    help="developer switches (include/mppi_hip.h MPPI_DEBUG_*): which kernel variant runs (experiments)")
     ap.add_argument("--graph", type=int, default=0, metavar="ITERATIONS",
                     help="hipGraph replay of the iteration loop, that many (even) iterations per graph; "
                          "0 = direct launches (single GPU; same results)")
@@ -383,6 +385,8 @@ def main():
         planner.solve = solve_staged
 
     runner = group if group_size > 1 else planner  # what iterates: one handle or the device group
+    if args.debug_flags:
+        planner.set_debug_flags(args.debug_flags)
 
     def barrier():
         hub.barrier()

@@ -22,6 +22,7 @@
 #include "rollout_kernels.h"
 #include "rollout_spec_kernel.h"
 #include "rollout_deep_kernel.h"
+#include "rollout_scan_kernel.h"
 #include "map_kernels.h"
 #include "update_kernels.h"
 #include "world_kernels.h"
@@ -679,6 +680,7 @@ struct mppi_planner {
   hipGraph_t graph[2] = {nullptr, nullptr};
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
   std::vector<unsigned char> graph_sig[2];  // everything the captured launches took by value
+  uint64_t graph_spec_tiles[2] = {0, 0};    // speculative tiles one replay of the graph launches
   long graph_replays = 0, graph_captures = 0;
   std::string last_rollout;        // which rollout kernel variant the last launch used (diagnostic)
   int debug_flags = 0;             // mppi_planner_set_debug_flags (tests pin every kernel variant through it)
@@ -694,6 +696,15 @@ struct mppi_planner {
   float* tile_beta = nullptr;  // [n_tiles] minimum cost of each tile of 64 rollouts
   int n_tiles = 0;
   bool tile_packets_fresh = false;  // w_rel / tile_beta written by the rollout kernel for the current costs
+  // k_rollout_scan (MPPI_MATH_FAST): per-tile sums of w_rel * noise, consumed by k_combine_tiles
+  float2* tnum = nullptr;  // [T][n_tiles]
+  float* tden = nullptr;   // [n_tiles]
+  bool scan_packets_fresh = false;  // ... written by the last rollout launch for the current costs
+  // the iteration loop of such a handle generates the noise INSIDE the rollout launch (Philox counter
+  // blocks, never stored): noise_buf is then stale, and whoever wants the noise of the last iteration
+  // (get_noise, get_state_rollout, a stage-level update) has it regenerated from the same counters
+  bool scan_gen_now = false;   // the coming rollout launch is to generate its own noise
+  bool noise_virtual = false;  // the noise of the last iteration exists as counters only (epoch noise_epoch - 1)
   double* packets = nullptr;  // [world][2+2T]; own packet at [rank]
   double* stats = nullptr;    // {beta, den} of the last update
   uint32_t* cells = nullptr;
@@ -790,6 +801,8 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   dev_free(p->weights_out);
   dev_free(p->w_rel);
   dev_free(p->tile_beta);
+  dev_free(p->tnum);
+  dev_free(p->tden);
   dev_free(p->packets);
   dev_free(p->stats);
   dev_free(p->cells);
@@ -1394,17 +1407,140 @@ static int upload_instances(mppi_planner* p) {
 #define MPPI_KLAUNCH(kernel, grid, block, lds, stream, ...) \
   hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, p->kev_start, p->kev_stop, 0, __VA_ARGS__)
 
+
+// ---- k_rollout_scan (rollout_scan_kernel.h): the time-parallel rollout of MPPI_MATH_FAST --------
+// Eligible: deterministic-dynamics mode, 16-bit cells (the reference's own maps always are), a horizon
+// of at most 16 chunks of 8 steps, LDS for the per-step records, and a map the speculation pays on.
+struct ScanPlan {
+  int waves = 0;       // chunks of 8 steps = waves per workgroup
+  size_t lds = 0;
+  bool pow2res = false, chain64 = true;
+};
+
+static bool scan_plan(const mppi_planner* p, ScanPlan* out) {
+  static const bool disabled = getenv("MPPI_NO_SCAN") != nullptr;  // developer switch (ablation)
+  if (disabled || (p->debug_flags & MPPI_DEBUG_NO_SCAN_KERNEL)) return false;
+  if (p->cfg.math != MPPI_MATH_FAST || p->cfg.mode != MPPI_MODE_DET) return false;
+  if (!p->cells16_valid || p->cells16_with_risk) return false;
+  if (p->speculation_off && !(p->debug_flags & MPPI_DEBUG_KEEP_SPECULATING)) return false;
+  const int T = p->cfg.num_steps;
+  ScanPlan plan;
+  plan.waves = ceil_div(T, 8);
+  if (plan.waves > 16) return false;
+  plan.chain64 = !(p->debug_flags & MPPI_DEBUG_SCAN_CHAIN32);
+  plan.lds = plan.chain64 ? ScanLds<8, true>::total(plan.waves) : ScanLds<8, false>::total(plan.waves);
+  if (plan.lds > (size_t)p->lds_per_cu - 1024) return false;
+  int res_exp = 0;
+  plan.pow2res = std::frexp((double)p->params.res, &res_exp) == 0.5;  // res == 2^k exactly
+  if (out) *out = plan;
+  return true;
+}
+
+// the iteration loop may let the rollout launch generate its own noise: Philox counters only
+static bool scan_generates_noise(const mppi_planner* p) {
+  static const bool disabled = getenv("MPPI_SCAN_READ_NOISE") != nullptr;  // developer switch (ablation)
+  return !disabled && !(p->debug_flags & (MPPI_DEBUG_SCAN_READ_NOISE | MPPI_DEBUG_SCAN_ROWS_UPDATE)) &&
+         p->cfg.rng == MPPI_RNG_PHILOX && scan_plan(p, nullptr);
+}
+
+// the noise of the last iteration into noise_buf when it exists as counters only
+static int materialize_noise(mppi_planner* p) {
+  if (!p->noise_virtual) return MPPI_OK;
+  NoiseJob j;
+  memset(&j, 0, sizeof(j));
+  j.out = p->noise;
+  j.seed = p->cfg.seed;
+  j.epoch = p->noise_epoch - 1;  // the block the last rollout launch consumed
+  j.n_local = p->n_local;
+  j.n_offset = p->n_offset;
+  j.n_steps = p->cfg.num_steps;
+  j.std0 = p->params.u_std[0];
+  j.std1 = p->params.u_std[1];
+  const long total = (long)noise_items(p->n_local, p->cfg.num_steps, true);
+  hipLaunchKernelGGL(k_noise, dim3(ceil_div(total, 256)), dim3(256), 0, p->stream, j);
+  HIP_TRY(hipGetLastError());
+  p->noise_virtual = false;
+  return MPPI_OK;
+}
+
+static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan) {
+  const int N = p->n_local, T = p->cfg.num_steps;
+  const int tiles = ceil_div(N, 64);
+  if (!p->tnum) {
+    TRY(dev_alloc(&p->tnum, (size_t)T * (size_t)tiles));
+    TRY(dev_alloc(&p->tden, (size_t)tiles));
+  }
+  const bool gen = p->scan_gen_now;
+  const bool rows_update = (p->debug_flags & MPPI_DEBUG_SCAN_ROWS_UPDATE) != 0;  // k_update_rows reads the noise
+  ScanPackets pk;
+  pk.tnum = rows_update ? nullptr : p->tnum;
+  pk.tden = p->tden;
+  pk.n_tiles = tiles;
+  NoiseJob gen_job, next_job;
+  memset(&gen_job, 0, sizeof(gen_job));
+  memset(&next_job, 0, sizeof(next_job));
+  int extra = 0;
+  if (gen) {
+    gen_job = make_noise_job(p, nullptr);  // (advances the Philox epoch: this iteration's block)
+  } else {
+    static const bool no_fused_noise = getenv("MPPI_NO_FUSED_NOISE") != nullptr;  // developer switch
+    if (p->next_noise_wanted && tiles < p->num_cus && !no_fused_noise) {  // spare CUs: the next iteration's noise
+      extra = p->num_cus - tiles;
+      next_job = make_noise_job(p, p->noise_buf[p->noise_cur ^ 1]);
+      p->next_noise_done = true;
+    }
+  }
+  p->spec_tiles_launched += (uint64_t)tiles;
+#define MPPI_LAUNCH_SCAN(P2, GEN, C64)                                                                     \
+  do {                                                                                                    \
+    auto kern = k_rollout_scan<8, P2, GEN, C64>;                                                          \
+    if (plan.lds > 64 * 1024)                                                                             \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));            \
+    MPPI_KLAUNCH(kern, dim3(tiles + extra), dim3(64 * plan.waves), plan.lds, p->stream, d, p->cells16,    \
+                 p->noise, gen_job, p->u, p->costs, p->w_rel, p->tile_beta, pk, tiles, next_job);          \
+  } while (0)
+#define MPPI_LAUNCH_SCAN_G(P2, C64)               \
+  do {                                            \
+    if (gen) MPPI_LAUNCH_SCAN(P2, true, C64);     \
+    else MPPI_LAUNCH_SCAN(P2, false, C64);        \
+  } while (0)
+  if (plan.pow2res && plan.chain64) MPPI_LAUNCH_SCAN_G(true, true);
+  else if (plan.pow2res) MPPI_LAUNCH_SCAN_G(true, false);
+  else if (plan.chain64) MPPI_LAUNCH_SCAN_G(false, true);
+  else MPPI_LAUNCH_SCAN_G(false, false);
+#undef MPPI_LAUNCH_SCAN_G
+#undef MPPI_LAUNCH_SCAN
+  HIP_TRY(hipGetLastError());
+  char buf[256];
+  snprintf(buf, sizeof(buf),
+           "k_rollout_scan chunk=8 waves=%d pow2res=%d noise=%s chain=%s update=%s lds=%zu noise_blocks=%d problems=%d",
+           plan.waves, (int)plan.pow2res, gen ? "in-kernel" : "read", plan.chain64 ? "f64" : "f32",
+           rows_update ? "rows" : "tile-packets", plan.lds, extra, p->inst_set ? p->B : 0);
+  p->last_rollout = buf;
+  p->tile_packets_fresh = true;
+  p->scan_packets_fresh = !rows_update;
+  p->noise_virtual = gen;
+  return MPPI_OK;
+}
+
 template <bool EXACT, bool BOUNDED>
 static int launch_rollout_t(mppi_planner* p, DevParams d) {
   const int N = p->n_local, T = p->cfg.num_steps, M = p->cfg.num_grid_samples;
   size_t lds = sizeof(double2) * (size_t)T;
   const size_t lds_map = sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);  // + staged u[t]
+  p->scan_packets_fresh = false;
+  if (p->noise_virtual && !p->scan_gen_now) TRY(materialize_noise(p));  // the coming kernel reads its noise
   switch (p->cfg.mode) {
     case MPPI_MODE_DET: {
       p->tile_packets_fresh = false;
       size_t lds_win = 0;
       bool have_window = plan_lds_window(p, d, &lds_win);
       TRY(upload_instances(p));
+      if (!EXACT) {
+        ScanPlan plan;
+        if (scan_plan(p, &plan)) return launch_scan(p, d, plan);
+      }
       static const bool no_pipe = getenv("MPPI_NO_PIPE") != nullptr;  // developer switch (ablation)
       // incremental trig: needs a heading increment |dt*w*traction| <= 0.36 rad and T <= 2000
       bool rot_ok = false, pow2res = false;
@@ -1868,6 +2004,25 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
   const int N = p->n_local, T = p->cfg.num_steps;
   const mppi_params& a = p->params;
   double* my_packet = p->packets + (size_t)p->cfg.rank * p->B * packet_len(T);
+  if (p->scan_packets_fresh) {
+    // the rollout launch (k_rollout_scan) has reduced w_rel * noise over every tile: combine the tiles
+    p->scan_packets_fresh = false;
+    p->tile_packets_fresh = false;
+    const dim3 grid(T, p->B);
+    unsigned long long* gen = p->graph_on ? p->gen_dev : (unsigned long long*)nullptr;
+    if (apply_here)
+      MPPI_KLAUNCH((k_combine_tiles<true>), grid, dim3(64), 0, p->stream, p->tile_beta, p->tden, p->tnum, p->inst_tiles,
+                   p->n_tiles, T, a.lambda_weight, my_packet, p->u, p->u_prev, p->u_host_dev, a.vrange[0], a.vrange[1],
+                   a.wrange[0], a.wrange[1], p->stats, gen);
+    else
+      MPPI_KLAUNCH((k_combine_tiles<false>), grid, dim3(64), 0, p->stream, p->tile_beta, p->tden, p->tnum, p->inst_tiles,
+                   p->n_tiles, T, a.lambda_weight, my_packet, p->u, p->u_prev, p->u_host_dev, a.vrange[0], a.vrange[1],
+                   a.wrange[0], a.wrange[1], p->stats, gen);
+    if (p->graph_on) ++p->bumps_launched;
+    HIP_TRY(hipGetLastError());
+    return MPPI_OK;
+  }
+  if (p->noise_virtual) TRY(materialize_noise(p));  // the row kernel streams the noise
   // rollout kernels without the weight epilogue: the row kernel forms the tile weights itself
   // from the costs (same bits) unless there are too many tiles for its LDS arrays
   const bool from_costs = !p->tile_packets_fresh && 2 * sizeof(float) * (size_t)p->inst_tiles <= 60 * 1024;
@@ -1950,12 +2105,22 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
   const bool side_stream_pays = (long)p->n_local * p->cfg.num_steps >= 4L * 1000 * 1000 &&
                                 ceil_div(ceil_div(p->n_local, 64), p->num_cus) <= 8 && !no_side_stream;
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[0], p->stream));
-  if (have_noise) {
+  // MPPI_MATH_FAST over a map the time-parallel kernel takes: the rollout launch computes its noise
+  // from the Philox counters itself; nothing is generated ahead, nothing is stored
+  const bool gen_in_rollout = scan_generates_noise(p);
+  p->scan_gen_now = gen_in_rollout;
+  if (gen_in_rollout) {
+    if (have_noise) discard_noise_ahead(p);  // (produced ahead by an earlier, different kind of launch)
+    have_noise = false;
+    want_next = false;
+  } else if (have_noise) {
     p->noise_cur ^= 1;
     if (p->noise_on_side_stream) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_noise_ready, 0));
     p->noise_on_side_stream = false;
+    p->noise_virtual = false;
   } else {
     TraceRange tr("mppi:noise");
+    p->noise_virtual = false;
     TRY(launch_noise(p, p->noise_buf[p->noise_cur]));
   }
   p->noise = p->noise_buf[p->noise_cur];
@@ -1993,6 +2158,7 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
     }
   }
   p->next_noise_wanted = false;
+  p->scan_gen_now = false;
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[2], p->stream));
   TraceRange tr_update("mppi:update");
   if (p->ktime_index >= 0) {
@@ -2018,7 +2184,7 @@ static void graph_signature(const mppi_planner* p, const DevParams& d, const mpp
     mppi_params params;
     const void *lin, *ang, *cells, *cells16, *cc, *sample_costs;
     uint64_t lin_grid, ang_grid, lin_maps, epoch_bias;
-    int noise_cur, inst_set, want_sample_costs, pad;
+    int noise_cur, inst_set, want_sample_costs, speculation_off, debug_flags, pad;
   } sig;
   memset(&sig, 0, sizeof(sig));
   sig.d = d;
@@ -2033,6 +2199,7 @@ static void graph_signature(const mppi_planner* p, const DevParams& d, const mpp
   sig.lin_grid = p->packed_lin_grid; sig.ang_grid = p->packed_ang_grid; sig.lin_maps = p->packed_lin_maps;
   sig.epoch_bias = p->noise_epoch - p->bumps_launched;
   sig.noise_cur = p->noise_cur; sig.inst_set = p->inst_set; sig.want_sample_costs = p->want_sample_costs;
+  sig.speculation_off = p->speculation_off ? 1 : 0; sig.debug_flags = p->debug_flags;
   out.assign(reinterpret_cast<unsigned char*>(&sig), reinterpret_cast<unsigned char*>(&sig) + sizeof(sig));
 }
 
@@ -2040,7 +2207,11 @@ static void graph_signature(const mppi_planner* p, const DevParams& d, const mpp
 // (iterate_async, profiling); solve() on the control path skips them
 // called where the host has just waited for the stream: did speculation pay on this map?
 static void review_speculation(mppi_planner* p) {
-  if (p->spec_tiles_launched == 0 || !p->spec_fail_host) return;
+  if (!p->spec_fail_host) return;
+  if (p->spec_tiles_launched == 0) {  // (nothing speculative ran: whatever the word holds is stale)
+    *p->spec_fail_host = 0u;
+    return;
+  }
   const uint64_t failed = *p->spec_fail_host;
   if (2 * failed >= p->spec_tiles_launched) p->speculation_off = true;
   *p->spec_fail_host = 0u;
@@ -2101,6 +2272,7 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
         if (p->graph[slot]) { (void)hipGraphDestroy(p->graph[slot]); p->graph[slot] = nullptr; }
         p->graph_sig[slot].clear();
         const bool primed_before = have_noise;
+        const uint64_t spec_before = p->spec_tiles_launched;
         HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
         int rc = MPPI_OK;
         for (int j = 0; j < chunk && rc == MPPI_OK; ++j) rc = launch_iteration(p, d, have_noise, true, false);
@@ -2110,12 +2282,15 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
         REQUIRE(have_noise == primed_before, MPPI_ERR_STATE, "graph capture: the iterations are not alike");
         HIP_TRY(hipGraphInstantiate(&p->graph_exec[slot], p->graph[slot], nullptr, nullptr, 0));
         p->graph_sig[slot] = sig;
+        p->graph_spec_tiles[slot] = p->spec_tiles_launched - spec_before;
         ++p->graph_captures;
         // (capturing ran the host side of two iterations; the launch below runs their device side)
       } else {
         // the host-side counters a direct launch of the two iterations would have advanced
         if (p->cfg.rng == MPPI_RNG_PHILOX) p->noise_epoch += (uint64_t)chunk;
         p->bumps_launched += (uint64_t)chunk;
+        // (the replayed kernels count their failed tiles like the captured ones did)
+        p->spec_tiles_launched += p->graph_spec_tiles[slot];
       }
       HIP_TRY(hipGraphLaunch(p->graph_exec[slot], p->stream));
       ++p->graph_replays;
@@ -2442,9 +2617,11 @@ extern "C" int mppi_planner_sample_noise(mppi_planner* p) {
     p->noise_cur ^= 1;
     p->noise = p->noise_buf[p->noise_cur];
     p->primed = false;
+    p->noise_virtual = false;
     HIP_TRY(hipStreamSynchronize(p->stream));
     return MPPI_OK;
   }
+  p->noise_virtual = false;
   TRY(launch_noise(p, p->noise));
   HIP_TRY(hipStreamSynchronize(p->stream));
   return MPPI_OK;
@@ -2454,6 +2631,7 @@ extern "C" int mppi_planner_set_noise(mppi_planner* p, const float* noise) {
   REQUIRE(p && noise, MPPI_ERR_INVALID, "NULL argument");
   HIP_TRY(hipSetDevice(p->cfg.device));
   size_t count = (size_t)p->n_local * p->cfg.num_steps;
+  p->noise_virtual = false;
   HIP_TRY(hipMemcpyAsync(p->staging, noise, count * sizeof(float2), hipMemcpyHostToDevice, p->stream));
   hipLaunchKernelGGL(k_noise_to_device_layout, dim3(ceil_div((long)count, 256)), dim3(256), 0, p->stream,
                      p->staging, p->n_local, p->cfg.num_steps, p->noise);
@@ -2466,6 +2644,7 @@ extern "C" int mppi_planner_get_noise(mppi_planner* p, float* noise) {
   REQUIRE(p && noise, MPPI_ERR_INVALID, "NULL argument");
   HIP_TRY(hipSetDevice(p->cfg.device));
   size_t count = (size_t)p->n_local * p->cfg.num_steps;
+  TRY(materialize_noise(p));
   hipLaunchKernelGGL(k_noise_to_host_layout, dim3(ceil_div((long)count, 256)), dim3(256), 0, p->stream, p->noise,
                      p->n_local, p->cfg.num_steps, p->staging);
   HIP_TRY(hipGetLastError());
@@ -2491,6 +2670,7 @@ extern "C" int mppi_planner_set_costs(mppi_planner* p, const float* costs) {
   HIP_TRY(hipSetDevice(p->cfg.device));
   HIP_TRY(hipMemcpyAsync(p->costs, costs, sizeof(float) * (size_t)p->n_local, hipMemcpyHostToDevice, p->stream));
   p->tile_packets_fresh = false;
+  p->scan_packets_fresh = false;
   HIP_TRY(hipStreamSynchronize(p->stream));
   return MPPI_OK;
 }
@@ -2619,6 +2799,7 @@ extern "C" int mppi_planner_get_instance_state_rollout(mppi_planner* p, mppi_tdm
   HIP_TRY(hipSetDevice(p->cfg.device));
   TRY(check_tdms(p, lin, ang));
   TRY(ensure_packed(p, lin, ang));  // uses the already sampled grids (mppi.py:572-573)
+  TRY(materialize_noise(p));
   DevParams d = make_dev_params(p, lin, ang);
   // one problem of a batched handle: its start state, its controls, its slice of the noise
   struct Rebased {

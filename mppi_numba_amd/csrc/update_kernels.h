@@ -246,6 +246,69 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
   MPPI_STAMP(stamp_wg, 517);
 }
 
+// ---- stage 2 after k_rollout_scan (rollout_scan_kernel.h): the rollout launch has already reduced
+// w_rel * noise over each tile of 64 rollouts (tnum [T][tiles] float2, tden [tiles]); what is left
+// of update_useq_numba (mppi.py:1147-1191) is the combination of the tiles -- T x tiles x 8 bytes
+// instead of a pass over the noise.  Grid (T, problems), one wave per step: beta = min over
+// tile_beta, scale_tile = exp(-(beta_tile - beta)/lambda), den / num in float64 in a fixed order
+// (identical den in every workgroup), then as k_update_rows: apply, or this rank's packet.
+template <bool APPLY>
+__global__ __launch_bounds__(64) void k_combine_tiles(const float* __restrict__ tile_beta,
+                                                      const float* __restrict__ tden,
+                                                      const float2* __restrict__ tnum, int n_tiles, int total_tiles,
+                                                      int n_steps, float lambda, double* __restrict__ rank_packet,
+                                                      float2* __restrict__ u, float2* __restrict__ u_prev,
+                                                      float2* __restrict__ u_mirror, float v_lo, float v_hi,
+                                                      float w_lo, float w_hi, double* __restrict__ stats,
+                                                      unsigned long long* __restrict__ gen_counter) {
+  if (gen_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *gen_counter += 1ull;
+  const int t = blockIdx.x, inst = blockIdx.y, lane = threadIdx.x;
+  tile_beta += (size_t)inst * n_tiles;
+  tden += (size_t)inst * n_tiles;
+  tnum += (size_t)t * total_tiles + (size_t)inst * n_tiles;
+  rank_packet += (size_t)inst * packet_len(n_steps);
+  u += (size_t)inst * n_steps;
+  u_prev += (size_t)inst * n_steps;
+  u_mirror += (size_t)inst * n_steps;
+  stats += 2 * inst;
+  // two tiles per lane cover N = 8192 in one batch of loads; more go round the loop
+  const int g0 = lane, g1 = lane + 64;
+  const float b0 = g0 < n_tiles ? tile_beta[g0] : __builtin_inff(), b1 = g1 < n_tiles ? tile_beta[g1] : __builtin_inff();
+  const float d0 = g0 < n_tiles ? tden[g0] : 0.0f, d1 = g1 < n_tiles ? tden[g1] : 0.0f;
+  const float2 m0 = g0 < n_tiles ? tnum[g0] : make_float2(0.0f, 0.0f), m1 = g1 < n_tiles ? tnum[g1] : make_float2(0.0f, 0.0f);
+  float b = fminf(b0, b1);
+  for (int g = lane + 128; g < n_tiles; g += 64) b = fminf(b, tile_beta[g]);
+  const float beta = wave_min_f32(b);
+  const double neg_inv_lambda = -1.0 / (double)lambda;
+  double den = 0.0, nx = 0.0, ny = 0.0;
+  auto take = [&](float tb, float td, float2 tn) {
+    const double s = (double)(float)exp(neg_inv_lambda * (double)(tb - beta));
+    den = fma(s, (double)td, den);
+    nx = fma(s, (double)tn.x, nx);
+    ny = fma(s, (double)tn.y, ny);
+  };
+  if (g0 < n_tiles) take(b0, d0, m0);
+  if (g1 < n_tiles) take(b1, d1, m1);
+  for (int g = lane + 128; g < n_tiles; g += 64) take(tile_beta[g], tden[g], tnum[g]);
+  den = wave_sum_f64(den);
+  nx = wave_sum_f64(nx);
+  ny = wave_sum_f64(ny);
+  if (lane == 0) {
+    if (APPLY) {
+      apply_update(u, u_prev, u_mirror, t, nx, ny, den, v_lo, v_hi, w_lo, w_hi);
+    } else {
+      rank_packet[2 + 2 * t] = nx;
+      rank_packet[3 + 2 * t] = ny;
+    }
+    if (t == 0) {
+      rank_packet[0] = (double)beta;
+      rank_packet[1] = den;
+      stats[0] = (double)beta;
+      stats[1] = den;
+    }
+  }
+}
+
 // combine the packets of all ranks (identical on every GPU, fixed g order).
 // Batched handle: blockIdx.x = problem b; rank g's packet for it is packets[(g*B + b)*len].
 __global__ __launch_bounds__(kUpdateThreads) void k_apply(const double* __restrict__ packets, int world,
