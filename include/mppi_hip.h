@@ -290,8 +290,7 @@ int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity)
 /* MPPI_MATH_FAST, the time-parallel rollout (k_rollout_scan): */
 #define MPPI_DEBUG_NO_SCAN_KERNEL 32     /* the float32 five-stage pipeline (k_rollout_deep<f32>) instead */
 #define MPPI_DEBUG_SCAN_READ_NOISE 64    /* the iteration loop stores its noise and the kernel reads it (as the stage-level calls do) */
-#define MPPI_DEBUG_SCAN_CHAIN32 128      /* the in-order cost accumulation in float32 instead of float64-rounded-per-step */
-#define MPPI_DEBUG_SCAN_ROWS_UPDATE 256  /* no per-tile sums in the rollout launch: k_update_rows streams the noise */
+#define MPPI_DEBUG_SCAN_FULL_TILES 128   /* workgroups of 64 rollouts (one lane per rollout) instead of 32 (two) */
 int mppi_planner_set_debug_flags(mppi_planner* p, int flags);
 int mppi_selftest_philox(int device, int* mismatches);
 /* developer instrumentation: in-kernel clock stamps of a -DMPPI_STAMPS build

@@ -21,7 +21,7 @@ PREP_TDM, PREP_DET, PREP_SPEED = 0, 1, 2
 DEBUG_NO_SPEC_KERNEL, DEBUG_NO_SPECULATION, DEBUG_NO_DEEP_KERNEL, DEBUG_CC_GLOBAL = 1, 2, 4, 8
 DEBUG_KEEP_SPECULATING = 16
 # MPPI_MATH_FAST, the time-parallel rollout kernel (include/mppi_hip.h)
-DEBUG_NO_SCAN_KERNEL, DEBUG_SCAN_READ_NOISE, DEBUG_SCAN_CHAIN32, DEBUG_SCAN_ROWS_UPDATE = 32, 64, 128, 256
+DEBUG_NO_SCAN_KERNEL, DEBUG_SCAN_READ_NOISE, DEBUG_SCAN_FULL_TILES = 32, 64, 128
 ABI_VERSION = 1
 
 

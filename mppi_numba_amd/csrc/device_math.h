@@ -250,6 +250,20 @@ __device__ __forceinline__ float wave_min_f32(float v) {
   const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
   return fminf(fminf(r0, r1), fminf(r2, r3));
 }
+// sum over the 64 lanes, result in lane 63 only (4 steps inside each row of 16 lanes, then row 0 -> 1,
+// 2 -> 3 and rows 0..1 -> 2..3 through row_bcast): 6 DPP additions, fixed order
+__device__ __forceinline__ float wave_sum_to_lane63_f32(float v) {
+  v += dpp_f32<kDppXor1>(v);
+  v += dpp_f32<kDppXor2>(v);
+  v += dpp_f32<kDppHalfMirror>(v);
+  v += dpp_f32<kDppMirror>(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));  // row_bcast:15
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));  // row_bcast:31
+  return v;
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {  // ... handed to every lane
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum_to_lane63_f32(v)), 63));
+}
 __device__ __forceinline__ double wave_sum_f64(double v) {
   v += dpp_f64<kDppXor1>(v);
   v += dpp_f64<kDppXor2>(v);

@@ -654,6 +654,10 @@ struct mppi_planner {
   // view of the same memory), solve() reads it after the stream has drained -- no copy on the hot path
   float2* u_host = nullptr;
   float2* u_host_dev = nullptr;
+  // Only solve() reads the mirror, after its LAST iteration: the update launches of every other
+  // iteration are spared the posted write across PCIe (their completion waits for it).
+  bool mirror_now = false;   // the coming update launch writes the mirror
+  bool mirror_done = false;  // ... the last one did
   // set_u(): pinned staging + asynchronous copy; the next set_u waits for the previous copy only
   float2* u_stage = nullptr;
   hipEvent_t ev_u_staged = nullptr;
@@ -697,8 +701,10 @@ struct mppi_planner {
   int n_tiles = 0;
   bool tile_packets_fresh = false;  // w_rel / tile_beta written by the rollout kernel for the current costs
   // k_rollout_scan (MPPI_MATH_FAST): per-tile sums of w_rel * noise, consumed by k_combine_tiles
-  float2* tnum = nullptr;  // [T][n_tiles]
-  float* tden = nullptr;   // [n_tiles]
+  float2* tnum = nullptr;  // [T][tiles]
+  float* tden = nullptr;   // [tiles]
+  float* tbeta = nullptr;  // [tiles] minimum cost of each of the kernel's tiles (32 or 64 rollouts)
+  int scan_tile = 32;      // rollouts per tile of the last such launch
   bool scan_packets_fresh = false;  // ... written by the last rollout launch for the current costs
   // the iteration loop of such a handle generates the noise INSIDE the rollout launch (Philox counter
   // blocks, never stored): noise_buf is then stale, and whoever wants the noise of the last iteration
@@ -803,6 +809,7 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   dev_free(p->tile_beta);
   dev_free(p->tnum);
   dev_free(p->tden);
+  dev_free(p->tbeta);
   dev_free(p->packets);
   dev_free(p->stats);
   dev_free(p->cells);
@@ -1137,6 +1144,10 @@ static DevParams make_dev_params(const mppi_planner* p, const mppi_tdm* lin, con
   d.inst_tiles = p->inst_tiles;
   d.n_inst = p->n_inst;
   d.spec_failures = p->spec_fail_dev;
+  d.cc_k0 = (float)((double)a.lambda_weight / d.s0sq);
+  d.cc_k1 = (float)((double)a.lambda_weight / d.s1sq);
+  d.inv_v_post_den = 1.0 / d.v_post_den;
+  d.neg_log2e_over_lambda = -1.4426950408889634 / (double)a.lambda_weight;
   return d;
 }
 
@@ -1410,11 +1421,12 @@ static int upload_instances(mppi_planner* p) {
 
 // ---- k_rollout_scan (rollout_scan_kernel.h): the time-parallel rollout of MPPI_MATH_FAST --------
 // Eligible: deterministic-dynamics mode, 16-bit cells (the reference's own maps always are), a horizon
-// of at most 16 chunks of 8 steps, LDS for the per-step records, and a map the speculation pays on.
+// of at most 16 waves of 8 steps, LDS for the per-step records, and a map the speculation pays on.
 struct ScanPlan {
-  int waves = 0;       // chunks of 8 steps = waves per workgroup
+  int waves = 0;       // 8 steps each = waves per workgroup
+  int tile = 32;       // rollouts per workgroup: 32 (two lanes per rollout) or 64
   size_t lds = 0;
-  bool pow2res = false, chain64 = true;
+  bool pow2res = false;
 };
 
 static bool scan_plan(const mppi_planner* p, ScanPlan* out) {
@@ -1427,8 +1439,10 @@ static bool scan_plan(const mppi_planner* p, ScanPlan* out) {
   ScanPlan plan;
   plan.waves = ceil_div(T, 8);
   if (plan.waves > 16) return false;
-  plan.chain64 = !(p->debug_flags & MPPI_DEBUG_SCAN_CHAIN32);
-  plan.lds = plan.chain64 ? ScanLds<8, true>::total(plan.waves) : ScanLds<8, false>::total(plan.waves);
+  plan.tile = (p->debug_flags & MPPI_DEBUG_SCAN_FULL_TILES) ? 64 : 32;
+  plan.lds = plan.tile == 64 ? ScanLds<64>::total(plan.waves) : ScanLds<32>::total(plan.waves);
+  // (the accumulating wave reads up to two groups of records past the last one: keep that inside the allocation)
+  plan.lds = std::max(plan.lds, (size_t)40 * 1024);
   if (plan.lds > (size_t)p->lds_per_cu - 1024) return false;
   int res_exp = 0;
   plan.pow2res = std::frexp((double)p->params.res, &res_exp) == 0.5;  // res == 2^k exactly
@@ -1439,8 +1453,8 @@ static bool scan_plan(const mppi_planner* p, ScanPlan* out) {
 // the iteration loop may let the rollout launch generate its own noise: Philox counters only
 static bool scan_generates_noise(const mppi_planner* p) {
   static const bool disabled = getenv("MPPI_SCAN_READ_NOISE") != nullptr;  // developer switch (ablation)
-  return !disabled && !(p->debug_flags & (MPPI_DEBUG_SCAN_READ_NOISE | MPPI_DEBUG_SCAN_ROWS_UPDATE)) &&
-         p->cfg.rng == MPPI_RNG_PHILOX && scan_plan(p, nullptr);
+  return !disabled && !(p->debug_flags & MPPI_DEBUG_SCAN_READ_NOISE) && p->cfg.rng == MPPI_RNG_PHILOX &&
+         scan_plan(p, nullptr);
 }
 
 // the noise of the last iteration into noise_buf when it exists as counters only
@@ -1465,16 +1479,18 @@ static int materialize_noise(mppi_planner* p) {
 
 static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan) {
   const int N = p->n_local, T = p->cfg.num_steps;
-  const int tiles = ceil_div(N, 64);
-  if (!p->tnum) {
-    TRY(dev_alloc(&p->tnum, (size_t)T * (size_t)tiles));
-    TRY(dev_alloc(&p->tden, (size_t)tiles));
+  const int tiles = ceil_div(N, plan.tile);
+  if (!p->tnum) {  // (sized for the smaller tile)
+    const size_t cap = (size_t)ceil_div(N, 32);
+    TRY(dev_alloc(&p->tnum, (size_t)T * cap));
+    TRY(dev_alloc(&p->tden, cap));
+    TRY(dev_alloc(&p->tbeta, cap));
   }
   const bool gen = p->scan_gen_now;
-  const bool rows_update = (p->debug_flags & MPPI_DEBUG_SCAN_ROWS_UPDATE) != 0;  // k_update_rows reads the noise
   ScanPackets pk;
-  pk.tnum = rows_update ? nullptr : p->tnum;
+  pk.tnum = p->tnum;
   pk.tden = p->tden;
+  pk.tbeta = p->tbeta;
   pk.n_tiles = tiles;
   NoiseJob gen_job, next_job;
   memset(&gen_job, 0, sizeof(gen_job));
@@ -1491,35 +1507,35 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
     }
   }
   p->spec_tiles_launched += (uint64_t)tiles;
-#define MPPI_LAUNCH_SCAN(P2, GEN, C64)                                                                     \
+#define MPPI_LAUNCH_SCAN(RR, P2, GEN)                                                                      \
   do {                                                                                                    \
-    auto kern = k_rollout_scan<8, P2, GEN, C64>;                                                          \
+    auto kern = k_rollout_scan<RR, P2, GEN>;                                                              \
     if (plan.lds > 64 * 1024)                                                                             \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));            \
     MPPI_KLAUNCH(kern, dim3(tiles + extra), dim3(64 * plan.waves), plan.lds, p->stream, d, p->cells16,    \
-                 p->noise, gen_job, p->u, p->costs, p->w_rel, p->tile_beta, pk, tiles, next_job);          \
+                 p->noise, gen_job, p->u, p->costs, p->w_rel, pk, tiles, next_job);                        \
   } while (0)
-#define MPPI_LAUNCH_SCAN_G(P2, C64)               \
-  do {                                            \
-    if (gen) MPPI_LAUNCH_SCAN(P2, true, C64);     \
-    else MPPI_LAUNCH_SCAN(P2, false, C64);        \
+#define MPPI_LAUNCH_SCAN_G(RR, P2)               \
+  do {                                           \
+    if (gen) MPPI_LAUNCH_SCAN(RR, P2, true);     \
+    else MPPI_LAUNCH_SCAN(RR, P2, false);        \
   } while (0)
-  if (plan.pow2res && plan.chain64) MPPI_LAUNCH_SCAN_G(true, true);
-  else if (plan.pow2res) MPPI_LAUNCH_SCAN_G(true, false);
-  else if (plan.chain64) MPPI_LAUNCH_SCAN_G(false, true);
-  else MPPI_LAUNCH_SCAN_G(false, false);
+  if (plan.tile == 64 && plan.pow2res) MPPI_LAUNCH_SCAN_G(64, true);
+  else if (plan.tile == 64) MPPI_LAUNCH_SCAN_G(64, false);
+  else if (plan.pow2res) MPPI_LAUNCH_SCAN_G(32, true);
+  else MPPI_LAUNCH_SCAN_G(32, false);
 #undef MPPI_LAUNCH_SCAN_G
 #undef MPPI_LAUNCH_SCAN
   HIP_TRY(hipGetLastError());
   char buf[256];
   snprintf(buf, sizeof(buf),
-           "k_rollout_scan chunk=8 waves=%d pow2res=%d noise=%s chain=%s update=%s lds=%zu noise_blocks=%d problems=%d",
-           plan.waves, (int)plan.pow2res, gen ? "in-kernel" : "read", plan.chain64 ? "f64" : "f32",
-           rows_update ? "rows" : "tile-packets", plan.lds, extra, p->inst_set ? p->B : 0);
+           "k_rollout_scan tile=%d waves=%d pow2res=%d noise=%s lds=%zu noise_blocks=%d problems=%d",
+           plan.tile, plan.waves, (int)plan.pow2res, gen ? "in-kernel" : "read", plan.lds, extra, p->inst_set ? p->B : 0);
   p->last_rollout = buf;
-  p->tile_packets_fresh = true;
-  p->scan_packets_fresh = !rows_update;
+  p->tile_packets_fresh = false;  // (w_rel is relative to this kernel's own tiles: tbeta, not tile_beta)
+  p->scan_packets_fresh = true;
+  p->scan_tile = plan.tile;
   p->noise_virtual = gen;
   return MPPI_OK;
 }
@@ -2010,13 +2026,14 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
     p->tile_packets_fresh = false;
     const dim3 grid(T, p->B);
     unsigned long long* gen = p->graph_on ? p->gen_dev : (unsigned long long*)nullptr;
+    const int per_problem = ceil_div(p->n_inst, p->scan_tile), total = ceil_div(p->n_local, p->scan_tile);
     if (apply_here)
-      MPPI_KLAUNCH((k_combine_tiles<true>), grid, dim3(64), 0, p->stream, p->tile_beta, p->tden, p->tnum, p->inst_tiles,
-                   p->n_tiles, T, a.lambda_weight, my_packet, p->u, p->u_prev, p->u_host_dev, a.vrange[0], a.vrange[1],
+      MPPI_KLAUNCH((k_combine_tiles<true>), grid, dim3(64), 0, p->stream, p->tbeta, p->tden, p->tnum, per_problem, total,
+                   T, a.lambda_weight, my_packet, p->u, p->u_prev, (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0], a.vrange[1],
                    a.wrange[0], a.wrange[1], p->stats, gen);
     else
-      MPPI_KLAUNCH((k_combine_tiles<false>), grid, dim3(64), 0, p->stream, p->tile_beta, p->tden, p->tnum, p->inst_tiles,
-                   p->n_tiles, T, a.lambda_weight, my_packet, p->u, p->u_prev, p->u_host_dev, a.vrange[0], a.vrange[1],
+      MPPI_KLAUNCH((k_combine_tiles<false>), grid, dim3(64), 0, p->stream, p->tbeta, p->tden, p->tnum, per_problem, total,
+                   T, a.lambda_weight, my_packet, p->u, p->u_prev, (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0], a.vrange[1],
                    a.wrange[0], a.wrange[1], p->stats, gen);
     if (p->graph_on) ++p->bumps_launched;
     HIP_TRY(hipGetLastError());
@@ -2038,7 +2055,7 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
 #define MPPI_LAUNCH_ROWS(APPLY, TC, FC)                                                                         \
   MPPI_KLAUNCH((k_update_rows<APPLY, TC, FC>), grid, dim3(kRowThreads), lds, p->stream,                   \
                      FC ? p->costs : p->w_rel, p->tile_beta, p->n_inst, p->inst_tiles, p->noise, T,             \
-                     a.lambda_weight, my_packet, p->u, p->u_prev, p->u_host_dev, a.vrange[0], a.vrange[1],      \
+                     a.lambda_weight, my_packet, p->u, p->u_prev, (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0], a.vrange[1],      \
                      a.wrange[0], a.wrange[1], p->stats, p->graph_on ? p->gen_dev : (unsigned long long*)nullptr)
 #define MPPI_LAUNCH_ROWS_TC(APPLY, FC)        \
   do {                                        \
@@ -2059,7 +2076,7 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
 static int launch_apply(mppi_planner* p) {
   const mppi_params& a = p->params;
   hipLaunchKernelGGL(k_apply, dim3(p->B), dim3(kUpdateThreads), 0, p->stream, p->packets, p->cfg.world_size,
-                     p->cfg.rank, p->cfg.num_steps, a.lambda_weight, p->u, p->u_prev, p->u_host_dev, a.vrange[0],
+                     p->cfg.rank, p->cfg.num_steps, a.lambda_weight, p->u, p->u_prev, (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0],
                      a.vrange[1], a.wrange[0], a.wrange[1], p->stats);
   HIP_TRY(hipGetLastError());
   return MPPI_OK;
@@ -2068,6 +2085,7 @@ static int launch_apply(mppi_planner* p) {
 // `defer_exchange` (mppi_group_iterate_async): stop after this rank's packet; the caller issues the
 // all-gathers of all its devices inside one RCCL group and then launches k_apply on each
 static int launch_update(mppi_planner* p, bool prof, bool defer_exchange = false) {
+  p->mirror_done = p->mirror_now;
   if (defer_exchange) return launch_update_local(p, false);
   // (a communicator on a single rank is honoured too: it exercises the same path as N ranks)
   // (samples sharded: every rank holds all N costs and all the noise -- the update is local)
@@ -2218,7 +2236,8 @@ static void review_speculation(mppi_planner* p) {
   p->spec_tiles_launched = 0;
 }
 
-static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int iterations, bool timed = true) {
+static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int iterations, bool timed = true,
+                          bool mirror_last = false) {
   REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
   TRY(check_tdms(p, lin, ang));
   TRY(ensure_packed(p, lin, ang));
@@ -2239,7 +2258,10 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
     for (int k = 0; k < iterations; ++k) {
       // profiled iteration: a steady-state one when there is one, else the last
       bool prof = p->profile_stages && k == (iterations >= 3 ? iterations - 2 : iterations - 1);
-      TRY(launch_iteration(p, d, have_noise, true, prof));
+      p->mirror_now = mirror_last && k == iterations - 1;
+      const int rc = launch_iteration(p, d, have_noise, true, prof);
+      p->mirror_now = false;
+      TRY(rc);
     }
     p->primed = have_noise;
   } else {
@@ -2363,10 +2385,13 @@ extern "C" int mppi_planner_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang,
   TraceRange tr("mppi:solve");
   TRY(check_tdms(p, lin, ang));
   TRY(sample_for_solve(p, lin, ang));
-  TRY(run_iterations(p, lin, ang, p->params.num_opt, /*timed=*/false));
+  p->mirror_done = false;
+  TRY(run_iterations(p, lin, ang, p->params.num_opt, /*timed=*/false, /*mirror_last=*/true));
   const size_t u_bytes = sizeof(float2) * (size_t)p->B * (size_t)p->cfg.num_steps;
-  // with at least one iteration the last update kernel has written the host-mapped mirror
-  if (p->params.num_opt < 1) HIP_TRY(hipMemcpyAsync(p->u_host, p->u, u_bytes, hipMemcpyDeviceToHost, p->stream));
+  // with at least one iteration the last update kernel has written the host-mapped mirror (a
+  // replayed graph has not: its launches are the loop's ordinary ones)
+  if (p->params.num_opt < 1 || !p->mirror_done)
+    HIP_TRY(hipMemcpyAsync(p->u_host, p->u, u_bytes, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   review_speculation(p);
   memcpy(u_out, p->u_host, u_bytes);

@@ -74,6 +74,10 @@ struct DevParams {
   // host looks at when it synchronises anyway: a map on which speculation does not pay gets the
   // exact pipelined kernel from then on), or nullptr
   unsigned int* spec_failures;
+  // k_rollout_scan: host-side quotients (float64 divisions off the device)
+  float cc_k0, cc_k1;              // lambda / u_std^2
+  double inv_v_post_den;           // 1 / (v_post_rollout + 1e-6)
+  double neg_log2e_over_lambda;    // -log2(e) / lambda
 };
 
 // What differs between the problems of a batched handle (mppi_planner_set_instances).

@@ -36,7 +36,7 @@ __device__ __forceinline__ void apply_update(float2* u, float2* u_prev, float2* 
   ut.y = clip_f32(ut.y + (float)(ny / den), w_lo, w_hi);
   u[t] = ut;
   u_prev[t] = ut;
-  u_mirror[t] = ut;
+  if (u_mirror) u_mirror[t] = ut;
 }
 
 // ---- stage 1: weights relative to the minimum of each tile of 64 rollouts ----------
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
     rank_packet += (size_t)inst * packet_len(n_steps);
     u += (size_t)inst * n_steps;
     u_prev += (size_t)inst * n_steps;
-    u_mirror += (size_t)inst * n_steps;
+    if (u_mirror) u_mirror += (size_t)inst * n_steps;
     stats += 2 * inst;
   }
   [[maybe_unused]] const bool stamp_wg = blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && threadIdx.x == 0;
@@ -263,39 +263,60 @@ __global__ __launch_bounds__(64) void k_combine_tiles(const float* __restrict__ 
                                                       unsigned long long* __restrict__ gen_counter) {
   if (gen_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *gen_counter += 1ull;
   const int t = blockIdx.x, inst = blockIdx.y, lane = threadIdx.x;
+  [[maybe_unused]] const bool stamp_wg = (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && blockIdx.y == 0;
+  [[maybe_unused]] const int stamp_base = blockIdx.x == 0 ? 520 : 528;
+  MPPI_STAMP(stamp_wg, stamp_base + 0);
   tile_beta += (size_t)inst * n_tiles;
   tden += (size_t)inst * n_tiles;
   tnum += (size_t)t * total_tiles + (size_t)inst * n_tiles;
   rank_packet += (size_t)inst * packet_len(n_steps);
   u += (size_t)inst * n_steps;
   u_prev += (size_t)inst * n_steps;
-  u_mirror += (size_t)inst * n_steps;
+  if (u_mirror) u_mirror += (size_t)inst * n_steps;
   stats += 2 * inst;
-  // two tiles per lane cover N = 8192 in one batch of loads; more go round the loop
-  const int g0 = lane, g1 = lane + 64;
-  const float b0 = g0 < n_tiles ? tile_beta[g0] : __builtin_inff(), b1 = g1 < n_tiles ? tile_beta[g1] : __builtin_inff();
-  const float d0 = g0 < n_tiles ? tden[g0] : 0.0f, d1 = g1 < n_tiles ? tden[g1] : 0.0f;
-  const float2 m0 = g0 < n_tiles ? tnum[g0] : make_float2(0.0f, 0.0f), m1 = g1 < n_tiles ? tnum[g1] : make_float2(0.0f, 0.0f);
-  float b = fminf(b0, b1);
-  for (int g = lane + 128; g < n_tiles; g += 64) b = fminf(b, tile_beta[g]);
-  const float beta = wave_min_f32(b);
-  const double neg_inv_lambda = -1.0 / (double)lambda;
+  // four tiles per lane cover N = 8192 (256 tiles of 32 rollouts) in one batch of loads; more go
+  // round the loop.  Everything is requested before anything is waited for.
+  constexpr int U = 4;
+  float b[U], d[U];
+  float2 m[U];
+#pragma unroll
+  for (int q = 0; q < U; ++q) {
+    const int g = lane + 64 * q;
+    const bool in = g < n_tiles;
+    b[q] = in ? tile_beta[g] : __builtin_inff();
+    d[q] = in ? tden[g] : 0.0f;
+    m[q] = in ? tnum[g] : make_float2(0.0f, 0.0f);
+  }
+  const float2 u_old = APPLY ? u[t] : make_float2(0.0f, 0.0f);
+  float bm = fminf(fminf(b[0], b[1]), fminf(b[2], b[3]));
+  for (int g = lane + 64 * U; g < n_tiles; g += 64) bm = fminf(bm, tile_beta[g]);
+  MPPI_STAMP(stamp_wg, stamp_base + 1);
+  const float beta = wave_min_f32(bm);
+  MPPI_STAMP(stamp_wg, stamp_base + 2);
+  // exp(-(beta_tile - beta)/lambda) through v_exp_f32: the argument is an exact float32 difference
+  const float scale = -1.4426950408889634f / lambda;
   double den = 0.0, nx = 0.0, ny = 0.0;
   auto take = [&](float tb, float td, float2 tn) {
-    const double s = (double)(float)exp(neg_inv_lambda * (double)(tb - beta));
+    const double s = (double)__builtin_amdgcn_exp2f((tb - beta) * scale);
     den = fma(s, (double)td, den);
     nx = fma(s, (double)tn.x, nx);
     ny = fma(s, (double)tn.y, ny);
   };
-  if (g0 < n_tiles) take(b0, d0, m0);
-  if (g1 < n_tiles) take(b1, d1, m1);
-  for (int g = lane + 128; g < n_tiles; g += 64) take(tile_beta[g], tden[g], tnum[g]);
+#pragma unroll
+  for (int q = 0; q < U; ++q) take(b[q] == __builtin_inff() ? beta : b[q], d[q], m[q]);
+  for (int g = lane + 64 * U; g < n_tiles; g += 64) take(tile_beta[g], tden[g], tnum[g]);
   den = wave_sum_f64(den);
   nx = wave_sum_f64(nx);
   ny = wave_sum_f64(ny);
+  MPPI_STAMP(stamp_wg, stamp_base + 3);
   if (lane == 0) {
     if (APPLY) {
-      apply_update(u, u_prev, u_mirror, t, nx, ny, den, v_lo, v_hi, w_lo, w_hi);
+      float2 ut = u_old;
+      ut.x = clip_f32(ut.x + (float)(nx / den), v_lo, v_hi);
+      ut.y = clip_f32(ut.y + (float)(ny / den), w_lo, w_hi);
+      u[t] = ut;
+      u_prev[t] = ut;
+      if (u_mirror) u_mirror[t] = ut;
     } else {
       rank_packet[2 + 2 * t] = nx;
       rank_packet[3 + 2 * t] = ny;
@@ -307,6 +328,7 @@ __global__ __launch_bounds__(64) void k_combine_tiles(const float* __restrict__ 
       stats[1] = den;
     }
   }
+  MPPI_STAMP(stamp_wg, stamp_base + 4);
 }
 
 // combine the packets of all ranks (identical on every GPU, fixed g order).
@@ -321,7 +343,7 @@ __global__ __launch_bounds__(kUpdateThreads) void k_apply(const double* __restri
   packets += (size_t)blockIdx.x * len;
   u += (size_t)blockIdx.x * n_steps;
   u_prev += (size_t)blockIdx.x * n_steps;
-  u_mirror += (size_t)blockIdx.x * n_steps;
+  if (u_mirror) u_mirror += (size_t)blockIdx.x * n_steps;
   stats += 2 * blockIdx.x;
   double beta = packets[0];
   for (int g = 1; g < world; ++g) beta = fmin(beta, packets[g * stride]);

@@ -96,7 +96,9 @@ def test_fast_math_runs_the_float32_pipeline_within_the_north_star_tolerance():
     without float64 intermediates.  Held to north_star's own bar against the oracle (the exact
     path is bit-identical; this one is an opt-in whose cost in accuracy and gain in time
     DESIGN.md section 4 reports: ~1.5 % faster, i.e. the float64 roundings are NOT what bounds C2)."""
+    from mppi_numba_amd import _lib
     w, cfg, lin, ang, planner, params = build("c2", 8192, math="fast")
+    planner.set_debug_flags(_lib.DEBUG_NO_SCAN_KERNEL)  # (the default fast-math kernel: tests/test_gpu_scan.py)
     planner.solve()
     planner.sample_noise()
     noise = planner.noise_samples_d.copy_to_host()
@@ -114,6 +116,7 @@ def test_fast_math_runs_the_float32_pipeline_within_the_north_star_tolerance():
     assert (np.abs(u_out - u_ref) / span).max() <= 1e-5
     # a map whose traction changes from cell to cell: the vote fails, the tile re-runs exact
     w, cfg, lin, ang, planner, params = build("c4", 8192, math="fast")
+    planner.set_debug_flags(_lib.DEBUG_NO_SCAN_KERNEL)
     planner.solve()
     planner.sample_noise()
     noise = planner.noise_samples_d.copy_to_host()

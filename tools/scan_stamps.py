@@ -6,7 +6,7 @@
 
 Workgroup 5: per wave (chunk) the cycles, from the workgroup's first stamp, at which it entered the
 kernel (0), had its noise and controls (1), reached barrier 1 (2), barrier 2 (3), had its stage costs
-(4), reached barrier 3 (5), barrier 4 (6); wave 0 also: costs written (7); every wave: end (8)."""
+(4), reached barrier 3 (5), barrier 4 (6); wave 0 also: costs written (7); every wave: end (8); wave 0: stage additions done (9), frozen steps done (10), weights written (11)."""
 import argparse
 import contextlib
 import ctypes as C
@@ -41,12 +41,22 @@ def main():
         _lib.call("mppi_debug_read_stamps", buf, 4096, 1)
         st = np.array(buf[:], dtype=np.uint64).astype(np.int64)
     print(planner.last_rollout_kernel())
-    rows = [st[64 + 16 * c: 64 + 16 * c + 9] for c in range(16)]
+    rows = [st[64 + 16 * c: 64 + 16 * c + 12] for c in range(16)]
     t0 = min(int(r[0]) for r in rows if r[0])
-    print("chunk  " + "".join("%8d" % k for k in range(9)))
+    print("chunk  " + "".join("%8d" % k for k in range(12)))
     for c, r in enumerate(rows):
         if r[0]:
             print("%5d  " % c + "".join("%8s" % (int(v - t0) if v else "-") for v in r))
+    # every workgroup's entry / exit (slots 2048 + 2 b, 2049 + 2 b) when the kernel records them
+    ent, ext = st[2048:2048 + 1024:2], st[2049:2049 + 1024:2]
+    if ent.any():
+        e0 = ent[ent > 0].min()
+        print("workgroup entries: first %d last %d; exits: first %d last %d (cycles from the first entry)" % (
+            0, int(ent.max() - e0), int(ext[ext > 0].min() - e0), int(ext.max() - e0)))
+        t0 = e0
+    print("k_combine_tiles, first / last workgroup: entry, loads back, minimum, sums, end (cycles from the rollout workgroup's first stamp)")
+    for base in (520, 528):
+        print("   ", [int(v - t0) if v else None for v in st[base:base + 5]])
 
 
 if __name__ == "__main__":
