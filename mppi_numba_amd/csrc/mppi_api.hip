@@ -710,7 +710,8 @@ struct mppi_planner {
   // blocks, never stored): noise_buf is then stale, and whoever wants the noise of the last iteration
   // (get_noise, get_state_rollout, a stage-level update) has it regenerated from the same counters
   bool scan_gen_now = false;   // the coming rollout launch is to generate its own noise
-  bool noise_virtual = false;  // the noise of the last iteration exists as counters only (epoch noise_epoch - 1)
+  bool noise_virtual = false;  // the noise of the last iteration exists as counters only ...
+  int noise_virtual_back = 1;  // ... of Philox epoch noise_epoch - noise_virtual_back
   double* packets = nullptr;  // [world][2+2T]; own packet at [rank]
   double* stats = nullptr;    // {beta, den} of the last update
   uint32_t* cells = nullptr;
@@ -1464,7 +1465,7 @@ static int materialize_noise(mppi_planner* p) {
   memset(&j, 0, sizeof(j));
   j.out = p->noise;
   j.seed = p->cfg.seed;
-  j.epoch = p->noise_epoch - 1;  // the block the last rollout launch consumed
+  j.epoch = p->noise_epoch - (uint64_t)p->noise_virtual_back;  // the block the last rollout launch consumed
   j.n_local = p->n_local;
   j.n_offset = p->n_offset;
   j.n_steps = p->cfg.num_steps;
@@ -1499,8 +1500,12 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
   if (gen) {
     gen_job = make_noise_job(p, nullptr);  // (advances the Philox epoch: this iteration's block)
   } else {
+    // a loop that stores its noise (debug switch; the stage-level calls): CUs without a workgroup
+    // produce the next iteration's, as in k_rollout_deep.  (Producing it in the launch's own tail, by
+    // the waves that idle while one wave accumulates the costs, was measured: the stage gained is lost
+    // again to the slower accumulation and the noise reads -- profiles/r03_scan_notes.md.)
     static const bool no_fused_noise = getenv("MPPI_NO_FUSED_NOISE") != nullptr;  // developer switch
-    if (p->next_noise_wanted && tiles < p->num_cus && !no_fused_noise) {  // spare CUs: the next iteration's noise
+    if (p->next_noise_wanted && tiles < p->num_cus && !no_fused_noise && p->cfg.rng == MPPI_RNG_PHILOX) {
       extra = p->num_cus - tiles;
       next_job = make_noise_job(p, p->noise_buf[p->noise_cur ^ 1]);
       p->next_noise_done = true;
@@ -1537,6 +1542,7 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
   p->scan_packets_fresh = true;
   p->scan_tile = plan.tile;
   p->noise_virtual = gen;
+  p->noise_virtual_back = 1 + (next_job.out ? 1 : 0);  // (the launch may have produced its successor's block too)
   return MPPI_OK;
 }
 

@@ -391,6 +391,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
 
   // ---------------------------------------------------------------- E: the accumulation, in order
   if (c == 0) {
+    __builtin_amdgcn_s_setprio(3);  // (the critical path of the launch from here on)
     // (R = 32: lanes 32..63 mirror lanes 0..31)
     const bool failed = flags[0] != 0u;
     float cost = 0.0f;

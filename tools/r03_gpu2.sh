@@ -8,7 +8,7 @@ timeout 900 python -m pytest tests/test_gpu_scan.py -q -s -p no:cacheprovider > 
 echo "pytest scan rc=$?"; tail -3 $OUT/pytest_scan.log
 timeout 1200 python -m pytest tests -m gpu -q -x -p no:cacheprovider --deselect tests/test_gpu_scan.py > $OUT/pytest_all.log 2>&1
 echo "pytest all rc=$?"; tail -3 $OUT/pytest_all.log
-for f in 0 64 128; do
+for f in 0 256 64 128; do
   timeout 300 python bench.py --math fast --steps 200 --warmup 20 --no-cpu-baseline --debug-flags $f > $OUT/bench_fast_$f.json 2> $OUT/bench_fast_$f.err
   python - <<PY
 import json
