@@ -130,15 +130,20 @@ def batch_problems(count, rng):
     return x0s, goals
 
 
-def algorithmic_bytes(w, n, rp, cp, rollout_writes_noise=True):
+def algorithmic_bytes(w, n, rp, cp, rollout_writes_noise=True, fused=False):
     """SURVEY.md section 8d.  Returns (bytes per iteration, bytes per rollout-kernel launch).
     Rollout launch, det mode: 8 (noise read) + 4 (map bytes) per rollout-step, + 8 (noise
     write) when it is the pipelined kernel, whose spare workgroups also produce the noise of
-    the following iteration."""
+    the following iteration.  `fused` (k_rollout_scan with in-launch noise): the launch does the
+    noise sampling, the rollout AND the update's pass over the noise -- all 28 bytes per
+    rollout-step of the reference's dataflow -- without the noise ever existing in memory; it is
+    priced against the same formula, as SURVEY.md 8d prescribes for a fused implementation."""
     t, m = w["t"], w["m"]
     if m == 1:
         it = n * t * 28 + n * 16 + 32 * t + 4 * rp * cp
         roll = n * t * (8 + 4 + (8 if rollout_writes_noise else 0)) + n * 4 + 8 * t + 4 * rp * cp
+        if fused:
+            roll = n * t * 28 + n * 8 + 8 * t + 4 * rp * cp
     else:
         it = 4 * n * m * t + 24 * n * t + 16 * n + 2 * m * rp * cp
         roll = 4 * n * m * t + 8 * n * t + 4 * n + 2 * m * rp * cp
@@ -212,8 +217,10 @@ def parity_margin(w, p, P, grids, planner):
     want = (O.rollout_det if w["m"] == 1 else O.rollout_tdm)(p, *grids, noise, u_in)
     _, u_ref, _ = O.update_useq(P["lambda_weight"], want, noise, P["vrange"], P["wrange"], u_in)
     span = np.array([P["vrange"][1] - P["vrange"][0], P["wrange"][1] - P["wrange"][0]])
+    rel = np.abs(got - want) / np.abs(want)
     return dict(costs_bit_identical=float((got.view(np.int32) == want.view(np.int32)).mean()),
-                costs_max_rel=float((np.abs(got - want) / np.abs(want)).max()),
+                costs_max_rel=float(rel.max()), costs_rel_q999=float(np.quantile(rel, 0.999)),
+                costs_within_1e6=float((rel <= 1e-6).mean()),
                 u_max_abs_over_range=float((np.abs(u_out - u_ref) / span).max()), u_bound=1e-5)
 
 
@@ -406,10 +413,16 @@ def main():
     t0 = time.perf_counter()
     runner.iterate_async(args.steps)
     runner.synchronize()
+    # every rank stops its own clock when ITS stream has drained; the slowest rank's time is the
+    # job's.  (The closing barrier -- a star of TCP messages through rank 0 -- is NOT inside the
+    # timed region: at 8 ranks it would be a visible share of a 0.5 ms run.  The ranks are already
+    # coupled by the all-gather of every iteration.)
+    own_elapsed = time.perf_counter() - t0
     barrier()
-    elapsed = time.perf_counter() - t0
+    closing_barrier_s = time.perf_counter() - t0 - own_elapsed
     gpu_ms = planner.last_elapsed_ms()
-    elapsed = hub.all_max(elapsed)
+    per_rank = hub.all_gather(own_elapsed) if world > 1 else [own_elapsed]
+    elapsed = max(per_rank)
     ms_per_step = 1e3 * elapsed / args.steps
     rollouts_per_step = (problems * n_local * world) if problems else n_global
     if by_samples:
@@ -432,8 +445,9 @@ def main():
     # the dominant kernels inside the ordinary loop: every launch carries its own start / stop HIP
     # events, which the runtime fills with the dispatch's begin / end timestamps (what rocprofv3
     # --kernel-trace reports); nothing is inserted between the kernels
+    # (every rank runs it: with RCCL the iterations it times contain the all-gather, a collective)
     kernel_us = None
-    if world == 1 and group_size == 1 and not args.graph:
+    if group_size == 1 and not args.graph and not (world > 1 and args.exchange == "host" and not problems):
         kernel_us = planner.time_kernels(200)
 
     if rank != 0:
@@ -442,12 +456,15 @@ def main():
         return
 
     kernel_name = planner.last_rollout_kernel().split(" ")[0]
+    fused = kernel_name == "k_rollout_scan" and "noise=in-kernel" in planner.last_rollout_kernel()
     bytes_iter, bytes_roll = algorithmic_bytes(w, n_local * max(1, problems), rp, cp,
-                                               rollout_writes_noise=(kernel_name in ("k_rollout_pipe", "k_rollout_spec", "k_rollout_deep")))
+                                               rollout_writes_noise=(kernel_name in ("k_rollout_pipe", "k_rollout_spec", "k_rollout_deep")),
+                                               fused=fused)
     traffic = None
     try:  # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-            traffic = json.load(fh).get(args.workload, {}).get("dominant_kernel_hbm_bytes_per_launch")
+            key = args.workload + ("_fast" if args.math == "fast" else "")
+            traffic = json.load(fh).get(key, {}).get("dominant_kernel_hbm_bytes_per_launch")
     except (OSError, ValueError):
         pass
     roll_s = kernel_us[0] * 1e-6 if kernel_us else stage["rollout"] * 1e-3
@@ -457,7 +474,7 @@ def main():
         "value": value, "unit": "rollouts/s", "n_gpus": world * group_size, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f64 intermediates / f32 state (the reference CPU path's roundings)"
-        if args.math == "exact" else "f32",
+        if args.math == "exact" else "f32 (tolerance mode: float64 only across chunk sums; costs accumulated in the reference's order)",
         "data": "synthetic",
         "config": {"workload": w["label"], "rollouts_per_gpu": n_local, "global_rollouts": n_global,
                    "horizon_steps": t_steps, "traction_samples": m_global, "traction_samples_per_gpu": m,
@@ -480,6 +497,10 @@ def main():
                                                              if "MPPI_RDZV_FILE" not in os.environ else
                                                              "started by bench.py itself")) if world > 1 else "single process"},
         "gpu_ms_per_step_events": gpu_ms / args.steps,
+        "ms_per_step_per_rank": [1e3 * e / args.steps for e in per_rank],
+        "closing_barrier_ms": 1e3 * closing_barrier_s,
+        "timing_note": "ms_per_step = the slowest rank's wall time of its own K steps (stream drained), over K; the closing "
+                       "barrier is outside the timed region and reported beside it",
         "kernel_ms": stage,
         "kernel_ms_note": "each stage of ONE iteration bracketed by its own HIP events on the planner's stream; every "
                           "bracket adds ~3 us of event overhead, so the stages sum to more than ms_per_step (which has "
@@ -490,7 +511,12 @@ def main():
                     "(hipExtLaunchKernelGGL: the dispatch's begin / end timestamps, as rocprofv3 --kernel-trace "
                     "reports them; averages agree with profiles/)"},
         "roofline": {"bound": "hbm",
-                     "kernel": kernel_name + (" (rollout + next iteration's noise)" if kernel_name in ("k_rollout_pipe", "k_rollout_spec", "k_rollout_deep") else ""),
+                     "kernel": kernel_name + (" (rollout + next iteration's noise)" if kernel_name in ("k_rollout_pipe", "k_rollout_spec", "k_rollout_deep") else
+                                              " (noise + rollout + per-tile update sums)" if fused else ""),
+                     "fused": fused,
+                     "fused_note": ("the launch samples the noise, rolls out and reduces the update per tile; the noise never "
+                                    "exists in memory, so `traffic` is a small fraction of `algorithmic_bytes_per_launch` and "
+                                    "the kernel is bound by instruction issue (Philox blocks: half of it), not by HBM") if fused else None,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "

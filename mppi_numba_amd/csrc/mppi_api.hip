@@ -769,6 +769,9 @@ struct mppi_planner {
   // this handle rolls ALL N control samples over its cfg.num_grid_samples grids; the per-(n, m)
   // costs of all shards are all-gathered and every rank forms the CVaR of every control sample
   int m_rank = 0, m_count = 1;
+  // a stage-level rollout of such a handle leaves the CVaR over the LOCAL samples in costs: the update
+  // must not run before the slabs of all shards have been reduced (launch_cvar_reduce)
+  bool sample_costs_local_only = false;
   float* slabs = nullptr;  // [m_count][n_local][M_local]
   // closed loop on the device (mppi_planner_closed_loop): world state, trajectory log
   double* loop_state = nullptr;   // [B][3]
@@ -2008,6 +2011,7 @@ static int launch_cvar_reduce(mppi_planner* p) {
                      p->params.cvar_alpha, p->costs, p->want_sample_costs ? p->sample_costs : (float*)nullptr, mp2);
   HIP_TRY(hipGetLastError());
   p->tile_packets_fresh = false;
+  p->sample_costs_local_only = false;
   return MPPI_OK;
 }
 
@@ -2692,6 +2696,13 @@ extern "C" int mppi_planner_rollout(mppi_planner* p, mppi_tdm* lin, mppi_tdm* an
   TRY(ensure_packed(p, lin, ang));
   DevParams d = make_dev_params(p, lin, ang);
   TRY(launch_rollout(p, d));
+  if (p->m_count > 1) {
+    // samples sharded over ranks: with a communicator the slabs are exchanged and reduced here, as
+    // inside the iteration loop; without one the caller owes sample_costs_local / sample_costs_apply
+    // before any update (the costs hold the CVaR over this rank's samples only)
+    if (p->comm) TRY(exchange_sample_costs(p));
+    else p->sample_costs_local_only = true;
+  }
   HIP_TRY(hipStreamSynchronize(p->stream));
   return MPPI_OK;
 }
@@ -2702,6 +2713,7 @@ extern "C" int mppi_planner_set_costs(mppi_planner* p, const float* costs) {
   HIP_TRY(hipMemcpyAsync(p->costs, costs, sizeof(float) * (size_t)p->n_local, hipMemcpyHostToDevice, p->stream));
   p->tile_packets_fresh = false;
   p->scan_packets_fresh = false;
+  p->sample_costs_local_only = false;
   HIP_TRY(hipStreamSynchronize(p->stream));
   return MPPI_OK;
 }
@@ -2772,6 +2784,9 @@ extern "C" int mppi_planner_sample_costs_apply(mppi_planner* p, const float* sla
 extern "C" int mppi_planner_update(mppi_planner* p) {
   REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
   REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
+  REQUIRE(!p->sample_costs_local_only, MPPI_ERR_STATE,
+          "samples sharded over %d ranks: the costs of the last rollout cover this rank's samples only -- exchange "
+          "them first (mppi_planner_sample_costs_local / _apply, or a communicator)", p->m_count);
   HIP_TRY(hipSetDevice(p->cfg.device));
   TRY(launch_update(p, false));
   HIP_TRY(hipStreamSynchronize(p->stream));
@@ -2787,6 +2802,7 @@ extern "C" int mppi_planner_packet_len(mppi_planner* p, int* doubles) {
 extern "C" int mppi_planner_update_local(mppi_planner* p, double* packet) {
   REQUIRE(p && packet, MPPI_ERR_INVALID, "NULL argument");
   REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
+  REQUIRE(!p->sample_costs_local_only, MPPI_ERR_STATE, "sample shards: exchange the per-sample costs before the update");
   HIP_TRY(hipSetDevice(p->cfg.device));
   TRY(launch_update_local(p, false));
   const int len = p->B * packet_len(p->cfg.num_steps);

@@ -193,6 +193,12 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
   }
 
   // ---------------------------------------------------------------- A: noise, controls, heading increments
+  // (requested before the Philox blocks: their first touch is a trip to memory)
+  float2 ut[CHL];
+#pragma unroll
+  for (int j = 0; j < CHL; ++j) ut[j] = uq[min(t0 + j, T - 1)];
+  // the assumption: every visited cell carries the traction bytes of the start cell
+  const uint32_t ref = scan_lookup<POW2RES>(Q, cells16, Q.x0, Q.y0) & 0x3fffu;
   float2 e[CHL];
   if constexpr (GEN) {
     const uint64_t epoch = gen.epoch + (gen.gen_counter ? *gen.gen_counter : 0ull);
@@ -208,11 +214,6 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
 #pragma unroll
     for (int j = 0; j < CHL; ++j) e[j] = col[(size_t)min(t0 + j, T - 1) * 64];
   }
-  float2 ut[CHL];
-#pragma unroll
-  for (int j = 0; j < CHL; ++j) ut[j] = uq[min(t0 + j, T - 1)];
-  // the assumption: every visited cell carries the traction bytes of the start cell
-  const uint32_t ref = scan_lookup<POW2RES>(Q, cells16, Q.x0, Q.y0) & 0x3fffu;
 #pragma unroll
   for (int j = 0; j < CHL; ++j) {
     const bool valid = j < nvalid;
@@ -253,9 +254,15 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
   // ---------------------------------------------------------------- B: headings, position increments
   float lx[CHL], ly[CHL];  // position gained inside the chunk up to and including step j
   {
+    // (eight sums requested per wait: one LDS round trip per addition was a third of this stage)
     double tb = (double)Q.th0 * 0.15915494309189535;
-    for (int i = 0; i < c * S; ++i) tb += sumS[(size_t)i * R + r];
-    if (S > 1 && h > 0) tb += sumS[(size_t)(c * S) * R + r];
+    for (int i0 = 0; i0 < k; i0 += 8) {
+      double v8[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v8[q] = sumS[(size_t)min(i0 + q, K - 1) * R + r];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) tb += (i0 + q < k) ? v8[q] : 0.0;
+    }
     const float fb = (float)__builtin_amdgcn_fract(tb);  // v_sin_f32 / v_cos_f32 take turns
     float sx = 0.0f, sy = 0.0f;
 #pragma unroll
@@ -280,13 +287,18 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
   uint32_t zero_bits = 0, mism_bits = 0, hit_bits = 0;
   {
     double bx = (double)Q.x0, by = (double)Q.y0;
-    for (int i = 0; i < c * S; ++i) {
-      bx += sumS[(size_t)(K + i) * R + r];
-      by += sumS[(size_t)(2 * K + i) * R + r];
-    }
-    if (S > 1 && h > 0) {
-      bx += sumS[(size_t)(K + c * S) * R + r];
-      by += sumS[(size_t)(2 * K + c * S) * R + r];
+    for (int i0 = 0; i0 < k; i0 += 8) {
+      double vx[8], vy[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        vx[q] = sumS[(size_t)(K + min(i0 + q, K - 1)) * R + r];
+        vy[q] = sumS[(size_t)(2 * K + min(i0 + q, K - 1)) * R + r];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        bx += (i0 + q < k) ? vx[q] : 0.0;
+        by += (i0 + q < k) ? vy[q] : 0.0;
+      }
     }
     xa[0] = (float)bx;
     ya[0] = (float)by;
@@ -549,10 +561,10 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
     }
     if (mine) w_rel[n] = wr;
     if (lane < R) wsh[lane] = wr;
-    const double den = wave_sum_f64((double)wr);
-    if (lane == 0) {
+    const float den = wave_sum_to_lane63_f32(wr);
+    if (lane == 63) {
       pk.tbeta[tile] = beta;
-      pk.tden[tile] = (float)den;
+      pk.tden[tile] = den;
     }
     MPPI_STAMP(stamp_wg, stamp_base + 11);
   }

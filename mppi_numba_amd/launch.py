@@ -10,12 +10,16 @@ Two ways in, same protocol:
   * launched by `python -m torch.distributed.run --nproc-per-node N ...`: the launcher has set
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT; the rendezvous file name is derived from the
     launcher's pid and port, which all ranks share.
-Rank 0 listens on an ephemeral port of 127.0.0.1 and publishes it through the rendezvous file
-(written atomically); the other ranks connect.  Single node only, as is the sharding itself.
+Rank 0 listens on an ephemeral port of 127.0.0.1 and publishes it, with a random token, through the
+rendezvous file (created exclusively, mode 0600, in a private directory when bench.py starts the
+ranks itself); the other ranks check that the file is their own user's, connect and present the
+token.  Messages are a tagged encoding of bytes / ints / floats / float arrays -- nothing that
+executes on decoding.  Single node only, as is the sharding itself.
 """
 import json
 import os
-import pickle
+import hmac
+import secrets
 import socket
 import struct
 import subprocess
@@ -45,9 +49,9 @@ def rendezvous_path():
 def spawn_ranks(world, argv, extra_env=None, timeout=None):
     """Start `world` copies of `argv` (a full command line), one per rank; returns rank 0's
     exit code after all have ended.  Rank 0 inherits stdout; every rank inherits stderr."""
-    fd, path = tempfile.mkstemp(prefix="mppi_rdzv_", suffix=".json")
-    os.close(fd)
-    os.unlink(path)
+    # a directory of our own (mode 0700): the file rank 0 creates in it cannot be anticipated by anyone
+    rdzv_dir = tempfile.mkdtemp(prefix="mppi_rdzv_")
+    path = os.path.join(rdzv_dir, "rendezvous.json")
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MPPI_RDZV_FILE=path,
@@ -80,25 +84,161 @@ def spawn_ranks(world, argv, extra_env=None, timeout=None):
                 p.kill()
         if os.path.exists(path):
             os.unlink(path)
+        try:
+            os.rmdir(rdzv_dir)
+        except OSError:
+            pass
     return codes[0]
 
 
+# ---- wire format -------------------------------------------------------------------------------
+# What crosses the hub is a 128-byte communicator id, a few ints / floats and float arrays: a small
+# tagged encoding of exactly those (nothing that executes on decoding; the previous version used
+# pickle, which does).
+_DTYPES = ["float32", "float64", "int32", "int64", "int8", "uint8"]
+
+
+def _encode(obj, out):
+    import numpy as np
+    if obj is None:
+        out.append(b"N")
+    elif isinstance(obj, bool):
+        out.append(b"T" if obj else b"f")
+    elif isinstance(obj, (int, np.integer)):
+        out.append(b"I" + struct.pack("<q", int(obj)))
+    elif isinstance(obj, (float, np.floating)):
+        out.append(b"F" + struct.pack("<d", float(obj)))
+    elif isinstance(obj, (bytes, bytearray)):
+        out.append(b"B" + struct.pack("<I", len(obj)) + bytes(obj))
+    elif isinstance(obj, str):
+        raw = obj.encode("utf-8")
+        out.append(b"S" + struct.pack("<I", len(raw)) + raw)
+    elif isinstance(obj, (list, tuple)):
+        out.append(b"L" + struct.pack("<I", len(obj)))
+        for item in obj:
+            _encode(item, out)
+    elif isinstance(obj, dict):
+        out.append(b"D" + struct.pack("<I", len(obj)))
+        for key, item in obj.items():
+            _encode(str(key), out)
+            _encode(item, out)
+    elif isinstance(obj, np.ndarray):
+        arr = np.ascontiguousarray(obj)
+        if arr.dtype.name not in _DTYPES:
+            raise TypeError("hub: arrays of dtype %s are not exchanged" % arr.dtype)
+        out.append(b"A" + struct.pack("<BB", _DTYPES.index(arr.dtype.name), arr.ndim) +
+                   struct.pack("<%dI" % arr.ndim, *arr.shape) + arr.tobytes())
+    else:
+        raise TypeError("hub: values of type %s are not exchanged" % type(obj).__name__)
+
+
+def _decode(buf, at=0):
+    import numpy as np
+    tag = buf[at:at + 1]
+    at += 1
+    if tag == b"N":
+        return None, at
+    if tag in (b"T", b"f"):
+        return tag == b"T", at
+    if tag == b"I":
+        return struct.unpack_from("<q", buf, at)[0], at + 8
+    if tag == b"F":
+        return struct.unpack_from("<d", buf, at)[0], at + 8
+    if tag in (b"B", b"S"):
+        (n,) = struct.unpack_from("<I", buf, at)
+        raw = bytes(buf[at + 4:at + 4 + n])
+        if len(raw) != n:
+            raise ValueError("hub: truncated message")
+        return (raw if tag == b"B" else raw.decode("utf-8")), at + 4 + n
+    if tag == b"L":
+        (n,) = struct.unpack_from("<I", buf, at)
+        at += 4
+        items = []
+        for _ in range(n):
+            item, at = _decode(buf, at)
+            items.append(item)
+        return items, at
+    if tag == b"D":
+        (n,) = struct.unpack_from("<I", buf, at)
+        at += 4
+        items = {}
+        for _ in range(n):
+            key, at = _decode(buf, at)
+            items[key], at = _decode(buf, at)
+        return items, at
+    if tag == b"A":
+        code, ndim = struct.unpack_from("<BB", buf, at)
+        at += 2
+        if code >= len(_DTYPES) or ndim > 8:
+            raise ValueError("hub: malformed array header")
+        shape = struct.unpack_from("<%dI" % ndim, buf, at)
+        at += 4 * ndim
+        dtype = np.dtype(_DTYPES[code])
+        count = 1
+        for d in shape:
+            count *= d
+        nbytes = count * dtype.itemsize
+        if at + nbytes > len(buf):
+            raise ValueError("hub: truncated array")
+        arr = np.frombuffer(buf, dtype=dtype, count=count, offset=at).reshape(shape).copy()
+        return arr, at + nbytes
+    raise ValueError("hub: unknown tag %r" % tag)
+
+
+_MAX_MESSAGE = 1 << 28
+
+
 def _send(sock, obj):
-    blob = pickle.dumps(obj)
+    parts = []
+    _encode(obj, parts)
+    blob = b"".join(parts)
     sock.sendall(struct.pack("<Q", len(blob)) + blob)
 
 
 def _recv(sock):
     def exactly(n):
-        buf = b""
+        buf = bytearray()
         while len(buf) < n:
             chunk = sock.recv(n - len(buf))
             if not chunk:
                 raise ConnectionError("peer closed the rendezvous socket")
             buf += chunk
-        return buf
+        return bytes(buf)
     (n,) = struct.unpack("<Q", exactly(8))
-    return pickle.loads(exactly(n))
+    if n > _MAX_MESSAGE:
+        raise ValueError("hub: message of %d bytes refused" % n)
+    value, end = _decode(exactly(n))
+    if end != n:
+        raise ValueError("hub: trailing bytes in message")
+    return value
+
+
+def _write_rendezvous(path, port, token):
+    """Created exclusively and owner-only: nobody else can pre-create it, point it elsewhere through a
+    symlink, or read the token the ranks have to present."""
+    try:
+        st = os.lstat(path)
+        if st.st_uid == os.getuid() and time.time() - st.st_mtime > 600.0:
+            os.unlink(path)  # a leftover of an earlier run of ours
+    except OSError:
+        pass
+    fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_WRONLY | getattr(os, "O_NOFOLLOW", 0), 0o600)
+    with os.fdopen(fd, "w") as fh:
+        json.dump({"port": port, "pid": os.getpid(), "time": time.time(), "token": token}, fh)
+
+
+def _read_rendezvous(path):
+    """The file as rank 0 wrote it, or None: it must be a regular file of OUR user that nobody else can write."""
+    fd = os.open(path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+    try:
+        st = os.fstat(fd)
+        import stat as _stat
+        if not _stat.S_ISREG(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o022):
+            return None
+        with os.fdopen(os.dup(fd)) as fh:
+            return json.load(fh)
+    finally:
+        os.close(fd)
 
 
 class Hub:
@@ -117,16 +257,26 @@ class Hub:
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind(("127.0.0.1", 0))
             srv.listen(world)
-            tmp = path + ".tmp%d" % os.getpid()
-            with open(tmp, "w") as fh:
-                json.dump({"port": srv.getsockname()[1], "pid": os.getpid(), "time": time.time()}, fh)
-            os.replace(tmp, path)
+            token = secrets.token_hex(32)
+            _write_rendezvous(path, srv.getsockname()[1], token)
             srv.settimeout(timeout)
             by_rank = {}
             while len(by_rank) < world - 1:
                 conn, _ = srv.accept()
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                by_rank[_recv(conn)] = conn
+                conn.settimeout(timeout)
+                try:  # the first message must be [token, rank]; anything else is not one of ours
+                    hello = _recv(conn)
+                    ok = (isinstance(hello, list) and len(hello) == 2 and isinstance(hello[0], str) and
+                          hmac.compare_digest(hello[0], token) and isinstance(hello[1], int) and
+                          1 <= hello[1] < world and hello[1] not in by_rank)
+                except (ValueError, ConnectionError, OSError, struct.error):
+                    ok = False
+                if not ok:
+                    conn.close()
+                    continue
+                conn.settimeout(None)
+                by_rank[hello[1]] = conn
             self.peers = [by_rank[r] for r in range(1, world)]
             srv.close()
             os.unlink(path)
@@ -135,9 +285,8 @@ class Hub:
             info = None
             while info is None:
                 try:
-                    with open(path) as fh:
-                        cand = json.load(fh)
-                    if cand["time"] > started - 600.0:  # not a leftover of an earlier run
+                    cand = _read_rendezvous(path)
+                    if cand is not None and cand["time"] > started - 600.0:  # not a leftover of an earlier run
                         info = cand
                 except (OSError, ValueError, KeyError):
                     pass
@@ -154,7 +303,7 @@ class Hub:
                         raise
                     time.sleep(0.05)
             self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            _send(self.sock, rank)
+            _send(self.sock, [info["token"], rank])
 
     def gather(self, value):
         """Rank 0 gets [value of rank 0, ..., value of rank world-1]; the others get None."""

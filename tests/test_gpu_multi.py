@@ -163,6 +163,28 @@ def test_sample_sharded_loop_needs_a_communicator_and_runs_with_one():
         p.solve()
 
 
+def test_stage_level_update_of_a_sample_shard_needs_the_exchange_first():
+    """rollout() of a sample-sharded handle leaves the CVaR over ITS samples in costs_d: an update()
+    from that would give every rank another u without any error.  It is refused
+    until the slabs of all shards have been applied."""
+    from mppi_numba_amd._lib import MppiError
+    parts = [_cvar_build(64, 8, shard=(r, 2)) for r in range(2)]
+    for tl, ta, p, params in parts:
+        tl.sample_grids(params["alpha_dyn"])
+        ta.sample_grids(params["alpha_dyn"])
+        p.sample_noise()
+        p.rollout()
+    with pytest.raises(MppiError, match="exchange"):
+        parts[0][2].update()
+    with pytest.raises(MppiError, match="exchange"):
+        parts[0][2].update_local()
+    slabs = np.stack([p.sample_costs_local() for _, _, p, _ in parts])
+    for _, _, p, _ in parts:
+        p.sample_costs_apply(slabs)
+        p.update()
+    np.testing.assert_array_equal(parts[0][2].u_cur_d.copy_to_host(), parts[1][2].u_cur_d.copy_to_host())
+
+
 def test_sample_shards_need_the_counter_based_generator_and_even_offsets():
     """The shards' draws are the unsharded ones because a draw's Philox counter is its global sample
     index; the numba-compatible xoroshiro streams cannot be split that way, and a Philox block

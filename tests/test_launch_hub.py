@@ -91,3 +91,81 @@ def test_a_dying_rank_takes_the_job_down(tmp_path):
     out = subprocess.run([sys.executable, "-c", driver], capture_output=True, text=True, timeout=60)
     assert out.returncode == 3
     assert "rank(s) [1] failed" in out.stderr
+
+
+def test_wire_format_round_trip_and_refusals():
+    """The hub's messages are a tagged encoding of bytes / numbers / float arrays: nothing that runs
+    code on decoding (the first version used pickle)."""
+    import socket
+    from mppi_numba_amd import launch
+    a, b = socket.socketpair()
+    try:
+        msg = [b"\x00" * 128, None, 3, -2.5, True, "text", {"rank": 1, "packet": np.arange(6, dtype=np.float64).reshape(3, 2)},
+               [np.float32(1.5), np.zeros((2, 0, 3), dtype=np.float32)]]
+        launch._send(a, msg)
+        got = launch._recv(b)
+        assert got[0] == msg[0] and got[1] is None and got[2] == 3 and got[3] == -2.5 and got[4] is True and got[5] == "text"
+        assert got[6]["rank"] == 1 and np.array_equal(got[6]["packet"], msg[6]["packet"]) and got[6]["packet"].dtype == np.float64
+        assert got[7][0] == 1.5 and got[7][1].shape == (2, 0, 3)
+        with pytest.raises(TypeError):
+            launch._send(a, object())
+        with pytest.raises(TypeError):
+            launch._send(a, np.array(["x"]))
+        import pickle, struct
+        blob = pickle.dumps({"x": 1})
+        a.sendall(struct.pack("<Q", len(blob)) + blob)  # what the old protocol would have sent
+        with pytest.raises(ValueError):
+            launch._recv(b)
+    finally:
+        a.close()
+        b.close()
+
+
+def test_rendezvous_file_is_exclusive_and_owner_only(tmp_path):
+    from mppi_numba_amd import launch
+    path = str(tmp_path / "r.json")
+    launch._write_rendezvous(path, 1234, "tok")
+    assert (os.stat(path).st_mode & 0o777) == 0o600
+    assert launch._read_rendezvous(path)["port"] == 1234
+    with pytest.raises(FileExistsError):
+        launch._write_rendezvous(path, 1, "other")  # (a fresh file of somebody else's is never overwritten)
+    os.chmod(path, 0o666)
+    assert launch._read_rendezvous(path) is None  # writable by others: not trusted
+    os.unlink(path)
+    os.symlink(str(tmp_path / "elsewhere"), path)
+    with pytest.raises(OSError):
+        launch._write_rendezvous(path, 1, "t")  # never through a symlink
+
+
+def test_hub_turns_away_a_peer_without_the_token(tmp_path):
+    import socket, threading, time as _time
+    from mppi_numba_amd import launch
+    path = str(tmp_path / "r.json")
+    result = {}
+
+    def rank0():
+        hub = launch.Hub(0, 2, path=path, timeout=30)
+        result["gathered"] = hub.all_gather("zero")
+        hub.close()
+
+    th = threading.Thread(target=rank0)
+    th.start()
+    info = None
+    for _ in range(500):
+        try:
+            info = launch._read_rendezvous(path)
+            if info:
+                break
+        except OSError:
+            pass
+        _time.sleep(0.01)
+    assert info
+    intruder = socket.create_connection(("127.0.0.1", info["port"]))
+    launch._send(intruder, ["not-the-token", 1])
+    _time.sleep(0.1)
+    hub1 = launch.Hub(1, 2, path=path, timeout=30)
+    got = hub1.all_gather("one")
+    hub1.close()
+    th.join(30)
+    intruder.close()
+    assert got == ["zero", "one"] and result["gathered"] == ["zero", "one"]
