@@ -226,21 +226,35 @@ def parity_margin(w, p, P, grids, planner):
 
 def reference_cpu_path():
     """BASELINE configs[0] through the reference's own code under the CUDA
-    simulator, when this box has both the reference and its interpreter; otherwise say so and
-    quote the build-container measurement committed under profiles/."""
+    simulator, when this box has both the reference checkout (MPPI_NUMBA_REFERENCE or
+    /root/reference) and an interpreter with numba (MPPI_NUMBA_PYTHON or /opt/conda/bin/python3.9).
+    Otherwise says which of the two is missing; the figure measured in the build container is kept
+    under a key that says what it is."""
     script = os.path.join(ROOT, "oracle", "time_reference_cudasim.py")
-    py, ref = "/opt/conda/bin/python3.9", "/root/reference/mppi_numba/mppi.py"
-    if os.path.exists(py) and os.path.exists(ref):
+    ref_root = os.environ.get("MPPI_NUMBA_REFERENCE") or "/root/reference"
+    if os.path.basename(os.path.normpath(ref_root)) == "mppi_numba":
+        ref_root = os.path.dirname(os.path.normpath(ref_root))
+    py = os.environ.get("MPPI_NUMBA_PYTHON") or "/opt/conda/bin/python3.9"
+    have_ref = os.path.isfile(os.path.join(ref_root, "mppi_numba", "mppi.py")) and \
+        os.path.isfile(os.path.join(ref_root, "barebone_mppi_numba.ipynb"))
+    have_py = os.path.exists(py)
+    if have_ref and have_py:
         import subprocess
         try:
-            run = subprocess.run([py, script, "--solves", "3"], capture_output=True, text=True, timeout=300)
+            run = subprocess.run([py, script, "--solves", "3", "--reference", ref_root], capture_output=True, text=True,
+                                 timeout=300)
             return json.loads(run.stdout.strip().splitlines()[-1])
         except Exception as e:  # noqa: BLE001 -- a diagnostic leg must not take the bench down
             return dict(status="failed: %s" % e)
-    out = dict(status="unavailable on this box (%s absent)" % ("/root/reference" if not os.path.exists(ref) else py))
+    missing = []
+    if not have_ref:
+        missing.append("reference checkout (%s has no mppi_numba/mppi.py + barebone_mppi_numba.ipynb; set MPPI_NUMBA_REFERENCE)" % ref_root)
+    if not have_py:
+        missing.append("interpreter with numba's CUDA simulator (%s; set MPPI_NUMBA_PYTHON)" % py)
+    out = dict(status="not measured in this run: missing " + " and ".join(missing))
     try:
         with open(os.path.join(ROOT, "profiles", "r02_reference_cudasim.json")) as fh:
-            out["measured_in_build_container"] = json.loads(fh.read())
+            out["stale_build_container_measurement"] = json.loads(fh.read())
     except (OSError, ValueError):
         pass
     return out

@@ -281,7 +281,11 @@ int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity)
 /* diagnostic: compares the library's single-block Philox4x32-10 with rocRAND's engine on
  * 65536 (seed, subsequence, offset) triples; *mismatches must come back 0 */
 /* developer switches for the parity tests, which pin every rollout kernel variant by name
- * (mppi_planner_describe_last_rollout): results never depend on them */
+ * (mppi_planner_describe_last_rollout).  With MPPI_MATH_EXACT the results never depend on them (every
+ * variant has the reference's bits).  With MPPI_MATH_FAST they select between kernels that agree to
+ * float32 tolerance only -- and so does whatever else decides which kernel runs there: N, the map
+ * (a failed traction vote re-runs a tile sequentially; a map that keeps failing switches the
+ * speculative kernels off until it changes). */
 #define MPPI_DEBUG_NO_SPEC_KERNEL 1  /* latency regime: k_rollout_pipe instead of k_rollout_spec */
 #define MPPI_DEBUG_NO_SPECULATION 2  /* the speculative kernels on their exact schedule from the first step */
 #define MPPI_DEBUG_NO_DEEP_KERNEL 4  /* one tile per CU: k_rollout_spec instead of k_rollout_deep */

@@ -16,9 +16,10 @@ drawing, no device code).  They resolve, in this order, to
      (e.g. PYTHONPATH=/root/repo:/root/reference).  Nothing is copied: the directory
      is appended to this package's `__path__`, so `import mppi_numba.density` loads the
      reference's density.py while `mppi_numba.mppi` stays the HIP engine;
-  2. otherwise the stand-ins shipped in mppi_numba_amd (same classes and functions,
-     written for this package), so that the notebooks still run where the reference
-     is not checked out (e.g. on a GPU box that only has this repository).
+  2. otherwise they do not resolve: this repository replaces the hot path, not the reference's
+     test-data generators and plotting.  The ImportError names
+     MPPI_NUMBA_REFERENCE.  (The test suite points MPPI_NUMBA_REFERENCE at minimal stand-ins under
+     tests/standins/ on boxes without the reference, so that the notebooks' flow still runs there.)
 """
 import importlib
 import os
@@ -60,27 +61,17 @@ if reference_dir is not None:
     __path__.append(reference_dir)
 else:
     import importlib.abc
-    import importlib.util
 
-    class _StandInLoader(importlib.abc.Loader):
-        """`mppi_numba.<helper>` IS `mppi_numba_amd.<helper>` (imported on first use)."""
-
-        def __init__(self, target):
-            self.target = target
-
-        def create_module(self, spec):
-            return importlib.import_module(self.target)
-
-        def exec_module(self, module):
-            pass
-
-    class _StandInFinder(importlib.abc.MetaPathFinder):
+    class _NoReferenceFinder(importlib.abc.MetaPathFinder):
         def find_spec(self, fullname, path=None, target=None):
             head, _, tail = fullname.rpartition(".")
             if head == __name__ and tail in _HOST_HELPERS:
-                return importlib.util.spec_from_loader(fullname, _StandInLoader("mppi_numba_amd." + tail))
+                raise ImportError(
+                    "%s is one of mit-acl/mppi_numba's host-side helper modules (sample generators, plotting), which "
+                    "this package does not replace: point MPPI_NUMBA_REFERENCE at a checkout of the reference (or put "
+                    "it behind this repository on PYTHONPATH)" % fullname)
             return None
 
-    sys.meta_path.append(_StandInFinder())
+    sys.meta_path.append(_NoReferenceFinder())
 
-host_helpers_from = reference_dir or os.path.dirname(os.path.abspath(config.__file__))
+host_helpers_from = reference_dir  # None: the helper modules are not importable

@@ -1,0 +1,204 @@
+// handles.h -- what the opaque handles of include/mppi_hip.h hold (included by mppi_api.hip only).
+#pragma once
+#include "host_common.h"
+
+// ---------------------------------------------------------------------------
+// TDM
+// ---------------------------------------------------------------------------
+struct mppi_tdm {
+  mppi_tdm_cfg cfg;
+  hipStream_t stream = nullptr;
+  int8_t* grid = nullptr;  // [G][max_rows][max_cols] int8 (reference layout)
+  int8_t* pmf = nullptr;   // [B][rows][cols]
+  size_t pmf_capacity = 0;
+  int8_t* table = nullptr;  // [B] bin -> int8 traction
+  int table_capacity = 0;
+  int8_t* obs = nullptr;  // [rows][cols]
+  int8_t* unk = nullptr;
+  int8_t* risk = nullptr;
+  size_t map_capacity = 0;
+  // staging of the raw inputs of mppi_tdm_set_maps_from_pmf (device-side preprocessing)
+  int8_t* raw = nullptr;  // raw PMF | raw obstacle | raw unknown
+  size_t raw_capacity = 0;
+  float* bin_values = nullptr;
+  int bin_values_capacity = 0;
+  int* prep_flags = nullptr;
+  uint64_t* states = nullptr;  // xoroshiro-compatible generator only
+  long n_states = 0;
+  int bins = 0, rows = 0, cols = 0;
+  bool has_risk = false, maps_set = false, one_hot = false;
+  bool compact_ok = false;  // masks are 0/1 and every traction byte is in [0,127]: 16-bit cells usable
+  int table_max = 127;      // largest traction byte the sampler can write
+  double lo = 0.0, ratio = 0.0;
+  uint64_t epoch = 0;         // Philox call counter
+  uint64_t maps_version = 0;  // bumped by set_maps
+  uint64_t grid_version = 0;  // bumped whenever `grid` changes
+  uint64_t sampled_maps_version = ~0ULL;
+  double sampled_alpha = -1.0;
+  // solve() of a CVaR planner samples straight into the planner's cell words (Philox only):
+  // the int8 grids are then produced on demand from the same counters
+  bool grid_stale = false;      // `grid` does not hold the draws of (sampled_epoch, sampled_alpha) yet
+  uint64_t sampled_epoch = 0;   // Philox epoch of the current draws
+  bool injected = false;  // grids came from mppi_tdm_set_sampled_grids
+  int8_t injected_max = 0, injected_min = 0;
+  // samples sharded over GPUs (mppi_tdm_set_sample_shard): this handle's G grids are samples
+  // [first_sample, first_sample + G) of the unsharded set; even, a Philox block serves a pair
+  int first_sample = 0;
+};
+
+// ---------------------------------------------------------------------------
+// planner
+// ---------------------------------------------------------------------------
+struct mppi_planner {
+  mppi_planner_cfg cfg;
+  hipStream_t stream = nullptr;
+  int n_local = 0, n_offset = 0;
+  // batched multi-query: B problems, each n_inst rollouts (inst_tiles tiles of 64) on this GPU;
+  // n_local = B * n_inst.  Per-problem start / goal / window origin live in inst_dev.
+  int B = 1, n_inst = 0, inst_tiles = 0;
+  std::vector<BatchInst> inst_host;
+  BatchInst* inst_dev = nullptr;
+  bool inst_set = false, inst_dirty = false;
+  // pinned, device-mapped (B,T) mirror of u: the update kernels write it (u_host_dev is the device
+  // view of the same memory), solve() reads it after the stream has drained -- no copy on the hot path
+  float2* u_host = nullptr;
+  float2* u_host_dev = nullptr;
+  // Only solve() reads the mirror, after its LAST iteration: the update launches of every other
+  // iteration are spared the posted write across PCIe (their completion waits for it).
+  bool mirror_now = false;   // the coming update launch writes the mirror
+  bool mirror_done = false;  // ... the last one did
+  // set_u(): pinned staging + asynchronous copy; the next set_u waits for the previous copy only
+  float2* u_stage = nullptr;
+  hipEvent_t ev_u_staged = nullptr;
+  bool u_stage_busy = false;
+  // device buffers
+  float2* noise = nullptr;    // tile-major (n_local, T): the buffer the NEXT rollout/update reads
+  float2* noise_buf[2] = {nullptr, nullptr};  // double buffer: noise of iteration k+1 is generated
+  int noise_cur = 0;                           // while iteration k runs (in-launch or on noise_stream)
+  // throughput regime (no idle CU for in-launch generation): the noise of iteration k+1 runs beside
+  // rollout k on a second stream while the rollout leaves wave slots free (run_iterations)
+  hipStream_t noise_stream = nullptr;
+  hipEvent_t ev_buf_free = nullptr, ev_noise_ready = nullptr;
+  // hipGraph replay of the iteration loop (mppi_planner_set_graph_replay): two iterations
+  // (one round of the noise double buffer) captured once, replayed while nothing a kernel
+  // argument carries has changed.  See run_iterations.
+  bool graph_on = false;
+  int graph_chunk = 2;                    // iterations per captured graph
+  unsigned long long* gen_dev = nullptr;  // device: update kernels executed since graph mode was enabled
+  uint64_t bumps_launched = 0;            // host mirror of *gen_dev once the stream has drained
+  bool primed = false;                    // noise_buf[noise_cur ^ 1] already holds the NEXT iteration's noise
+  bool graph_warm = false;                // one direct iteration has run since graph mode was enabled
+  // one cached graph per parity of the noise double buffer (a call with an odd number of
+  // iterations leaves the other parity behind)
+  hipGraph_t graph[2] = {nullptr, nullptr};
+  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+  std::vector<unsigned char> graph_sig[2];  // everything the captured launches took by value
+  uint64_t graph_spec_tiles[2] = {0, 0};    // speculative tiles one replay of the graph launches
+  long graph_replays = 0, graph_captures = 0;
+  std::string last_rollout;        // which rollout kernel variant the last launch used (diagnostic)
+  int debug_flags = 0;             // mppi_planner_set_debug_flags (tests pin every kernel variant through it)
+  bool next_noise_wanted = false;  // the coming rollout launch should also generate noise_buf[cur^1]
+  bool next_noise_done = false;    // ... and it did
+  bool noise_on_side_stream = false;  // the noise produced ahead is still in flight on noise_stream
+  float2* staging = nullptr;  // (n_local,T) host-layout staging for set/get_noise
+  float2* u = nullptr;        // [T]
+  float2* u_prev = nullptr;   // [T]
+  float* costs = nullptr;     // [n_local]
+  float* weights_out = nullptr;  // [n_local] normalised weights, filled on request
+  float* w_rel = nullptr;      // [n_local] exp(-(c - beta_tile)/lambda)
+  float* tile_beta = nullptr;  // [n_tiles] minimum cost of each tile of 64 rollouts
+  int n_tiles = 0;
+  bool tile_packets_fresh = false;  // w_rel / tile_beta written by the rollout kernel for the current costs
+  // k_rollout_scan (MPPI_MATH_FAST): per-tile sums of w_rel * noise, consumed by k_combine_tiles
+  float2* tnum = nullptr;  // [T][tiles]
+  float* tden = nullptr;   // [tiles]
+  float* tbeta = nullptr;  // [tiles] minimum cost of each of the kernel's tiles (32 or 64 rollouts)
+  int scan_tile = 32;      // rollouts per tile of the last such launch
+  bool scan_packets_fresh = false;  // ... written by the last rollout launch for the current costs
+  // the iteration loop of such a handle generates the noise INSIDE the rollout launch (Philox counter
+  // blocks, never stored): noise_buf is then stale, and whoever wants the noise of the last iteration
+  // (get_noise, get_state_rollout, a stage-level update) has it regenerated from the same counters
+  bool scan_gen_now = false;   // the coming rollout launch is to generate its own noise
+  bool noise_virtual = false;  // the noise of the last iteration exists as counters only ...
+  int noise_virtual_back = 1;  // ... of Philox epoch noise_epoch - noise_virtual_back
+  double* packets = nullptr;  // [world][2+2T]; own packet at [rank]
+  double* stats = nullptr;    // {beta, den} of the last update
+  uint32_t* cells = nullptr;
+  size_t cells_capacity = 0;
+  double* cc_scratch = nullptr;  // [T][n_local] control-cost products of the pipelined rollout
+  uint16_t* cells16 = nullptr;  // 16-bit cells, row pitch multiple of 8 (LDS window source)
+  size_t cells16_capacity = 0;
+  int pitch16 = 0;
+  bool cells16_valid = false;
+  bool cells16_with_risk = false;  // cells16 holds 32-bit cells with the risk byte (speed-map mode)
+  int num_cus = 256;
+  int lds_per_cu = 160 * 1024;
+  int8_t* risk_ref = nullptr;
+  float* sample_costs = nullptr;  // [n_local][M], allocated on first request
+  bool want_sample_costs = false;
+  uint64_t* states = nullptr;  // xoroshiro-compatible generator only
+  long n_states = 0;
+  float2* obs_pos = nullptr;
+  float* obs_r = nullptr;
+  int n_obstacles = 0;
+  float* state_rollout = nullptr;  // [V][T+1][3]
+  // host state
+  mppi_params params;
+  bool params_set = false;
+  uint64_t noise_epoch = 0;
+  const mppi_tdm* packed_lin = nullptr;
+  const mppi_tdm* packed_ang = nullptr;
+  uint64_t packed_lin_grid = ~0ULL, packed_ang_grid = ~0ULL, packed_lin_maps = ~0ULL;
+  // timing
+  hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+  hipEvent_t ev_stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool profile_stages = false;
+  float stage_ms[4] = {0, 0, 0, 0};
+  float last_elapsed_ms = 0.f;
+  bool elapsed_pending = false;
+  int last_iterations = 0;
+  // Speculative rollout kernels (k_rollout_deep / k_rollout_spec) on a map where the traction
+  // changes from cell to cell: every tile fails its vote and re-runs on the exact schedule, slower
+  // than launching k_rollout_pipe in the first place (N = 8192, T = 200 over a CVaR-bin map: 85 vs
+  // 49 us).  The kernels count failed tiles in a host-mapped word; whenever the host has
+  // synchronised anyway it compares that with the tiles launched and, past one half, stops
+  // speculating until the packed map changes.
+  unsigned int* spec_fail_host = nullptr;  // pinned, device-mapped
+  unsigned int* spec_fail_dev = nullptr;   // device view of the same word
+  uint64_t spec_tiles_launched = 0;
+  bool speculation_off = false;
+  // mppi_planner_time_kernels: dispatch begin / end of the rollout and update launches of the
+  // iterations it runs (4 events per iteration), picked up by MPPI_KLAUNCH
+  hipEvent_t kev_start = nullptr, kev_stop = nullptr;
+  std::vector<hipEvent_t> ktime_events;
+  int ktime_index = -1;
+  // comm
+  ncclComm_t comm = nullptr;
+  // CVaR mode with the M traction samples sharded over GPUs (mppi_planner_set_sample_sharding):
+  // this handle rolls ALL N control samples over its cfg.num_grid_samples grids; the per-(n, m)
+  // costs of all shards are all-gathered and every rank forms the CVaR of every control sample
+  int m_rank = 0, m_count = 1;
+  // a stage-level rollout of such a handle leaves the CVaR over the LOCAL samples in costs: the update
+  // must not run before the slabs of all shards have been reduced (launch_cvar_reduce)
+  bool sample_costs_local_only = false;
+  float* slabs = nullptr;  // [m_count][n_local][M_local]
+  // closed loop on the device (mppi_planner_closed_loop): world state, trajectory log
+  double* loop_state = nullptr;   // [B][3]
+  double* loop_xhist = nullptr;   // [B][loop_capacity + 1][3]
+  float2* loop_uhist = nullptr;   // [B][loop_capacity]
+  int* loop_done = nullptr;       // [B]
+  float2* loop_u_final = nullptr; // [B][T] controls of a problem at the step it reached its goal
+  int* loop_done_count = nullptr;      // pinned, device-mapped
+  int* loop_done_count_dev = nullptr;  // device view of the same int
+  int loop_capacity = 0;
+};
+
+static void drop_graphs(mppi_planner* p) {
+  for (int i = 0; i < 2; ++i) {
+    if (p->graph_exec[i]) (void)hipGraphExecDestroy(p->graph_exec[i]);
+    if (p->graph[i]) (void)hipGraphDestroy(p->graph[i]);
+    p->graph_exec[i] = nullptr;
+    p->graph[i] = nullptr;
+    p->graph_sig[i].clear();
+  }
+}

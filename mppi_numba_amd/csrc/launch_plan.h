@@ -1,0 +1,1387 @@
+// launch_plan.h -- which kernels an iteration launches and with what geometry: packing of the map cells,
+// LDS window planning, the regime selection of the rollout kernels, the update / exchange launches, the
+// iteration loop with its hipGraph replay.  Host code only; the C ABI shims that call into it are in
+// mppi_api.hip (which is the only file that includes this one: everything here has internal linkage).
+#pragma once
+#include "handles.h"
+
+static int tdm_max_byte(const mppi_tdm* t) { return t->injected ? (int)t->injected_max : t->table_max; }
+
+// ---- helpers -------------------------------------------------------------------
+static int check_tdms(const mppi_planner* p, const mppi_tdm* lin, const mppi_tdm* ang) {
+  if (p->cfg.mode == MPPI_MODE_BAREBONE) return MPPI_OK;
+  REQUIRE(lin && ang, MPPI_ERR_INVALID, "lin/ang TDM required in this mode");
+  REQUIRE(lin->maps_set && ang->maps_set, MPPI_ERR_STATE, "TDM maps not set");
+  REQUIRE(lin->cfg.device == p->cfg.device && ang->cfg.device == p->cfg.device, MPPI_ERR_INVALID,
+          "planner and TDMs live on different devices");
+  REQUIRE(lin->rows == ang->rows && lin->cols == ang->cols, MPPI_ERR_INVALID,
+          "lin and ang TDMs differ in padded size (%dx%d vs %dx%d)", lin->rows, lin->cols, ang->rows,
+          ang->cols);
+  REQUIRE(lin->cfg.num_grids == p->cfg.num_grid_samples && ang->cfg.num_grids == p->cfg.num_grid_samples,
+          MPPI_ERR_INVALID, "TDM num_grids (%d, %d) != planner num_grid_samples (%d)", lin->cfg.num_grids,
+          ang->cfg.num_grids, p->cfg.num_grid_samples);
+  REQUIRE(lin->cfg.max_rows == ang->cfg.max_rows && lin->cfg.max_cols == ang->cfg.max_cols, MPPI_ERR_INVALID,
+          "lin and ang TDMs differ in max_map_dim");
+  REQUIRE(p->cfg.mode != MPPI_MODE_SPEED_MAP || lin->has_risk, MPPI_ERR_STATE,
+          "speed-map mode needs lin TDM's risk traction map");
+  return MPPI_OK;
+}
+
+static DevParams make_dev_params(const mppi_planner* p, const mppi_tdm* lin, const mppi_tdm* ang) {
+  const mppi_params& a = p->params;
+  DevParams d;
+  memset(&d, 0, sizeof(d));
+  d.x0 = a.x0[0]; d.y0 = a.x0[1]; d.th0 = a.x0[2];
+  d.xg = a.xgoal[0]; d.yg = a.xgoal[1];
+  d.v_lo = a.vrange[0]; d.v_hi = a.vrange[1];
+  d.w_lo = a.wrange[0]; d.w_hi = a.wrange[1];
+  d.dt = a.dt;
+  d.gt2 = a.goal_tolerance * a.goal_tolerance;  // float32 product (mppi.py:960)
+  d.lambda = a.lambda_weight;
+  d.obs_cost = a.obs_cost;
+  d.unk_cost = a.unknown_cost;
+  d.res = a.res > 0.f ? a.res : 1.f;
+  d.inv_res = 1.0f / d.res;
+  d.xlo = a.xlo; d.ylo = a.ylo;
+  d.cvar_alpha = a.cvar_alpha;
+  d.numel = (int)std::ceil((double)p->cfg.num_grid_samples * (double)a.cvar_alpha);
+  if (d.numel < 1) d.numel = 1;
+  if (d.numel > p->cfg.num_grid_samples) d.numel = p->cfg.num_grid_samples;
+  // (samples sharded over GPUs: the local kernel's own reduction is not used; cvar_numel())
+  d.dist_weight = a.dist_weight;
+  d.v_post_den = (double)a.v_post_rollout + 1e-6;
+  if (lin) { d.lin_lo = lin->lo; d.lin_ratio = lin->ratio; d.rows = lin->rows; d.cols = lin->cols; }
+  if (ang) { d.ang_lo = ang->lo; d.ang_ratio = ang->ratio; }
+  d.lin_zero_byte = -1;
+  for (int b = 0; b < 128 && lin; ++b)
+    if (std::fma(d.lin_ratio, (double)b, d.lin_lo) == 0.0) { d.lin_zero_byte = b; break; }
+  d.lin_max_byte = lin ? tdm_max_byte(lin) : 0;
+  d.ang_max_byte = ang ? tdm_max_byte(ang) : 0;
+  d.s0sq = (double)a.u_std[0] * (double)a.u_std[0];
+  d.s1sq = (double)a.u_std[1] * (double)a.u_std[1];
+  d.n_local = p->n_local;
+  d.n_steps = p->cfg.num_steps;
+  d.n_grids = p->cfg.num_grid_samples;
+  d.n_obstacles = p->n_obstacles;
+  d.inst = p->inst_set ? p->inst_dev : nullptr;
+  d.inst_tiles = p->inst_tiles;
+  d.n_inst = p->n_inst;
+  d.spec_failures = p->spec_fail_dev;
+  d.cc_k0 = (float)((double)a.lambda_weight / d.s0sq);
+  d.cc_k1 = (float)((double)a.lambda_weight / d.s1sq);
+  d.inv_v_post_den = 1.0 / d.v_post_den;
+  d.neg_log2e_over_lambda = -1.4426950408889634 / (double)a.lambda_weight;
+  return d;
+}
+
+static int reserve_cells(mppi_planner* p, const mppi_tdm* lin, int M) {
+  size_t need = (size_t)lin->rows * lin->cols * M;
+  if (need > p->cells_capacity) {
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    dev_free(p->cells);
+    p->cells_capacity = 0;  // (stays 0 if the allocation below fails)
+    TRY(dev_alloc(&p->cells, need));
+    p->cells_capacity = need;
+  }
+  return MPPI_OK;
+}
+
+// solve() of a CVaR planner, Philox generators: both TDMs sampled straight into the cell words
+// the rollout gathers (k_sample_cellsM_philox), no (G, R, C) int8 grids and no transpose; the
+// int8 grids follow on demand from the same counters (tdm_materialize).  Returns false when
+// the ordinary sample + pack path has to run.
+static bool sample_into_cells(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, double alpha_dyn, int* rc) {
+  *rc = MPPI_OK;
+  static const bool disabled = getenv("MPPI_NO_FUSED_SAMPLING") != nullptr;  // developer switch (ablation)
+  if (disabled || p->cfg.mode != MPPI_MODE_TDM || lin == ang) return false;
+  if (lin->cfg.rng != MPPI_RNG_PHILOX || ang->cfg.rng != MPPI_RNG_PHILOX) return false;
+  if (lin->bins > 64 || ang->bins > 64 || !(alpha_dyn > 0.0)) return false;
+  if (lin->first_sample != ang->first_sample) return false;
+  const int M = p->cfg.num_grid_samples;
+  // a wave of this kernel sets up the thresholds of its 4 cells for M/64 rounds of draws: measured
+  // against sample + sample + transpose, 65 vs 61 us at M = 128 and 192 vs 363 us at M = 1024
+  if (M < 192) return false;
+  if ((*rc = reserve_cells(p, lin, M)) != MPPI_OK) return true;
+  const long cell_groups = (long)lin->rows * ((lin->cols + 3) / 4);
+  const int bins = std::max(lin->bins, ang->bins);
+  dim3 grid((unsigned)ceil_div(cell_groups, 4));
+#define MPPI_SAMPLE_CELLS(MAXB)                                                                                    \
+  hipLaunchKernelGGL(k_sample_cellsM_philox<MAXB>, grid, dim3(256), 0, p->stream, lin->pmf, lin->bins, lin->table, \
+                     lin->cfg.seed, lin->epoch, ang->pmf, ang->bins, ang->table, ang->cfg.seed, ang->epoch,        \
+                     lin->obs, lin->unk, lin->rows, lin->cols, alpha_dyn, M, p->cells,                            \
+                     (uint64_t)(lin->first_sample >> 1) * (uint64_t)cell_groups)
+  if (bins <= 8) MPPI_SAMPLE_CELLS(8);
+  else if (bins <= 16) MPPI_SAMPLE_CELLS(16);
+  else if (bins <= 32) MPPI_SAMPLE_CELLS(32);
+  else MPPI_SAMPLE_CELLS(64);
+#undef MPPI_SAMPLE_CELLS
+  if (hipGetLastError() != hipSuccess) {
+    *rc = fail(MPPI_ERR_HIP, "k_sample_cellsM_philox launch failed");
+    return true;
+  }
+  for (mppi_tdm* t : {lin, ang}) {
+    t->sampled_epoch = t->epoch++;
+    t->sampled_alpha = alpha_dyn;
+    t->sampled_maps_version = t->maps_version;
+    t->grid_stale = true;  // the int8 grids of these draws do not exist yet
+    t->injected = false;
+    ++t->grid_version;
+  }
+  p->cells16_valid = false;
+  p->risk_ref = lin->risk;
+  p->packed_lin = lin;
+  p->packed_ang = ang;
+  p->packed_lin_grid = lin->grid_version;
+  p->packed_ang_grid = ang->grid_version;
+  if (p->packed_lin_maps != lin->maps_version) p->speculation_off = false;  // a new map: speculate again
+  p->packed_lin_maps = lin->maps_version;
+  return true;
+}
+
+// (re)build the packed cell words when the sampled grids or the masks changed
+static int ensure_packed(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang) {
+  if (p->cfg.mode == MPPI_MODE_BAREBONE) return MPPI_OK;
+  // solve() samples the traction grids itself; the stage-level entry points use what is there
+  REQUIRE(lin->grid_version > 0 && ang->grid_version > 0, MPPI_ERR_STATE,
+          "traction grids have never been sampled: call mppi_tdm_sample_grids (or mppi_planner_solve) first");
+  if (p->packed_lin == lin && p->packed_ang == ang && p->packed_lin_grid == lin->grid_version &&
+      p->packed_ang_grid == ang->grid_version && p->packed_lin_maps == lin->maps_version)
+    return MPPI_OK;
+  const int M = p->cfg.num_grid_samples;
+  TRY(reserve_cells(p, lin, M));
+  // (another planner may have sampled these TDMs straight into ITS cell words)
+  TRY(tdm_materialize(lin, p->stream));
+  TRY(tdm_materialize(ang, p->stream));
+  p->cells16_valid = false;
+  if (M == 1) {
+    hipLaunchKernelGGL(k_pack_cells_single, dim3(ceil_div((long)lin->rows * lin->cols, 256)), dim3(256), 0,
+                       p->stream, lin->grid, ang->grid, lin->cfg.max_cols, lin->obs, lin->unk, lin->rows,
+                       lin->cols, p->cells);
+    auto grid_7bit = [](const mppi_tdm* t) {
+      return t->injected ? (t->injected_min >= 0) : t->compact_ok;
+    };
+    if (lin->compact_ok && grid_7bit(lin) && grid_7bit(ang)) {
+      p->pitch16 = ceil_div(lin->cols, 8) * 8;
+      // speed-map mode: 32-bit cells (16 bits + risk byte) in the same buffer, twice the 16-bit units
+      const bool with_risk = p->cfg.mode == MPPI_MODE_SPEED_MAP && lin->has_risk;
+      size_t need16 = (size_t)lin->rows * p->pitch16 * (with_risk ? 2 : 1);
+      if (need16 > p->cells16_capacity) {
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        dev_free(p->cells16);
+        p->cells16_capacity = 0;  // (stays 0 if the allocation below fails)
+        TRY(dev_alloc(&p->cells16, need16));
+        p->cells16_capacity = need16;
+      }
+      if (with_risk)
+        hipLaunchKernelGGL(k_pack_cells32_risk, dim3(ceil_div((long)lin->rows * p->pitch16, 256)), dim3(256), 0,
+                           p->stream, lin->grid, ang->grid, lin->cfg.max_cols, lin->obs, lin->unk, lin->risk,
+                           lin->rows, lin->cols, p->pitch16, reinterpret_cast<uint32_t*>(p->cells16));
+      else
+        hipLaunchKernelGGL(k_pack_cells16, dim3(ceil_div((long)need16, 256)), dim3(256), 0, p->stream, lin->grid,
+                           ang->grid, lin->cfg.max_cols, lin->obs, lin->unk, lin->rows, lin->cols, p->pitch16,
+                           p->cells16);
+      p->cells16_valid = true;
+      p->cells16_with_risk = with_risk;
+    }
+  } else {
+    dim3 grid((unsigned)(lin->rows * ceil_div(lin->cols, 64)), (unsigned)ceil_div(M, 64));
+    hipLaunchKernelGGL(k_pack_cells_multi, grid, dim3(256), 0, p->stream, lin->grid, ang->grid,
+                       lin->cfg.max_rows, lin->cfg.max_cols, lin->obs, lin->unk, lin->rows, lin->cols, M,
+                       p->cells);
+  }
+  HIP_TRY(hipGetLastError());
+  p->risk_ref = lin->risk;
+  p->packed_lin = lin;
+  p->packed_ang = ang;
+  p->packed_lin_grid = lin->grid_version;
+  p->packed_ang_grid = ang->grid_version;
+  if (p->packed_lin_maps != lin->maps_version) p->speculation_off = false;  // a new map: speculate again
+  p->packed_lin_maps = lin->maps_version;
+  return MPPI_OK;
+}
+
+// describe one noise generation (advances the Philox epoch)
+static NoiseJob make_noise_job(mppi_planner* p, float2* target) {
+  NoiseJob j;
+  j.out = target;
+  j.states = (p->cfg.rng == MPPI_RNG_XOROSHIRO) ? p->states : nullptr;
+  j.seed = p->cfg.seed;
+  // graph mode: the epoch is split into a by-value part that stays the same from one replay to
+  // the next and the device-side count of executed updates (bumps_launched mirrors it: every
+  // earlier update is ahead of this generator in stream order)
+  j.gen_counter = p->graph_on ? (const uint64_t*)p->gen_dev : nullptr;
+  j.epoch = p->graph_on ? p->noise_epoch - p->bumps_launched : p->noise_epoch;
+  j.n_local = p->n_local;
+  j.n_offset = p->n_offset;
+  j.n_steps = p->cfg.num_steps;
+  j.std0 = p->params.u_std[0];
+  j.std1 = p->params.u_std[1];
+  if (p->cfg.rng == MPPI_RNG_PHILOX) ++p->noise_epoch;
+  return j;
+}
+
+static int launch_noise(mppi_planner* p, float2* target, hipStream_t stream = nullptr) {
+  long total = (long)noise_items(p->n_local, p->cfg.num_steps, p->cfg.rng == MPPI_RNG_PHILOX);  // one thread per item
+  NoiseJob job = make_noise_job(p, target);
+  hipLaunchKernelGGL(k_noise, dim3(ceil_div(total, 256)), dim3(256), 0, stream ? stream : p->stream, job);
+  HIP_TRY(hipGetLastError());
+  return MPPI_OK;
+}
+
+// Decide whether the deterministic rollout can keep its map in LDS: the 16-bit cell
+// window must cover every cell reachable from x0 within the horizon and fit next to
+// the staged controls.  Fills the window fields of `d`.
+static bool plan_lds_window(mppi_planner* p, DevParams& d, size_t* lds_bytes) {
+  const int T = p->cfg.num_steps;
+  const size_t head = sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);
+  const size_t budget = (size_t)p->lds_per_cu - 1024;  // leave room for the runtime's own use
+  if (!p->cells16_valid) return false;
+  if (p->cfg.mode == MPPI_MODE_SPEED_MAP ? !p->cells16_with_risk : p->cfg.mode != MPPI_MODE_DET) return false;
+  const size_t cell_bytes = p->cells16_with_risk ? sizeof(uint32_t) : sizeof(uint16_t);
+  const mppi_params& a = p->params;
+  d.pitch16 = p->pitch16;
+  const size_t whole = (size_t)d.rows * p->pitch16 * cell_bytes;
+  // cells reachable from x0 within the horizon (plus a margin), columns in multiples of 8
+  double vmax = std::fmax(std::fabs((double)a.vrange[0]), std::fabs((double)a.vrange[1]));
+  double trmax = std::fmax(std::fabs(d.lin_lo), std::fabs(d.lin_lo + (double)d.lin_max_byte * d.lin_ratio));
+  double reach_m = (double)T * (double)a.dt * vmax * trmax;
+  size_t bytes = whole + 1;
+  long r0 = 0, r1 = d.rows, c0 = 0, c1 = p->pitch16;
+  if (p->inst_set) {
+    // batched handle: one window SIZE for all problems (the full reach square, clipped to the
+    // map size), one ORIGIN per problem, shifted inwards at the map border
+    for (BatchInst& I : p->inst_host) I.win_r0 = I.win_c0 = 0;
+    d.win_step_cells = std::isfinite(reach_m) ? (float)((double)a.dt * vmax * trmax / (double)a.res) : 0.0f;
+    d.win_progressive = std::isfinite(reach_m) ? 1 : 0;
+    if (std::isfinite(reach_m)) {
+      long reach = (long)std::ceil(reach_m / (double)a.res) + 2;
+      long wr = std::min((long)d.rows, 2 * reach + 1);
+      long wc = std::min((long)p->pitch16, (2 * reach + 1 + 7) / 8 * 8 + 8);
+      size_t wbytes = (size_t)wr * (size_t)wc * cell_bytes;
+      if (wbytes < whole) {
+        if (head + wbytes > budget) return false;
+        for (BatchInst& I : p->inst_host) {
+          long xi0 = (long)std::floor(((double)I.x0 - (double)a.xlo) / (double)a.res);
+          long yi0 = (long)std::floor(((double)I.y0 - (double)a.ylo) / (double)a.res);
+          I.win_r0 = (int)std::min(std::max(0L, yi0 - reach), (long)d.rows - wr);
+          I.win_c0 = (int)std::min(std::max(0L, xi0 - reach) / 8 * 8, (long)p->pitch16 - wc);
+        }
+        d.win_r0 = 0; d.win_c0 = 0; d.win_rows = (int)wr; d.win_cols = (int)wc;
+        *lds_bytes = head + wbytes;
+        return true;
+      }
+    }
+    if (head + whole > budget) return false;
+    d.win_r0 = 0; d.win_c0 = 0; d.win_rows = d.rows; d.win_cols = p->pitch16;
+    *lds_bytes = head + whole;
+    return true;
+  }
+  if (std::isfinite(reach_m)) {
+    long reach = (long)std::ceil(reach_m / (double)a.res) + 2;
+    long xi0 = (long)std::floor(((double)a.x0[0] - (double)a.xlo) / (double)a.res);
+    long yi0 = (long)std::floor(((double)a.x0[1] - (double)a.ylo) / (double)a.res);
+    r0 = std::max(0L, yi0 - reach);
+    r1 = std::min((long)d.rows, yi0 + reach + 1);
+    c0 = std::max(0L, xi0 - reach) / 8 * 8;
+    c1 = std::min((long)p->pitch16, (std::min((long)d.cols, xi0 + reach + 1) + 7) / 8 * 8);
+    if (r1 > r0 && c1 > c0) bytes = (size_t)(r1 - r0) * (size_t)(c1 - c0) * cell_bytes;
+  }
+  // (either way the rollouts spread at most step_cells per step: k_rollout_spec copies the window in
+  //  bands of rows as they go)
+  d.win_step_cells = std::isfinite(reach_m) ? (float)((double)a.dt * vmax * trmax / (double)a.res) : 0.0f;
+  d.win_progressive = std::isfinite(reach_m) ? 1 : 0;
+  if (bytes < whole) {  // the reach window is smaller: less to copy, more LDS left
+    if (head + bytes > budget) return false;
+    d.win_r0 = (int)r0; d.win_c0 = (int)c0; d.win_rows = (int)(r1 - r0); d.win_cols = (int)(c1 - c0);
+    *lds_bytes = head + bytes;
+    return true;
+  }
+  if (head + whole > budget) return false;
+  d.win_r0 = 0; d.win_c0 = 0; d.win_rows = d.rows; d.win_cols = p->pitch16;
+  *lds_bytes = head + whole;
+  return true;
+}
+
+// Waves (tiles of 64 rollouts) per workgroup of the one-wave-per-tile kernels that keep the map
+// window in LDS.  The window makes it one workgroup per CU, so the workgroup is sized to cover
+// the problem in one round: at least 4 waves (one per SIMD, and enough lanes to copy the
+// window), at most 16.  Batched handle: a workgroup stays inside one problem, i.e. the count
+// divides the tiles per problem -- among the divisors the one with the fewest rounds, then the
+// smallest (1536 tiles: 8 waves in 1 round, not 4 waves in 2; measured 130 -> 105 us).
+static int fused_waves_per_workgroup(const mppi_planner* p, int n_rollouts) {
+  const int tiles = ceil_div(n_rollouts, 64);
+  int waves = ceil_div(tiles, p->num_cus);
+  waves = waves < 4 ? 4 : (waves > 16 ? 16 : waves);
+  if (!p->inst_set) return waves;
+  auto pick = [&](int lowest) {
+    int best = 0, best_rounds = 1 << 30;
+    for (int d = lowest; d <= 16; ++d) {
+      if (p->inst_tiles % d != 0) continue;
+      const int rounds = ceil_div(ceil_div(tiles, d), p->num_cus);
+      if (rounds < best_rounds) { best = d; best_rounds = rounds; }  // ascending: ties keep the smallest
+    }
+    return best;
+  };
+  const int at_least_four = pick(4);
+  return at_least_four ? at_least_four : pick(1);
+}
+
+// per-problem start / goal / window origin -> device, when they changed
+static int upload_instances(mppi_planner* p) {
+  if (!p->inst_set || !p->inst_dirty) return MPPI_OK;
+  HIP_TRY(hipMemcpyAsync(p->inst_dev, p->inst_host.data(), sizeof(BatchInst) * (size_t)p->B,
+                         hipMemcpyHostToDevice, p->stream));
+  p->inst_dirty = false;
+  return MPPI_OK;
+}
+
+// Rollout and update launches go through the extended launch call: with p->kev_start / kev_stop
+// set (mppi_planner_time_kernels) the runtime stamps the dispatch's own begin / end -- what
+// rocprofv3 reads -- into those events; with both null it is an ordinary launch.
+#define MPPI_KLAUNCH(kernel, grid, block, lds, stream, ...) \
+  hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, p->kev_start, p->kev_stop, 0, __VA_ARGS__)
+
+
+// ---- k_rollout_scan (rollout_scan_kernel.h): the time-parallel rollout of MPPI_MATH_FAST --------
+// Eligible: deterministic-dynamics mode, 16-bit cells (the reference's own maps always are), a horizon
+// of at most 16 waves of 8 steps, LDS for the per-step records, and a map the speculation pays on.
+struct ScanPlan {
+  int waves = 0;       // 8 steps each = waves per workgroup
+  int tile = 32;       // rollouts per workgroup: 32 (two lanes per rollout) or 64
+  size_t lds = 0;
+  bool pow2res = false;
+};
+
+static bool scan_plan(const mppi_planner* p, ScanPlan* out) {
+  static const bool disabled = getenv("MPPI_NO_SCAN") != nullptr;  // developer switch (ablation)
+  if (disabled || (p->debug_flags & MPPI_DEBUG_NO_SCAN_KERNEL)) return false;
+  if (p->cfg.math != MPPI_MATH_FAST || p->cfg.mode != MPPI_MODE_DET) return false;
+  if (!p->cells16_valid || p->cells16_with_risk) return false;
+  if (p->speculation_off && !(p->debug_flags & MPPI_DEBUG_KEEP_SPECULATING)) return false;
+  const int T = p->cfg.num_steps;
+  ScanPlan plan;
+  plan.waves = ceil_div(T, 8);
+  if (plan.waves > 16) return false;
+  plan.tile = (p->debug_flags & MPPI_DEBUG_SCAN_FULL_TILES) ? 64 : 32;
+  plan.lds = plan.tile == 64 ? ScanLds<64>::total(plan.waves) : ScanLds<32>::total(plan.waves);
+  // (the accumulating wave reads up to two groups of records past the last one: keep that inside the allocation)
+  plan.lds = std::max(plan.lds, (size_t)40 * 1024);
+  if (plan.lds > (size_t)p->lds_per_cu - 1024) return false;
+  int res_exp = 0;
+  plan.pow2res = std::frexp((double)p->params.res, &res_exp) == 0.5;  // res == 2^k exactly
+  if (out) *out = plan;
+  return true;
+}
+
+// the iteration loop may let the rollout launch generate its own noise: Philox counters only
+static bool scan_generates_noise(const mppi_planner* p) {
+  static const bool disabled = getenv("MPPI_SCAN_READ_NOISE") != nullptr;  // developer switch (ablation)
+  return !disabled && !(p->debug_flags & MPPI_DEBUG_SCAN_READ_NOISE) && p->cfg.rng == MPPI_RNG_PHILOX &&
+         scan_plan(p, nullptr);
+}
+
+// the noise of the last iteration into noise_buf when it exists as counters only
+static int materialize_noise(mppi_planner* p) {
+  if (!p->noise_virtual) return MPPI_OK;
+  NoiseJob j;
+  memset(&j, 0, sizeof(j));
+  j.out = p->noise;
+  j.seed = p->cfg.seed;
+  j.epoch = p->noise_epoch - (uint64_t)p->noise_virtual_back;  // the block the last rollout launch consumed
+  j.n_local = p->n_local;
+  j.n_offset = p->n_offset;
+  j.n_steps = p->cfg.num_steps;
+  j.std0 = p->params.u_std[0];
+  j.std1 = p->params.u_std[1];
+  const long total = (long)noise_items(p->n_local, p->cfg.num_steps, true);
+  hipLaunchKernelGGL(k_noise, dim3(ceil_div(total, 256)), dim3(256), 0, p->stream, j);
+  HIP_TRY(hipGetLastError());
+  p->noise_virtual = false;
+  return MPPI_OK;
+}
+
+static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan) {
+  const int N = p->n_local, T = p->cfg.num_steps;
+  const int tiles = ceil_div(N, plan.tile);
+  if (!p->tnum) {  // (sized for the smaller tile)
+    const size_t cap = (size_t)ceil_div(N, 32);
+    TRY(dev_alloc(&p->tnum, (size_t)T * cap));
+    TRY(dev_alloc(&p->tden, cap));
+    TRY(dev_alloc(&p->tbeta, cap));
+  }
+  const bool gen = p->scan_gen_now;
+  ScanPackets pk;
+  pk.tnum = p->tnum;
+  pk.tden = p->tden;
+  pk.tbeta = p->tbeta;
+  pk.n_tiles = tiles;
+  NoiseJob gen_job, next_job;
+  memset(&gen_job, 0, sizeof(gen_job));
+  memset(&next_job, 0, sizeof(next_job));
+  int extra = 0;
+  if (gen) {
+    gen_job = make_noise_job(p, nullptr);  // (advances the Philox epoch: this iteration's block)
+  } else {
+    // a loop that stores its noise (debug switch; the stage-level calls): CUs without a workgroup
+    // produce the next iteration's, as in k_rollout_deep.  (Producing it in the launch's own tail, by
+    // the waves that idle while one wave accumulates the costs, was measured: the stage gained is lost
+    // again to the slower accumulation and the noise reads -- profiles/r03_scan_notes.md.)
+    static const bool no_fused_noise = getenv("MPPI_NO_FUSED_NOISE") != nullptr;  // developer switch
+    if (p->next_noise_wanted && tiles < p->num_cus && !no_fused_noise && p->cfg.rng == MPPI_RNG_PHILOX) {
+      extra = p->num_cus - tiles;
+      next_job = make_noise_job(p, p->noise_buf[p->noise_cur ^ 1]);
+      p->next_noise_done = true;
+    }
+  }
+  p->spec_tiles_launched += (uint64_t)tiles;
+#define MPPI_LAUNCH_SCAN(RR, P2, GEN)                                                                      \
+  do {                                                                                                    \
+    auto kern = k_rollout_scan<RR, P2, GEN>;                                                              \
+    if (plan.lds > 64 * 1024)                                                                             \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));            \
+    MPPI_KLAUNCH(kern, dim3(tiles + extra), dim3(64 * plan.waves), plan.lds, p->stream, d, p->cells16,    \
+                 p->noise, gen_job, p->u, p->costs, p->w_rel, pk, tiles, next_job);                        \
+  } while (0)
+#define MPPI_LAUNCH_SCAN_G(RR, P2)               \
+  do {                                           \
+    if (gen) MPPI_LAUNCH_SCAN(RR, P2, true);     \
+    else MPPI_LAUNCH_SCAN(RR, P2, false);        \
+  } while (0)
+  if (plan.tile == 64 && plan.pow2res) MPPI_LAUNCH_SCAN_G(64, true);
+  else if (plan.tile == 64) MPPI_LAUNCH_SCAN_G(64, false);
+  else if (plan.pow2res) MPPI_LAUNCH_SCAN_G(32, true);
+  else MPPI_LAUNCH_SCAN_G(32, false);
+#undef MPPI_LAUNCH_SCAN_G
+#undef MPPI_LAUNCH_SCAN
+  HIP_TRY(hipGetLastError());
+  char buf[256];
+  snprintf(buf, sizeof(buf),
+           "k_rollout_scan tile=%d waves=%d pow2res=%d noise=%s lds=%zu noise_blocks=%d problems=%d",
+           plan.tile, plan.waves, (int)plan.pow2res, gen ? "in-kernel" : "read", plan.lds, extra, p->inst_set ? p->B : 0);
+  p->last_rollout = buf;
+  p->tile_packets_fresh = false;  // (w_rel is relative to this kernel's own tiles: tbeta, not tile_beta)
+  p->scan_packets_fresh = true;
+  p->scan_tile = plan.tile;
+  p->noise_virtual = gen;
+  p->noise_virtual_back = 1 + (next_job.out ? 1 : 0);  // (the launch may have produced its successor's block too)
+  return MPPI_OK;
+}
+
+// ---- deterministic-dynamics mode: which rollout kernel runs ------------------
+// Decided per launch from measurements (profiles/r01_ablation.md, r02_stamps.md, r03_scan_notes.md):
+//   MPPI_MATH_FAST, 16-bit cells, T <= 128      k_rollout_scan   (time-parallel; launch_scan above)
+//   every tile of 64 rollouts can have a CU     k_rollout_deep   (five-stage speculative pipeline)
+//   up to two tiles per CU                      k_rollout_spec   (four-wave speculative pipeline)
+//   up to three                                 k_rollout_pipe   (exact three-wave schedule)
+//   beyond (throughput regime)                  k_rollout_fused  (one wave per tile, 4..16 per CU)
+//   no LDS window / no incremental trig         k_rollout_map    (general)
+// Each try_launch_* plans its LDS, launches when its regime applies and says so.
+struct DetRegime {
+  bool have_window;       // the 16-bit cell window reachable within the horizon fits in LDS
+  size_t lds_win;         // ... bytes of {staged controls, window}
+  bool rot_ok;            // incremental trig applies (|dt*w*traction| <= 0.36 rad, T <= 2000, exact math)
+  bool pow2res;           // resolution is a power of two: four-instruction cell coordinates
+  bool fast_deep_ok;      // MPPI_MATH_FAST: |theta| stays inside v_sin_f32's range
+  bool keep_speculating;  // the map has not (yet) proved the traction assumption a loss
+};
+
+template <bool EXACT>
+static int try_launch_deep(mppi_planner* p, DevParams& d, const DetRegime& r, bool* launched) {
+  *launched = false;
+  const int N = p->n_local, T = p->cfg.num_steps;
+  [[maybe_unused]] const bool have_window = r.have_window, rot_ok = r.rot_ok, pow2res = r.pow2res,
+                              fast_deep_ok = r.fast_deep_ok, keep_speculating = r.keep_speculating;
+  [[maybe_unused]] const size_t lds_win = r.lds_win;
+  static const bool no_pipe = getenv("MPPI_NO_PIPE") != nullptr;  // developer switch (ablation)
+  static const bool no_deep = getenv("MPPI_NO_DEEP") != nullptr;  // developer switch (ablation)
+  if (have_window && (EXACT ? rot_ok : fast_deep_ok) && !no_pipe && !no_deep && keep_speculating &&
+      !(p->debug_flags & (MPPI_DEBUG_NO_SPEC_KERNEL | MPPI_DEBUG_NO_DEEP_KERNEL)) &&
+      ceil_div(N, 64) <= p->num_cus) {
+    // five-stage speculative pipeline, one tile per CU (rollout_deep_kernel.h)
+    const size_t map_bytes = lds_win - sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);
+    const size_t Tp = ((size_t)T + 7) & ~(size_t)7;
+    const size_t head = sizeof(double2) * (Tp + Tp / 2);
+    const size_t budget = (size_t)p->lds_per_cu - 1024;
+    const size_t cc_bytes = Tp * 64 * sizeof(double);
+    // the exact re-execution path (pipe_tile_body<8>) lives in the same allocation
+    const size_t exact_need = lds_win + (size_t)PipeRing<8>::kBytesPerPair;
+    int chunk = 0;
+    auto ring_size = [](int c) {
+      return c == 8 ? (size_t)DeepRing<8>::kBytes : c == 4 ? (size_t)DeepRing<4>::kBytes : (size_t)DeepRing<2>::kBytes;
+    };
+    static const int forced_chunk = getenv("MPPI_DEEP_CHUNK") ? atoi(getenv("MPPI_DEEP_CHUNK")) : 0;  // developer switch
+    for (int cnd : {8, 4, 2})
+      if (head + map_bytes + ring_size(cnd) <= budget && (!forced_chunk || cnd <= forced_chunk)) { chunk = cnd; break; }
+    // (chunks of 8 with the control-cost products in LDS, else of 4 with them in LDS, else as found)
+    if (chunk == 8 && head + map_bytes + ring_size(8) + cc_bytes > budget &&
+        head + map_bytes + ring_size(4) + cc_bytes <= budget)
+      chunk = 4;
+    if (chunk > 0 && exact_need <= budget) {
+      const size_t rings = ring_size(chunk);
+      const size_t spec_need = head + map_bytes + rings;
+      const bool cc_lds = spec_need + cc_bytes <= budget && exact_need + (size_t)T * 64 * sizeof(double) <= budget &&
+                          !(p->debug_flags & MPPI_DEBUG_CC_GLOBAL);
+      const size_t lds_total = std::max(spec_need + (cc_lds ? cc_bytes : 0),
+                                        exact_need + (cc_lds ? (size_t)T * 64 * sizeof(double) : 0));
+      const int grid = ceil_div(N, 64);
+      NoiseJob next_job;
+      memset(&next_job, 0, sizeof(next_job));
+      int extra = 0;
+      static const bool no_fused_noise = getenv("MPPI_NO_FUSED_NOISE") != nullptr;  // developer switch
+      if (p->next_noise_wanted && grid < p->num_cus && !no_fused_noise) {  // (no spare CU otherwise: in line)
+        extra = p->num_cus - grid;
+        next_job = make_noise_job(p, p->noise_buf[p->noise_cur ^ 1]);
+        p->next_noise_done = true;
+      }
+      if (!cc_lds && !p->cc_scratch) TRY(dev_alloc(&p->cc_scratch, (size_t)ceil_div(N, 64) * 64 * T));
+      const int speculate = (p->debug_flags & MPPI_DEBUG_NO_SPECULATION) ? 0 : 1;
+      if (speculate) p->spec_tiles_launched += (uint64_t)ceil_div(N, 64);
+#define MPPI_LAUNCH_DEEP(CH, P2, CL)                                                                   \
+  do {                                                                                                \
+auto kern = k_rollout_deep<CH, P2, CL, !EXACT>;                                                   \
+if (lds_total > 64 * 1024)                                                                        \
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));       \
+MPPI_KLAUNCH(kern, dim3(grid + extra), dim3(64 * kDeepWaves), lds_total, p->stream, d,      \
+                   p->cells16, p->noise, p->u, p->costs, p->w_rel, p->tile_beta, p->cc_scratch,   \
+                   (int)map_bytes, grid, speculate, next_job);                                     \
+  } while (0)
+#define MPPI_LAUNCH_DEEP_C(P2, CL)            \
+  do {                                        \
+if (chunk == 8) MPPI_LAUNCH_DEEP(8, P2, CL);      \
+else if (chunk == 4) MPPI_LAUNCH_DEEP(4, P2, CL); \
+else MPPI_LAUNCH_DEEP(2, P2, CL);                 \
+  } while (0)
+      if (pow2res && cc_lds) MPPI_LAUNCH_DEEP_C(true, true);
+      else if (pow2res) MPPI_LAUNCH_DEEP_C(true, false);
+      else if (cc_lds) MPPI_LAUNCH_DEEP_C(false, true);
+      else MPPI_LAUNCH_DEEP_C(false, false);
+#undef MPPI_LAUNCH_DEEP_C
+#undef MPPI_LAUNCH_DEEP
+      char buf[320];
+      snprintf(buf, sizeof(buf),
+               "k_rollout_deep%s chunk=%d pow2res=%d cc_lds=%d speculate=%d window=%dx%d@(%d,%d) lds=%zu "
+               "noise_blocks=%d problems=%d",
+               EXACT ? "" : "<f32>", chunk, (int)pow2res, (int)cc_lds, speculate, d.win_rows, d.win_cols, d.win_r0, d.win_c0, lds_total,
+               extra, p->inst_set ? p->B : 0);
+      p->last_rollout = buf;
+      p->tile_packets_fresh = true;
+      *launched = true;
+      return MPPI_OK;
+    }
+  }
+  return MPPI_OK;
+}
+
+template <bool EXACT>
+static int try_launch_spec(mppi_planner* p, DevParams& d, const DetRegime& r, bool* launched) {
+  *launched = false;
+  const int N = p->n_local, T = p->cfg.num_steps;
+  [[maybe_unused]] const bool have_window = r.have_window, rot_ok = r.rot_ok, pow2res = r.pow2res,
+                              fast_deep_ok = r.fast_deep_ok, keep_speculating = r.keep_speculating;
+  [[maybe_unused]] const size_t lds_win = r.lds_win;
+  static const bool no_pipe = getenv("MPPI_NO_PIPE") != nullptr;  // developer switch (ablation)
+  static const bool no_spec = getenv("MPPI_NO_SPEC") != nullptr;  // developer switch (ablation)
+  if (have_window && rot_ok && !no_pipe && !no_spec && keep_speculating &&
+      !(p->debug_flags & MPPI_DEBUG_NO_SPEC_KERNEL)) {
+    // speculative 4-wave pipeline (rollout_spec_kernel.h): same regime as the pipelined kernel below
+    const size_t map_bytes = lds_win - sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);
+    // (this kernel pads the staged controls to a multiple of 8 steps)
+    const size_t Tp = ((size_t)T + 7) & ~(size_t)7;
+    const size_t lds_win = map_bytes + sizeof(double2) * (Tp + Tp / 2);
+    int tiles_wg = ceil_div(ceil_div(N, 64), p->num_cus);
+    if (tiles_wg < 1) tiles_wg = 1;
+    if (tiles_wg > 3) tiles_wg = 3;  // (three tiles per CU: the pipelined kernel below)
+    if (p->inst_set) while (p->inst_tiles % tiles_wg != 0) --tiles_wg;
+    const size_t budget = (size_t)p->lds_per_cu - 1024;
+    auto ring_bytes = [&](int chunk) {
+      const size_t per_tile = chunk == 8 ? SpecRing<8>::kBytesPerTile : chunk == 4 ? SpecRing<4>::kBytesPerTile
+                                                                                  : SpecRing<2>::kBytesPerTile;
+      return (size_t)tiles_wg * per_tile + 16;
+    };
+    int chunk = 0;
+    for (;;) {
+      for (int cnd : {8, 4, 2})
+        if (lds_win + ring_bytes(cnd) <= budget) { chunk = cnd; break; }
+      if (chunk > 0 || tiles_wg == 1) break;
+      --tiles_wg;
+      if (p->inst_set) while (p->inst_tiles % tiles_wg != 0) --tiles_wg;
+    }
+    const bool latency_regime = tiles_wg <= 2 && ceil_div(ceil_div(N, 64), tiles_wg) <= p->num_cus;
+    if (chunk > 0 && latency_regime) {
+      // (rows padded to whole chunks: the cost wave reads them at immediate offsets)
+      const size_t cc_bytes = (size_t)tiles_wg * ceil_div(T, chunk) * chunk * 64 * sizeof(double);
+      const bool cc_lds = lds_win + ring_bytes(chunk) + cc_bytes <= budget && !(p->debug_flags & MPPI_DEBUG_CC_GLOBAL);
+      const size_t lds_total = lds_win + ring_bytes(chunk) + (cc_lds ? cc_bytes : 0);
+      const int block = 256 * tiles_wg;
+      const int grid = ceil_div(N, 64 * tiles_wg);
+      NoiseJob next_job;
+      memset(&next_job, 0, sizeof(next_job));
+      int extra = 0;
+      static const bool no_fused_noise = getenv("MPPI_NO_FUSED_NOISE") != nullptr;  // developer switch
+      if (p->next_noise_wanted && grid < p->num_cus && !no_fused_noise) {  // (no spare CU otherwise: in line)
+        extra = p->num_cus - grid;
+        next_job = make_noise_job(p, p->noise_buf[p->noise_cur ^ 1]);
+        p->next_noise_done = true;
+      }
+      if (!cc_lds && !p->cc_scratch) TRY(dev_alloc(&p->cc_scratch, (size_t)ceil_div(N, 64) * 64 * T));
+      const int speculate = (p->debug_flags & MPPI_DEBUG_NO_SPECULATION) ? 0 : 1;
+      if (speculate) p->spec_tiles_launched += (uint64_t)ceil_div(N, 64);
+#define MPPI_LAUNCH_SPEC(CH, P2, CL)                                                                   \
+  do {                                                                                                \
+auto kern = tiles_wg == 1 ? k_rollout_spec<CH, P2, CL, 1> : k_rollout_spec<CH, P2, CL, 2>;        \
+if (lds_total > 64 * 1024)                                                                        \
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));       \
+MPPI_KLAUNCH(kern, dim3(grid + extra), dim3(block), lds_total, p->stream, d, p->cells16,    \
+                   p->noise, p->u, p->costs, p->w_rel, p->tile_beta, p->cc_scratch,                \
+                   (int)map_bytes, grid, speculate, next_job);                                     \
+  } while (0)
+#define MPPI_LAUNCH_SPEC_C(P2, CL)            \
+  do {                                        \
+if (chunk == 8) MPPI_LAUNCH_SPEC(8, P2, CL);      \
+else if (chunk == 4) MPPI_LAUNCH_SPEC(4, P2, CL); \
+else MPPI_LAUNCH_SPEC(2, P2, CL);                 \
+  } while (0)
+      if (pow2res && cc_lds) MPPI_LAUNCH_SPEC_C(true, true);
+      else if (pow2res) MPPI_LAUNCH_SPEC_C(true, false);
+      else if (cc_lds) MPPI_LAUNCH_SPEC_C(false, true);
+      else MPPI_LAUNCH_SPEC_C(false, false);
+#undef MPPI_LAUNCH_SPEC_C
+#undef MPPI_LAUNCH_SPEC
+      char buf[320];
+      snprintf(buf, sizeof(buf),
+               "k_rollout_spec chunk=%d pow2res=%d cc_lds=%d tiles_per_wg=%d speculate=%d window=%dx%d@(%d,%d) "
+               "progressive=%d lds=%zu noise_blocks=%d problems=%d",
+               chunk, (int)pow2res, (int)cc_lds, tiles_wg, speculate, d.win_rows, d.win_cols, d.win_r0, d.win_c0,
+               d.win_progressive, lds_total, extra, p->inst_set ? p->B : 0);
+      p->last_rollout = buf;
+      p->tile_packets_fresh = true;
+      *launched = true;
+      return MPPI_OK;
+    }
+  }
+  return MPPI_OK;
+}
+
+template <bool EXACT>
+static int try_launch_pipe(mppi_planner* p, DevParams& d, const DetRegime& r, bool* launched) {
+  *launched = false;
+  const int N = p->n_local, T = p->cfg.num_steps;
+  [[maybe_unused]] const bool have_window = r.have_window, rot_ok = r.rot_ok, pow2res = r.pow2res,
+                              fast_deep_ok = r.fast_deep_ok, keep_speculating = r.keep_speculating;
+  [[maybe_unused]] const size_t lds_win = r.lds_win;
+  static const bool no_pipe = getenv("MPPI_NO_PIPE") != nullptr;  // developer switch (ablation)
+  if (have_window && rot_ok && !no_pipe) {
+    // pipelined kernel: the map window in LDS + the incremental trig
+    const size_t map_bytes = lds_win - sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);
+    int pairs = ceil_div(ceil_div(N, 64), p->num_cus);  // wave triples per workgroup
+    if (pairs < 1) pairs = 1;
+    if (pairs > 5) pairs = 5;                            // 15 waves = 960 threads
+    // batched handle: the triples of a workgroup share one problem's window and controls
+    if (p->inst_set) while (p->inst_tiles % pairs != 0) --pairs;
+    const size_t budget = (size_t)p->lds_per_cu - 1024;
+    auto ring_bytes = [&](int chunk) {
+      return (size_t)pairs * (2 * (size_t)chunk * 64 * (sizeof(float2) + sizeof(double2)) + 2 * (size_t)chunk * 64);
+    };
+    int chunk = 0;
+    for (;;) {  // fewer triples per workgroup (more workgroups than CUs) before giving the kernel up
+      for (int cnd : {8, 4, 2})
+        if (lds_win + ring_bytes(cnd) <= budget) { chunk = cnd; break; }
+      if (chunk > 0 || pairs == 1) break;
+      --pairs;
+      if (p->inst_set) while (p->inst_tiles % pairs != 0) --pairs;
+    }
+    // The pipelined kernel is the low-latency choice: it wins while one workgroup per CU covers
+    // the problem with at most three triples (measured, profiles/r01_ablation.md: 1 triple
+    // 53 vs 79 us, 2 triples 76 vs 83 us, 4 triples a tie, two rounds 162 vs 88 us at T=200).
+    // Beyond that the fused kernel below, 4..16 waves per CU, has the better throughput.
+    const bool latency_regime = pairs <= 3 && ceil_div(ceil_div(N, 64), pairs) <= p->num_cus;
+    if (chunk > 0 && latency_regime) {
+      // control-cost products in LDS when there is room, else in a global scratch array
+      const size_t cc_bytes = (size_t)pairs * T * 64 * sizeof(double);
+      const bool cc_lds = lds_win + ring_bytes(chunk) + cc_bytes <= budget;
+      const size_t lds_total = lds_win + ring_bytes(chunk) + (cc_lds ? cc_bytes : 0);
+      const int block = 192 * pairs;
+      const int grid = ceil_div(N, 64 * pairs);
+      // spare CUs generate the next iteration's noise inside this launch
+      NoiseJob next_job;
+      memset(&next_job, 0, sizeof(next_job));
+      int extra = 0;
+      static const bool no_fused_noise = getenv("MPPI_NO_FUSED_NOISE") != nullptr;  // developer switch
+      if (p->next_noise_wanted && grid < p->num_cus && !no_fused_noise) {  // (no spare CU otherwise: in line)
+        extra = p->num_cus - grid;
+        next_job = make_noise_job(p, p->noise_buf[p->noise_cur ^ 1]);
+        p->next_noise_done = true;
+      }
+      if (!cc_lds && !p->cc_scratch) TRY(dev_alloc(&p->cc_scratch, (size_t)ceil_div(N, 64) * 64 * T));
+#define MPPI_LAUNCH_PIPE(CH, P2, CL)                                                                  \
+  do {                                                                                                \
+auto kern = k_rollout_pipe<CH, P2, CL>;                                                           \
+if (lds_total > 64 * 1024)                                                                        \
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));       \
+MPPI_KLAUNCH(kern, dim3(grid + extra), dim3(block), lds_total, p->stream, d, p->cells16,    \
+                   p->noise, p->u, p->costs, p->w_rel, p->tile_beta, p->cc_scratch,                \
+                   (int)map_bytes, grid, next_job);                                                \
+  } while (0)
+#define MPPI_LAUNCH_PIPE_C(P2, CL)            \
+  do {                                        \
+if (chunk == 8) MPPI_LAUNCH_PIPE(8, P2, CL);      \
+else if (chunk == 4) MPPI_LAUNCH_PIPE(4, P2, CL); \
+else MPPI_LAUNCH_PIPE(2, P2, CL);                 \
+  } while (0)
+      if (pow2res && cc_lds) MPPI_LAUNCH_PIPE_C(true, true);
+      else if (pow2res) MPPI_LAUNCH_PIPE_C(true, false);
+      else if (cc_lds) MPPI_LAUNCH_PIPE_C(false, true);
+      else MPPI_LAUNCH_PIPE_C(false, false);
+#undef MPPI_LAUNCH_PIPE_C
+      {
+        char buf[256];
+        snprintf(buf, sizeof(buf),
+                 "k_rollout_pipe chunk=%d pow2res=%d cc_lds=%d triples_per_wg=%d window=%dx%d@(%d,%d) lds=%zu "
+                 "noise_blocks=%d problems=%d",
+                 chunk, (int)pow2res, (int)cc_lds, pairs, d.win_rows, d.win_cols, d.win_r0, d.win_c0, lds_total,
+                 extra, p->inst_set ? p->B : 0);
+        p->last_rollout = buf;
+      }
+#undef MPPI_LAUNCH_PIPE
+      p->tile_packets_fresh = true;
+      *launched = true;
+      return MPPI_OK;
+    }
+  }
+  return MPPI_OK;
+}
+
+template <bool EXACT, bool BOUNDED>
+static int launch_windowed_or_general(mppi_planner* p, DevParams& d, const DetRegime& r) {
+  const int N = p->n_local, T = p->cfg.num_steps;
+  [[maybe_unused]] const bool have_window = r.have_window, rot_ok = r.rot_ok, pow2res = r.pow2res,
+                              fast_deep_ok = r.fast_deep_ok, keep_speculating = r.keep_speculating;
+  [[maybe_unused]] const size_t lds_win = r.lds_win;
+  const size_t lds_map = sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);  // + staged u[t]
+  static const bool no_window = getenv("MPPI_NO_WINDOW") != nullptr;  // developer switch (ablation)
+  if (have_window && !no_window) {
+    // the window makes it one workgroup per CU: size the workgroup so that the grid
+    // is at most one wave of workgroups over the CUs
+    // (at least 4 waves: one per SIMD, and four times the lanes to copy the window)
+    const int waves = fused_waves_per_workgroup(p, N);
+    int block = 64 * waves;
+    static const bool no_fused = getenv("MPPI_NO_FUSED") != nullptr;  // developer switch (ablation)
+    if (rot_ok && !no_fused) {
+      auto fused = pow2res ? k_rollout_fused<true> : k_rollout_fused<false>;
+      if (lds_win > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fused),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
+      MPPI_KLAUNCH(fused, dim3(ceil_div(N, block)), dim3(block), lds_win, p->stream, d, p->cells16,
+                         p->noise, p->u, p->costs, p->w_rel, p->tile_beta);
+      char buf[200];
+      snprintf(buf, sizeof(buf), "k_rollout_fused pow2res=%d waves_per_wg=%d window=%dx%d problems=%d",
+               (int)pow2res, waves, d.win_rows, d.win_cols, p->inst_set ? p->B : 0);
+      p->last_rollout = buf;
+      p->tile_packets_fresh = true;
+            return MPPI_OK;
+    }
+    auto kern = k_rollout_map<MAP_DET, EXACT, BOUNDED, true>;
+    if (lds_win > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
+    MPPI_KLAUNCH(kern, dim3(ceil_div(N, block)), dim3(block), lds_win, p->stream, d, p->cells,
+                       p->cells16, (const int8_t*)nullptr, p->noise, p->u, p->costs);
+    {
+      char buf[200];
+      snprintf(buf, sizeof(buf), "k_rollout_map det lds_window exact=%d waves_per_wg=%d window=%dx%d problems=%d",
+               (int)EXACT, waves, d.win_rows, d.win_cols, p->inst_set ? p->B : 0);
+      p->last_rollout = buf;
+    }
+  } else {
+    MPPI_KLAUNCH((k_rollout_map<MAP_DET, EXACT, BOUNDED, false>), dim3(ceil_div(N, 64)), dim3(64),
+                       lds_map, p->stream, d, p->cells, (const uint16_t*)nullptr, (const int8_t*)nullptr,
+                       p->noise, p->u, p->costs);
+    p->last_rollout = "k_rollout_map det global_cells exact=" + std::to_string((int)EXACT);
+  }
+  return MPPI_OK;
+}
+
+template <bool EXACT, bool BOUNDED>
+static int launch_rollout_det(mppi_planner* p, DevParams d) {
+  const int T = p->cfg.num_steps;
+  p->tile_packets_fresh = false;
+  size_t lds_win = 0;
+  bool have_window = plan_lds_window(p, d, &lds_win);
+  TRY(upload_instances(p));
+  if (!EXACT) {
+    ScanPlan plan;
+    if (scan_plan(p, &plan)) return launch_scan(p, d, plan);
+  }
+  // incremental trig: needs a heading increment |dt*w*traction| <= 0.36 rad and T <= 2000
+  bool rot_ok = false, pow2res = false;
+  {
+    const mppi_params& a = p->params;
+    double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
+    double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
+    double dmax = (double)a.dt * wmax * trmax;
+    rot_ok = EXACT && BOUNDED && std::isfinite(dmax) && dmax <= 0.36 && T <= 2000;
+    int res_exp = 0;
+    pow2res = std::frexp((double)a.res, &res_exp) == 0.5;  // res == 2^k exactly
+  }
+  // MPPI_MATH_FAST: the same five-stage pipeline in float32 (hardware sin / cos: |theta| must stay
+  // inside v_sin_f32's +-256 revolutions)
+  bool fast_deep_ok = false;
+  if (!EXACT) {
+    const mppi_params& a = p->params;
+    double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
+    double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
+    double th0_max = std::fabs((double)a.x0[2]);
+    if (p->inst_set) for (const BatchInst& I : p->inst_host) th0_max = std::fmax(th0_max, std::fabs((double)I.th0));
+    const double bound = th0_max + (double)T * (double)a.dt * wmax * trmax;
+    fast_deep_ok = std::isfinite(bound) && bound < 1500.0 && T <= 2000;
+  }
+  const bool keep_speculating = !p->speculation_off || (p->debug_flags & MPPI_DEBUG_KEEP_SPECULATING);
+  DetRegime r;
+  r.have_window = have_window; r.lds_win = lds_win; r.rot_ok = rot_ok; r.pow2res = pow2res;
+  r.fast_deep_ok = fast_deep_ok; r.keep_speculating = keep_speculating;
+  bool launched = false;
+  TRY(try_launch_deep<EXACT>(p, d, r, &launched));
+  if (!launched) TRY(try_launch_spec<EXACT>(p, d, r, &launched));
+  if (!launched) TRY(try_launch_pipe<EXACT>(p, d, r, &launched));
+  if (!launched) TRY((launch_windowed_or_general<EXACT, BOUNDED>(p, d, r)));
+  HIP_TRY(hipGetLastError());
+  return MPPI_OK;
+}
+
+template <bool EXACT, bool BOUNDED>
+static int launch_rollout_speed_map(mppi_planner* p, DevParams d) {
+  const int N = p->n_local, T = p->cfg.num_steps;
+  [[maybe_unused]] const int M = p->cfg.num_grid_samples;
+  [[maybe_unused]] size_t lds = sizeof(double2) * (size_t)T;
+  [[maybe_unused]] const size_t lds_map = sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);  // + staged u[t]
+  p->tile_packets_fresh = false;
+  size_t lds_win = 0;
+  const bool have_window = plan_lds_window(p, d, &lds_win);  // 32-bit cells: 16 bits + risk byte
+  TRY(upload_instances(p));
+  const mppi_params& a = p->params;
+  double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
+  double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
+  double dmax = (double)a.dt * wmax * trmax;
+  static const bool no_fused = getenv("MPPI_NO_FUSED") != nullptr;  // developer switch (ablation)
+  if (have_window && EXACT && BOUNDED && std::isfinite(dmax) && dmax <= 0.36 && T <= 2000 && !no_fused) {
+    const int waves = fused_waves_per_workgroup(p, N);
+    int res_exp = 0;
+    const bool pow2res = std::frexp((double)a.res, &res_exp) == 0.5;
+    auto fused = pow2res ? k_rollout_fused<true, true> : k_rollout_fused<false, true>;
+    if (lds_win > 64 * 1024)
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fused),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
+    MPPI_KLAUNCH(fused, dim3(ceil_div(N, 64 * waves)), dim3(64 * waves), lds_win, p->stream, d, p->cells16,
+                       p->noise, p->u, p->costs, p->w_rel, p->tile_beta);
+    char buf[200];
+    snprintf(buf, sizeof(buf), "k_rollout_fused speed_map pow2res=%d waves_per_wg=%d window=%dx%d problems=%d",
+             (int)pow2res, waves, d.win_rows, d.win_cols, p->inst_set ? p->B : 0);
+    p->last_rollout = buf;
+    p->tile_packets_fresh = true;
+    HIP_TRY(hipGetLastError());
+    return MPPI_OK;
+  }
+  MPPI_KLAUNCH((k_rollout_map<MAP_SPEED, EXACT, BOUNDED, false>), dim3(ceil_div(N, 64)), dim3(64),
+                     lds_map, p->stream, d, p->cells, (const uint16_t*)nullptr, (const int8_t*)p->risk_ref,
+                     p->noise, p->u, p->costs);
+  p->last_rollout = "k_rollout_map speed_map global_cells exact=" + std::to_string((int)EXACT);
+  HIP_TRY(hipGetLastError());
+  return MPPI_OK;
+}
+
+template <bool EXACT, bool BOUNDED>
+static int launch_rollout_tdm(mppi_planner* p, DevParams d) {
+  const int N = p->n_local, T = p->cfg.num_steps;
+  [[maybe_unused]] const int M = p->cfg.num_grid_samples;
+  [[maybe_unused]] size_t lds = sizeof(double2) * (size_t)T;
+  [[maybe_unused]] const size_t lds_map = sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);  // + staged u[t]
+  int mp2 = next_pow2(M);
+  int threads = ceil_div(M, 64) * 64;
+  if (threads > 1024) threads = 1024;
+  lds += sizeof(float) * (size_t)mp2;
+  REQUIRE(lds <= 160 * 1024, MPPI_ERR_INVALID, "T=%d, M=%d need %zu bytes of LDS (> 160 KiB)", T, M, lds);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout_tdm<EXACT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if (p->want_sample_costs && !p->sample_costs && p->m_count == 1) TRY(dev_alloc(&p->sample_costs, (size_t)N * M));
+  if (p->m_count > 1 && !p->slabs) TRY(dev_alloc(&p->slabs, (size_t)p->m_count * N * M));
+  // sharded samples: the per-sample costs go into this rank's slab of the gather buffer
+  float* const sc_dst = p->m_count > 1 ? p->slabs + (size_t)p->m_rank * N * M
+                                       : (p->want_sample_costs ? p->sample_costs : nullptr);
+  p->tile_packets_fresh = false;
+  TRY(upload_instances(p));
+  {
+    const mppi_params& a = p->params;
+    double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
+    double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
+    double dmax = (double)a.dt * wmax * trmax;
+    const size_t lds_fast = (sizeof(double2) + sizeof(double)) * (size_t)T + sizeof(float) * (size_t)mp2;
+    if (EXACT && BOUNDED && std::isfinite(dmax) && dmax <= 0.36 && T <= 2000 && lds_fast <= 64 * 1024) {
+      int res_exp = 0;
+      const bool pow2res = std::frexp((double)a.res, &res_exp) == 0.5;
+      float* sc_out = sc_dst;
+      // the next iteration's noise by workgroups appended to the grid (they run in the launch's tail)
+      NoiseJob next_job;
+      memset(&next_job, 0, sizeof(next_job));
+      int extra = 0;
+      static const bool no_fused_noise = getenv("MPPI_NO_FUSED_NOISE") != nullptr;  // developer switch
+      if (p->next_noise_wanted && !no_fused_noise && p->cfg.rng == MPPI_RNG_PHILOX) {
+        const long rows = (long)(noise_items(p->n_local, T, true) >> 6);
+        extra = (int)std::min<long>(2L * p->num_cus, ceil_div(rows, (long)(threads / 64) * 4));
+        if (extra > 0) {
+          next_job = make_noise_job(p, p->noise_buf[p->noise_cur ^ 1]);
+          p->next_noise_done = true;
+        }
+      }
+      if (pow2res)
+        MPPI_KLAUNCH((k_rollout_tdm_fast<true>), dim3(N + extra), dim3(threads), lds_fast, p->stream, d, p->cells,
+                           p->noise, p->u, p->costs, sc_out, mp2, N, next_job);
+      else
+        MPPI_KLAUNCH((k_rollout_tdm_fast<false>), dim3(N + extra), dim3(threads), lds_fast, p->stream, d, p->cells,
+                           p->noise, p->u, p->costs, sc_out, mp2, N, next_job);
+      p->last_rollout = std::string("k_rollout_tdm_fast pow2res=") + (pow2res ? "1" : "0") +
+                        " noise_blocks=" + std::to_string(extra);
+      HIP_TRY(hipGetLastError());
+      return MPPI_OK;
+    }
+  }
+  MPPI_KLAUNCH((k_rollout_tdm<EXACT>), dim3(N), dim3(threads), lds, p->stream, d, p->cells, p->noise,
+                     p->u, p->costs, sc_dst, mp2);
+  p->last_rollout = "k_rollout_tdm exact=" + std::to_string((int)EXACT);
+  HIP_TRY(hipGetLastError());
+  return MPPI_OK;
+}
+
+template <bool EXACT, bool BOUNDED>
+static int launch_rollout_t(mppi_planner* p, DevParams d) {
+  p->scan_packets_fresh = false;
+  if (p->noise_virtual && !p->scan_gen_now) TRY(materialize_noise(p));  // the coming kernel reads its noise
+  switch (p->cfg.mode) {
+    case MPPI_MODE_DET: return launch_rollout_det<EXACT, BOUNDED>(p, d);
+    case MPPI_MODE_SPEED_MAP: return launch_rollout_speed_map<EXACT, BOUNDED>(p, d);
+    case MPPI_MODE_TDM: return launch_rollout_tdm<EXACT, BOUNDED>(p, d);
+    case MPPI_MODE_BAREBONE: {
+      const int N = p->n_local;
+      p->tile_packets_fresh = false;
+      MPPI_KLAUNCH((k_rollout_barebone<EXACT>), dim3(ceil_div(N, 64)), dim3(64), sizeof(double2) * (size_t)p->cfg.num_steps,
+                   p->stream, d, p->obs_pos, p->obs_r, p->noise, p->u, p->costs);
+      p->last_rollout = "k_rollout_barebone exact=" + std::to_string((int)EXACT);
+      break;
+    }
+    default:
+      return fail(MPPI_ERR_INVALID, "bad mode");
+  }
+  HIP_TRY(hipGetLastError());
+  return MPPI_OK;
+}
+
+
+static int launch_rollout(mppi_planner* p, const DevParams& d) {
+  REQUIRE(p->B == 1 || p->inst_set, MPPI_ERR_STATE,
+          "num_instances = %d: call mppi_planner_set_instances before solving", p->B);
+  REQUIRE((size_t)p->cfg.num_steps * sizeof(double2) <= 64 * 1024, MPPI_ERR_INVALID, "num_steps %d too large",
+          p->cfg.num_steps);
+  // |theta| can never exceed |theta0| + T*dt*max|w|*max(traction): when that is far
+  // inside the range of the two-term pi/2 reduction, the kernels drop the libm branch
+  const mppi_params& a = p->params;
+  double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
+  double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
+  if (p->cfg.mode == MPPI_MODE_BAREBONE) trmax = 1.0;
+  double th0_max = std::fabs((double)a.x0[2]);
+  if (p->inst_set) {
+    th0_max = 0.0;
+    for (const BatchInst& I : p->inst_host) th0_max = std::fmax(th0_max, std::fabs((double)I.th0));
+  }
+  double theta_bound = th0_max + (double)p->cfg.num_steps * (double)a.dt * wmax * trmax;
+  bool bounded = std::isfinite(theta_bound) && theta_bound < 5.0e4;
+  if (p->cfg.math != MPPI_MATH_EXACT) return launch_rollout_t<false, false>(p, d);
+  return bounded ? launch_rollout_t<true, true>(p, d) : launch_rollout_t<true, false>(p, d);
+}
+
+// tile-relative weights (unless the rollout kernel just emitted them) + the row kernel:
+// applies the update on a single GPU; with several GPUs leaves this rank's packet in
+// packets[rank] for the exchange
+// ---- CVaR mode, samples sharded over GPUs: all-gather of the (N, M/G) cost slabs, then every
+//      rank reduces all N control samples over all M costs ---------------
+static int cvar_numel(const mppi_planner* p) {
+  const int M = p->cfg.num_grid_samples * p->m_count;
+  int numel = (int)std::ceil((double)M * (double)p->params.cvar_alpha);  // mppi.py:716-717 over all M samples
+  return numel < 1 ? 1 : (numel > M ? M : numel);
+}
+
+static int launch_cvar_reduce(mppi_planner* p) {
+  const int N = p->n_local, Ml = p->cfg.num_grid_samples, M = Ml * p->m_count;
+  const int mp2 = next_pow2(M);
+  const int threads = mp2 > 1024 ? 1024 : (mp2 < 64 ? 64 : mp2);  // one element per thread when it fits
+  const size_t lds = sizeof(float) * (size_t)mp2;
+  REQUIRE(lds <= 64 * 1024, MPPI_ERR_INVALID, "M = %d samples over all shards: too many for the CVaR reduction", M);
+  if (p->want_sample_costs && p->sample_costs == nullptr) TRY(dev_alloc(&p->sample_costs, (size_t)N * M));
+  hipLaunchKernelGGL(k_cvar_reduce, dim3(N), dim3(threads), lds, p->stream, p->slabs, p->m_count, N, Ml, cvar_numel(p),
+                     p->params.cvar_alpha, p->costs, p->want_sample_costs ? p->sample_costs : (float*)nullptr, mp2);
+  HIP_TRY(hipGetLastError());
+  p->tile_packets_fresh = false;
+  p->sample_costs_local_only = false;
+  return MPPI_OK;
+}
+
+// inside the iteration loop: RCCL all-gather of the slabs on the planner's stream, then the reduction
+static int exchange_sample_costs(mppi_planner* p) {
+  if (p->m_count <= 1) return MPPI_OK;
+  REQUIRE(p->comm, MPPI_ERR_STATE,
+          "samples sharded over %d ranks but no communicator: call mppi_planner_comm_init "
+          "(or drive rollout / sample_costs_local / sample_costs_apply / update yourself)", p->m_count);
+  const size_t len = (size_t)p->n_local * p->cfg.num_grid_samples;
+  RCCL_TRY(g_rccl.AllGather(p->slabs + (size_t)p->m_rank * len, p->slabs, len, ncclFloat, p->comm, p->stream));
+  return launch_cvar_reduce(p);
+}
+
+static int launch_update_local(mppi_planner* p, bool apply_here) {
+  const int N = p->n_local, T = p->cfg.num_steps;
+  const mppi_params& a = p->params;
+  double* my_packet = p->packets + (size_t)p->cfg.rank * p->B * packet_len(T);
+  if (p->scan_packets_fresh) {
+    // the rollout launch (k_rollout_scan) has reduced w_rel * noise over every tile: combine the tiles
+    p->scan_packets_fresh = false;
+    p->tile_packets_fresh = false;
+    const dim3 grid(T, p->B);
+    unsigned long long* gen = p->graph_on ? p->gen_dev : (unsigned long long*)nullptr;
+    const int per_problem = ceil_div(p->n_inst, p->scan_tile), total = ceil_div(p->n_local, p->scan_tile);
+    if (apply_here)
+      MPPI_KLAUNCH((k_combine_tiles<true>), grid, dim3(64), 0, p->stream, p->tbeta, p->tden, p->tnum, per_problem, total,
+                   T, a.lambda_weight, my_packet, p->u, p->u_prev, (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0], a.vrange[1],
+                   a.wrange[0], a.wrange[1], p->stats, gen);
+    else
+      MPPI_KLAUNCH((k_combine_tiles<false>), grid, dim3(64), 0, p->stream, p->tbeta, p->tden, p->tnum, per_problem, total,
+                   T, a.lambda_weight, my_packet, p->u, p->u_prev, (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0], a.vrange[1],
+                   a.wrange[0], a.wrange[1], p->stats, gen);
+    if (p->graph_on) ++p->bumps_launched;
+    HIP_TRY(hipGetLastError());
+    return MPPI_OK;
+  }
+  if (p->noise_virtual) TRY(materialize_noise(p));  // the row kernel streams the noise
+  // rollout kernels without the weight epilogue: the row kernel forms the tile weights itself
+  // from the costs (same bits) unless there are too many tiles for its LDS arrays
+  const bool from_costs = !p->tile_packets_fresh && 2 * sizeof(float) * (size_t)p->inst_tiles <= 60 * 1024;
+  if (!p->tile_packets_fresh && !from_costs)
+    MPPI_KLAUNCH(k_tile_weights, dim3(p->n_tiles), dim3(64), 0, p->stream, p->costs, N, a.lambda_weight,
+                       p->w_rel, p->tile_beta);
+  p->tile_packets_fresh = false;
+  const size_t lds = sizeof(float) * (size_t)p->inst_tiles * (from_costs ? 2 : 1);
+  REQUIRE(lds <= 60 * 1024, MPPI_ERR_INVALID, "too many rollouts per GPU for the update kernel (%d)", N);
+  // rows per workgroup: see k_update_rows
+  const bool many_rows = (long)T * p->B >= 2048;
+  const dim3 grid(many_rows ? ceil_div(T, 4) : T, p->B);
+#define MPPI_LAUNCH_ROWS(APPLY, TC, FC)                                                                         \
+  MPPI_KLAUNCH((k_update_rows<APPLY, TC, FC>), grid, dim3(kRowThreads), lds, p->stream,                   \
+                     FC ? p->costs : p->w_rel, p->tile_beta, p->n_inst, p->inst_tiles, p->noise, T,             \
+                     a.lambda_weight, my_packet, p->u, p->u_prev, (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0], a.vrange[1],      \
+                     a.wrange[0], a.wrange[1], p->stats, p->graph_on ? p->gen_dev : (unsigned long long*)nullptr)
+#define MPPI_LAUNCH_ROWS_TC(APPLY, FC)        \
+  do {                                        \
+    if (many_rows) MPPI_LAUNCH_ROWS(APPLY, 4, FC); \
+    else MPPI_LAUNCH_ROWS(APPLY, 1, FC);           \
+  } while (0)
+  if (apply_here && from_costs) MPPI_LAUNCH_ROWS_TC(true, true);
+  else if (apply_here) MPPI_LAUNCH_ROWS_TC(true, false);
+  else if (from_costs) MPPI_LAUNCH_ROWS_TC(false, true);
+  else MPPI_LAUNCH_ROWS_TC(false, false);
+#undef MPPI_LAUNCH_ROWS_TC
+#undef MPPI_LAUNCH_ROWS
+  if (p->graph_on) ++p->bumps_launched;
+  HIP_TRY(hipGetLastError());
+  return MPPI_OK;
+}
+
+static int launch_apply(mppi_planner* p) {
+  const mppi_params& a = p->params;
+  hipLaunchKernelGGL(k_apply, dim3(p->B), dim3(kUpdateThreads), 0, p->stream, p->packets, p->cfg.world_size,
+                     p->cfg.rank, p->cfg.num_steps, a.lambda_weight, p->u, p->u_prev, (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0],
+                     a.vrange[1], a.wrange[0], a.wrange[1], p->stats);
+  HIP_TRY(hipGetLastError());
+  return MPPI_OK;
+}
+
+// `defer_exchange` (mppi_group_iterate_async): stop after this rank's packet; the caller issues the
+// all-gathers of all its devices inside one RCCL group and then launches k_apply on each
+static int launch_update(mppi_planner* p, bool prof, bool defer_exchange = false) {
+  p->mirror_done = p->mirror_now;
+  if (defer_exchange) return launch_update_local(p, false);
+  // (a communicator on a single rank is honoured too: it exercises the same path as N ranks)
+  // (samples sharded: every rank holds all N costs and all the noise -- the update is local)
+  if ((p->cfg.world_size == 1 && !p->comm) || p->m_count > 1) {
+    TRY(launch_update_local(p, true));
+    if (prof) {
+      HIP_TRY(hipEventRecord(p->ev_stage[3], p->stream));
+      HIP_TRY(hipEventRecord(p->ev_stage[4], p->stream));
+    }
+    return MPPI_OK;
+  }
+  REQUIRE(p->comm, MPPI_ERR_STATE,
+          "world_size %d but no communicator: call mppi_planner_comm_init (or use update_local/update_apply)",
+          p->cfg.world_size);
+  TRY(launch_update_local(p, false));
+  const int len = p->B * packet_len(p->cfg.num_steps);
+  if (prof) HIP_TRY(hipEventRecord(p->ev_stage[3], p->stream));
+  // one all-gather of (2T+2) doubles per problem and iteration, in place
+  TraceRange tr("mppi:all_gather_packets");
+  RCCL_TRY(g_rccl.AllGather(p->packets + (size_t)p->cfg.rank * len, p->packets, (size_t)len, ncclDouble, p->comm,
+                            p->stream));
+  if (prof) HIP_TRY(hipEventRecord(p->ev_stage[4], p->stream));
+  return launch_apply(p);
+}
+
+// One iteration: {noise unless it was produced ahead, rollout (+ the next iteration's noise when
+// `want_next`), update}.  `have_noise`: noise_buf[noise_cur ^ 1] already holds this iteration's
+// noise; on return it says the same for the following iteration.
+static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_noise, bool want_next, bool prof,
+                            bool defer_exchange = false) {
+  // (below ~4M rollout-steps the generator takes less than the ~12 us a cross-stream dependency costs)
+  static const bool no_side_stream = getenv("MPPI_NO_SIDE_STREAM") != nullptr;  // developer switch
+  // and above 8 rollout waves per CU the register file has no room for the generator's waves: it
+  // then runs in the rollout's tail and collides with the update (measured, profiles/r01_ablation.md)
+  const bool side_stream_pays = (long)p->n_local * p->cfg.num_steps >= 4L * 1000 * 1000 &&
+                                ceil_div(ceil_div(p->n_local, 64), p->num_cus) <= 8 && !no_side_stream;
+  if (prof) HIP_TRY(hipEventRecord(p->ev_stage[0], p->stream));
+  // MPPI_MATH_FAST over a map the time-parallel kernel takes: the rollout launch computes its noise
+  // from the Philox counters itself; nothing is generated ahead, nothing is stored
+  const bool gen_in_rollout = scan_generates_noise(p);
+  p->scan_gen_now = gen_in_rollout;
+  if (gen_in_rollout) {
+    if (have_noise) discard_noise_ahead(p);  // (produced ahead by an earlier, different kind of launch)
+    have_noise = false;
+    want_next = false;
+  } else if (have_noise) {
+    p->noise_cur ^= 1;
+    if (p->noise_on_side_stream) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_noise_ready, 0));
+    p->noise_on_side_stream = false;
+    p->noise_virtual = false;
+  } else {
+    TraceRange tr("mppi:noise");
+    p->noise_virtual = false;
+    TRY(launch_noise(p, p->noise_buf[p->noise_cur]));
+  }
+  p->noise = p->noise_buf[p->noise_cur];
+  p->next_noise_wanted = want_next;
+  p->next_noise_done = false;
+  if (prof) HIP_TRY(hipEventRecord(p->ev_stage[1], p->stream));
+  // the other noise buffer was last read by the previous update, which is behind us on this stream
+  if (want_next && side_stream_pays) HIP_TRY(hipEventRecord(p->ev_buf_free, p->stream));
+  {
+    TraceRange tr("mppi:rollout");
+    if (p->ktime_index >= 0) {
+      p->kev_start = p->ktime_events[4 * (size_t)p->ktime_index];
+      p->kev_stop = p->ktime_events[4 * (size_t)p->ktime_index + 1];
+    }
+    const int rc = launch_rollout(p, d);
+    p->kev_start = p->kev_stop = nullptr;
+    TRY(rc);
+  }
+  if (p->m_count > 1) {
+    TraceRange tr("mppi:exchange_sample_costs");
+    TRY(exchange_sample_costs(p));
+  }
+  have_noise = p->next_noise_done;
+  if (want_next && !have_noise && side_stream_pays) {
+    HIP_TRY(hipStreamWaitEvent(p->noise_stream, p->ev_buf_free, 0));
+    TraceRange tr("mppi:noise_ahead");
+    TRY(launch_noise(p, p->noise_buf[p->noise_cur ^ 1], p->noise_stream));
+    HIP_TRY(hipEventRecord(p->ev_noise_ready, p->noise_stream));
+    have_noise = p->noise_on_side_stream = true;
+    if (p->graph_on) {
+      // graph mode: join before the update, which advances the epoch counter the generator reads
+      // (and a captured iteration must not leave a fork open)
+      HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_noise_ready, 0));
+      p->noise_on_side_stream = false;
+    }
+  }
+  p->next_noise_wanted = false;
+  p->scan_gen_now = false;
+  if (prof) HIP_TRY(hipEventRecord(p->ev_stage[2], p->stream));
+  TraceRange tr_update("mppi:update");
+  if (p->ktime_index >= 0) {
+    p->kev_start = p->ktime_events[4 * (size_t)p->ktime_index + 2];
+    p->kev_stop = p->ktime_events[4 * (size_t)p->ktime_index + 3];
+    ++p->ktime_index;
+  }
+  {
+    const int rc = launch_update(p, prof, defer_exchange);
+    p->kev_start = p->kev_stop = nullptr;
+    TRY(rc);
+  }
+  if (prof) HIP_TRY(hipEventRecord(p->ev_stage[5], p->stream));
+  return MPPI_OK;
+}
+
+// Everything the launches of an iteration take by value or derive on the host: a captured graph
+// may be replayed only while none of it has changed.
+static void graph_signature(const mppi_planner* p, const DevParams& d, const mppi_tdm* lin, const mppi_tdm* ang,
+                            std::vector<unsigned char>& out) {
+  struct Sig {
+    DevParams d;
+    mppi_params params;
+    const void *lin, *ang, *cells, *cells16, *cc, *sample_costs;
+    uint64_t lin_grid, ang_grid, lin_maps, epoch_bias;
+    int noise_cur, inst_set, want_sample_costs, speculation_off, debug_flags, pad;
+  } sig;
+  memset(&sig, 0, sizeof(sig));
+  sig.d = d;
+  sig.params = p->params;
+  if (p->inst_set) {  // batched handle: start and goal are read from device memory, not from arguments
+    sig.d.x0 = sig.d.y0 = sig.d.th0 = sig.d.xg = sig.d.yg = 0.0f;
+    memset(sig.params.x0, 0, sizeof(sig.params.x0));
+    memset(sig.params.xgoal, 0, sizeof(sig.params.xgoal));
+  }
+  sig.lin = lin; sig.ang = ang; sig.cells = p->cells; sig.cells16 = p->cells16; sig.cc = p->cc_scratch;
+  sig.sample_costs = p->sample_costs;
+  sig.lin_grid = p->packed_lin_grid; sig.ang_grid = p->packed_ang_grid; sig.lin_maps = p->packed_lin_maps;
+  sig.epoch_bias = p->noise_epoch - p->bumps_launched;
+  sig.noise_cur = p->noise_cur; sig.inst_set = p->inst_set; sig.want_sample_costs = p->want_sample_costs;
+  sig.speculation_off = p->speculation_off ? 1 : 0; sig.debug_flags = p->debug_flags;
+  out.assign(reinterpret_cast<unsigned char*>(&sig), reinterpret_cast<unsigned char*>(&sig) + sizeof(sig));
+}
+
+// `timed`: bracket the iterations with events for mppi_planner_last_elapsed_ms / stage_times
+// (iterate_async, profiling); solve() on the control path skips them
+// called where the host has just waited for the stream: did speculation pay on this map?
+static void review_speculation(mppi_planner* p) {
+  if (!p->spec_fail_host) return;
+  if (p->spec_tiles_launched == 0) {  // (nothing speculative ran: whatever the word holds is stale)
+    *p->spec_fail_host = 0u;
+    return;
+  }
+  const uint64_t failed = *p->spec_fail_host;
+  if (2 * failed >= p->spec_tiles_launched) p->speculation_off = true;
+  *p->spec_fail_host = 0u;
+  p->spec_tiles_launched = 0;
+}
+
+static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int iterations, bool timed = true,
+                          bool mirror_last = false) {
+  REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
+  TRY(check_tdms(p, lin, ang));
+  TRY(ensure_packed(p, lin, ang));
+  DevParams d = make_dev_params(p, lin, ang);
+  timed = timed || p->profile_stages;
+  if (timed) HIP_TRY(hipEventRecord(p->ev_begin, p->stream));
+  // The noise of iteration k+1 does not depend on iteration k.  When the pipelined rollout
+  // kernel runs, its spare workgroups generate it into the other half of the double buffer
+  // (same launch, no extra dependency); otherwise it is generated in line.
+  // (a sharded handle replays too: RCCL's all-gather is captured into the graph with the kernels;
+  //  without a communicator the exchange is host-staged and cannot be captured)
+  const bool use_graph = p->graph_on && !p->profile_stages && (p->cfg.world_size == 1 || p->comm);
+  if (!use_graph) {
+    // Every iteration, the last one of a call included, asks for its successor's noise: when the
+    // rollout kernel can produce it on the side (spare workgroups, second stream) the next call --
+    // the next control step -- starts with its noise already there (`primed`).
+    bool have_noise = p->primed;
+    for (int k = 0; k < iterations; ++k) {
+      // profiled iteration: a steady-state one when there is one, else the last
+      bool prof = p->profile_stages && k == (iterations >= 3 ? iterations - 2 : iterations - 1);
+      p->mirror_now = mirror_last && k == iterations - 1;
+      const int rc = launch_iteration(p, d, have_noise, true, prof);
+      p->mirror_now = false;
+      TRY(rc);
+    }
+    p->primed = have_noise;
+  } else {
+    // Graph mode.  Every iteration also asks for the noise of its successor (`primed`; kernels that
+    // cannot produce it ahead generate in line instead), so that all iterations look alike; two of
+    // them bring the noise double buffer back to where it was and are what gets captured.
+    // Host-side effects of a launch (which kernel, window plan, instance upload, lazy allocations)
+    // happen in the direct iteration that precedes any capture.
+    bool have_noise = p->primed;
+    int k = 0;
+    if (p->inst_set && p->inst_dirty) {  // batched handle: new start states -> window origins, upload
+      size_t unused = 0;
+      DevParams plan = d;
+      (void)plan_lds_window(p, plan, &unused);
+      TRY(upload_instances(p));
+    }
+    if ((!have_noise || !p->graph_warm) && k < iterations) {
+      TRY(launch_iteration(p, d, have_noise, true, false));
+      p->graph_warm = true;
+      ++k;
+    }
+    const int chunk = p->graph_chunk;  // iterations per graph: even (noise double buffer)
+    while (iterations - k >= chunk) {
+      std::vector<unsigned char> sig;
+      graph_signature(p, d, lin, ang, sig);
+      sig.push_back(have_noise ? 1 : 0);
+      const int slot = p->noise_cur & 1;
+      if (!p->graph_exec[slot] || sig != p->graph_sig[slot]) {
+        if (p->graph_exec[slot]) { (void)hipGraphExecDestroy(p->graph_exec[slot]); p->graph_exec[slot] = nullptr; }
+        if (p->graph[slot]) { (void)hipGraphDestroy(p->graph[slot]); p->graph[slot] = nullptr; }
+        p->graph_sig[slot].clear();
+        const bool primed_before = have_noise;
+        const uint64_t spec_before = p->spec_tiles_launched;
+        HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+        int rc = MPPI_OK;
+        for (int j = 0; j < chunk && rc == MPPI_OK; ++j) rc = launch_iteration(p, d, have_noise, true, false);
+        hipError_t end = hipStreamEndCapture(p->stream, &p->graph[slot]);
+        if (rc != MPPI_OK) return rc;
+        HIP_TRY(end);
+        REQUIRE(have_noise == primed_before, MPPI_ERR_STATE, "graph capture: the iterations are not alike");
+        HIP_TRY(hipGraphInstantiate(&p->graph_exec[slot], p->graph[slot], nullptr, nullptr, 0));
+        p->graph_sig[slot] = sig;
+        p->graph_spec_tiles[slot] = p->spec_tiles_launched - spec_before;
+        ++p->graph_captures;
+        // (capturing ran the host side of two iterations; the launch below runs their device side)
+      } else {
+        // the host-side counters a direct launch of the two iterations would have advanced
+        if (p->cfg.rng == MPPI_RNG_PHILOX) p->noise_epoch += (uint64_t)chunk;
+        p->bumps_launched += (uint64_t)chunk;
+        // (the replayed kernels count their failed tiles like the captured ones did)
+        p->spec_tiles_launched += p->graph_spec_tiles[slot];
+      }
+      HIP_TRY(hipGraphLaunch(p->graph_exec[slot], p->stream));
+      ++p->graph_replays;
+      k += chunk;
+    }
+    for (; k < iterations; ++k) TRY(launch_iteration(p, d, have_noise, true, false));
+    p->primed = have_noise;
+  }
+  if (timed) {
+    HIP_TRY(hipEventRecord(p->ev_end, p->stream));
+    p->elapsed_pending = true;
+    p->last_iterations = iterations;
+  }
+  return MPPI_OK;
+}
+
+static int finish_timing(mppi_planner* p) {
+  if (!p->elapsed_pending) return MPPI_OK;
+  HIP_TRY(hipEventSynchronize(p->ev_end));
+  HIP_TRY(hipEventElapsedTime(&p->last_elapsed_ms, p->ev_begin, p->ev_end));
+  if (p->profile_stages && p->last_iterations > 0) {
+    // ev_stage: 0 noise | 1 rollout | 2 update-local | 3 collective | 4 apply .. ev_end
+    float noise, roll, upd, coll, tail;
+    HIP_TRY(hipEventElapsedTime(&noise, p->ev_stage[0], p->ev_stage[1]));
+    HIP_TRY(hipEventElapsedTime(&roll, p->ev_stage[1], p->ev_stage[2]));
+    HIP_TRY(hipEventElapsedTime(&upd, p->ev_stage[2], p->ev_stage[3]));
+    HIP_TRY(hipEventElapsedTime(&coll, p->ev_stage[3], p->ev_stage[4]));
+    HIP_TRY(hipEventElapsedTime(&tail, p->ev_stage[4], p->ev_stage[5]));
+    p->stage_ms[0] = noise;
+    p->stage_ms[1] = roll;
+    p->stage_ms[2] = upd + tail;
+    p->stage_ms[3] = coll;
+  }
+  p->elapsed_pending = false;
+  return MPPI_OK;
+}
+
+// grids are sampled once per solve(), not per optimisation iteration
+// (mppi.py:247-248, 321-322, 391-394); the deterministic modes pass alpha_dyn = 1
+static int sample_for_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang) {
+  if (p->cfg.mode == MPPI_MODE_BAREBONE) return MPPI_OK;
+  TraceRange tr("mppi:sample_grids");
+  double alpha = (p->cfg.mode == MPPI_MODE_TDM) ? p->params.alpha_dyn : 1.0;
+  int rc = MPPI_OK;
+  if (sample_into_cells(p, lin, ang, alpha, &rc)) return rc;
+  TRY(tdm_sample_on(lin, alpha, p->stream));
+  TRY(tdm_sample_on(ang, alpha, p->stream));
+  return MPPI_OK;
+}

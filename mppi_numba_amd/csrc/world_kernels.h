@@ -84,6 +84,7 @@ struct WorldLoop {
   float2* uhist;      // [B][max_steps]
   int* done;          // [B] 0 = running, else the number of steps taken when the goal was reached
   int* done_count;    // host-mapped: problems that have reached their goal
+  float2* u_final;    // [B][T] the controls a problem had when it reached its goal (shifted once)
   int max_steps;
   double dt, goal_tolerance;
   // the LDS window plan of the planner (plan_lds_window): origin per problem around its start cell
@@ -100,8 +101,10 @@ struct WorldLoop {
 __global__ void k_world_step(WorldGrid G, WorldLoop L, BatchInst* __restrict__ inst, float2* __restrict__ u,
                              int n_steps, int step) {
   extern __shared__ float2 shifted[];
+  __shared__ int reached_now;
   const int b = blockIdx.x;
   if (L.done[b]) return;  // (uniform over the block)
+  if (threadIdx.x == 0) reached_now = 0;
   float2* ub = u + (size_t)b * n_steps;
   for (int t = threadIdx.x; t < n_steps; t += blockDim.x) shifted[t] = ub[t];
   __syncthreads();
@@ -134,11 +137,30 @@ __global__ void k_world_step(WorldGrid G, WorldLoop L, BatchInst* __restrict__ i
     const double dx = x1 - (double)I.xg, dy = y1 - (double)I.yg;
     if (sqrt(dx * dx + dy * dy) <= L.goal_tolerance) {
       L.done[b] = step + 1;
+      reached_now = 1;
       atomicAdd_system(L.done_count, 1);
       __threadfence_system();
     }
   }
+  __syncthreads();
   for (int t = threadIdx.x; t + 1 < n_steps; t += blockDim.x) ub[t] = shifted[t + 1];
+  // The host looks at done_count only every few steps, and the planner keeps optimising the
+  // controls of a finished problem until then: what the notebook's loop leaves behind -- the last
+  // solution, shifted once -- is put aside here and restored when the loop ends (k_world_restore).
+  if (reached_now) {
+    float2* uf = L.u_final + (size_t)b * n_steps;
+    for (int t = threadIdx.x; t < n_steps; t += blockDim.x) uf[t] = shifted[min(t + 1, n_steps - 1)];
+  }
+}
+
+__global__ void k_world_restore(WorldLoop L, float2* __restrict__ u, float2* __restrict__ u_prev, int n_steps) {
+  const int b = blockIdx.x;
+  if (!L.done[b]) return;
+  for (int t = threadIdx.x; t < n_steps; t += blockDim.x) {
+    const float2 v = L.u_final[(size_t)b * n_steps + t];
+    u[(size_t)b * n_steps + t] = v;
+    u_prev[(size_t)b * n_steps + t] = v;
+  }
 }
 
 }  // namespace mppi

@@ -337,7 +337,9 @@ class MPPI_Numba(object):
         (xhist (max_steps+1, 3) float64, uhist (max_steps, 2) float32, steps_taken) --
         with a leading problem axis for a batched handle; rows never reached are NaN, as in
         the notebook.  Afterwards params['x0'] and the device's control sequence are where
-        the loop left them (the last solution, shifted once)."""
+        the loop left them (the last solution, shifted once: the host looks at the goal flags only
+        every 16 steps, the solves that ran meanwhile have advanced the generators' counters and
+        nothing else -- a finished problem's controls are put aside at its goal and restored)."""
         from .terrain import DeviceWorld
         if not self.check_solve_conditions():
             print("MPPI solve condition not met. Cannot solve. Return")
@@ -440,7 +442,8 @@ class MPPI_Numba(object):
         return buf.value.decode()
 
     def set_debug_flags(self, flags):
-        """Developer switches (_lib.DEBUG_*): which rollout kernel variant runs; never the results."""
+        """Developer switches (_lib.DEBUG_*): which rollout kernel variant runs.  math="exact": never the
+        results; math="fast": variants agree to float32 tolerance (include/mppi_hip.h)."""
         _lib.call("mppi_planner_set_debug_flags", self._handle, int(flags))
 
     def set_graph_replay(self, enabled=True, iterations_per_graph=2):

@@ -18,6 +18,8 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+if "--reference" in sys.argv:  # (before the shim is imported: it reads MPPI_REFERENCE_ROOT at import time)
+    os.environ["MPPI_REFERENCE_ROOT"] = sys.argv[sys.argv.index("--reference") + 1]
 import cudasim_shim  # noqa: E402  (must precede anything that imports numba)
 
 import numpy as np  # noqa: E402
@@ -27,6 +29,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--solves", type=int, default=3)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--reference", default=None, help="checkout root of mit-acl/mppi_numba (default /root/reference)")
     args = ap.parse_args()
     ns = cudasim_shim.load_barebone_namespace()
     cfg = ns["Config"](T=3.0, dt=0.1, num_control_rollouts=100, num_vis_state_rollouts=1, seed=1)

@@ -8,6 +8,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The reference's host-side helper modules (mppi_numba.density / visualization / utils) are out of this
+# repository's scope; the alias package forwards them to a reference checkout.  On a box without one
+# (the GPU box) the notebook-flow test uses the minimal stand-ins under tests/standins/ instead.
+if "MPPI_NUMBA_REFERENCE" not in os.environ:
+    _ref = "/root/reference"
+    os.environ["MPPI_NUMBA_REFERENCE"] = _ref if os.path.isfile(os.path.join(_ref, "mppi_numba", "density.py")) \
+        else os.path.join(ROOT, "tests", "standins")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
 

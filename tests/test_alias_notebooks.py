@@ -1,6 +1,7 @@
 """The `mppi_numba` alias package: code written against the reference imports the HIP engine
 for config / mppi / terrain and finds the reference's host-side helpers (density,
-visualization, utils) either in a reference checkout or in this repository's stand-ins.
+visualization, utils) in a reference checkout; without one they do not resolve (they are out of
+this repository's scope) and the ImportError says where to point MPPI_NUMBA_REFERENCE.
 Reference notebooks' first cell: /root/reference/test.ipynb cell 1 (all five notebooks start
 with the same imports)."""
 import importlib
@@ -37,11 +38,30 @@ def run_py(code, pythonpath, env_extra=None):
     return out.stdout.strip().splitlines()
 
 
-def test_import_cell_without_reference_uses_the_stand_ins():
-    lines = run_py(IMPORT_CELL, ROOT)
-    assert lines[0] == os.path.join(ROOT, "mppi_numba_amd", "density.py")
+def test_without_a_reference_the_engine_imports_and_the_helpers_say_where_to_find_them():
+    code = ("from mppi_numba.terrain import Terrain, TDM_Numba, TractionGrid\n"
+            "from mppi_numba.mppi import MPPI_Numba\n"
+            "from mppi_numba.config import Config\n"
+            "import mppi_numba.mppi\n"
+            "print(mppi_numba.mppi.__file__)\n"
+            "print(MPPI_Numba.__module__, TDM_Numba.__module__, Config.__module__)\n"
+            "try:\n"
+            "    import mppi_numba.density\n"
+            "    print('imported')\n"
+            "except ImportError as e:\n"
+            "    print('MPPI_NUMBA_REFERENCE' in str(e))\n")
+    lines = run_py(code, ROOT)
+    assert lines[0] == os.path.join(ROOT, "mppi_numba_amd", "mppi.py")
+    assert lines[1] == "mppi_numba_amd.mppi mppi_numba_amd.terrain mppi_numba_amd.config"
+    assert lines[2] == "True"
+
+
+def test_the_test_suites_stand_ins_resolve_through_the_same_hook():
+    """tests/standins/ (minimal density / visualization / utils for boxes without the reference:
+    test infrastructure of tests/test_gpu_notebook_flow.py) is found the way a checkout is."""
+    lines = run_py(IMPORT_CELL, ROOT, {"MPPI_NUMBA_REFERENCE": os.path.join(ROOT, "tests", "standins")})
+    assert lines[0] == os.path.join(ROOT, "tests", "standins", "density.py")
     assert lines[1] == os.path.join(ROOT, "mppi_numba_amd", "mppi.py")
-    assert lines[2] == "mppi_numba_amd.mppi mppi_numba_amd.terrain mppi_numba_amd.config"
 
 
 @pytest.mark.skipif(not HAVE_REFERENCE, reason="no reference checkout on this box")
@@ -78,106 +98,3 @@ def test_reference_notebook_terrain_cell_executes():
             "print(type(ns['bush']).__module__, len(ns['b_lin_pmf']), round(float(ns['b_lin_pmf'].sum()), 6))\n"
             % (ROOT, os.path.join(REFERENCE, "test.ipynb")))
     assert run_py(code, ROOT + ":" + REFERENCE)[-1] == "mppi_numba_amd.terrain 22 1.0"
-
-
-# ---- the stand-ins themselves ---------------------------------------------------------
-def test_stand_in_density_statistics_and_pmf():
-    from mppi_numba_amd.density import Density, GaussianMixture
-    np.random.seed(0)
-    gm = GaussianMixture(sample_bounds=[0, 1.0], pmf_bounds=[0, 1.0], weights=[0.6, 0.4], means=[0, 0.8],
-                         stds=[0.15, 0.1], num_samples=20000)
-    assert isinstance(gm, Density) and gm.num_components == 2 and not gm.sample_initialized
-    s = gm.sample(5000)
-    assert s.shape == (5000,) and s.min() >= 0.0 and s.max() <= 1.0
-    values, pmf = gm.get_pmf(num_bins=20)
-    assert gm.sample_initialized and len(values) == len(pmf) == 22
-    assert values[0] == 0.0 and values[-1] == 1.0 and pmf[0] == 0.0 and pmf[-1] == 0.0
-    np.testing.assert_allclose(values[1:-1], 0.025 + 0.05 * np.arange(20))
-    assert abs(pmf.sum() - 1.0) < 1e-12
-    # truncated mixture: the half-Gaussian at 0 keeps 0.6*0.5 of its mass, renormalised
-    low_mass = pmf[values < 0.45].sum()
-    assert abs(low_mass - 0.3 / 0.7) < 0.02
-    tail_mean, thres = gm.cvar(0.2)
-    assert tail_mean < thres < gm.mean() and gm.var() > 0
-    upper_mean, upper_thres = gm.cvar(0.2, front=False)
-    assert upper_mean > upper_thres > gm.mean()
-    values_plain, pmf_plain = gm.get_pmf(num_bins=10, include_min_max=False)
-    assert len(values_plain) == 10 and abs(pmf_plain.sum() - 1.0) < 1e-12
-
-
-@pytest.mark.skipif(not HAVE_REFERENCE, reason="no reference checkout on this box")
-def test_stand_in_density_matches_the_reference_on_the_same_samples():
-    spec = importlib.util.spec_from_file_location("ref_density", os.path.join(REFERENCE, "mppi_numba", "density.py"))
-    ref = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(ref)
-    from mppi_numba_amd.density import Density
-    rng = np.random.default_rng(3)
-    fixed = rng.beta(2.0, 3.0, 4000)
-    ours = Density([0, 1], [0, 1], lambda n: fixed[:int(n)], num_samples=4000)
-    theirs = ref.Density([0, 1], [0, 1], lambda n: fixed[:int(n)], num_samples=4000)
-    for bins, mm in ((20, True), (7, False)):
-        v0, p0 = ours.get_pmf(bins, include_min_max=mm)
-        v1, p1 = theirs.get_pmf(bins, include_min_max=mm)
-        np.testing.assert_array_equal(v0, v1)
-        np.testing.assert_array_equal(p0, p1)
-    assert ours.mean() == theirs.mean() and ours.var() == theirs.var()
-    for alpha, front in ((0.2, True), (0.3, False), (1.0, True)):
-        if alpha == 1.0:
-            continue  # both assert on an empty tail mask only when the threshold is the minimum
-        assert ours.cvar(alpha, front=front) == theirs.cvar(alpha, front=front)
-
-
-def test_stand_in_utils():
-    from mppi_numba_amd.utils import normalize_angle, normalize_angle_np
-    for th in (-7.0, -np.pi, -0.1, 0.0, 3.0, np.pi, 3.5, 9.9, 40.0):
-        w = normalize_angle(th)
-        assert -np.pi < w <= np.pi and abs(np.sin(w) - np.sin(th)) < 1e-12 and abs(np.cos(w) - np.cos(th)) < 1e-12
-    arr = np.array([-7.0, -0.1, 3.5, 9.9])
-    np.testing.assert_allclose(normalize_angle_np(arr), [normalize_angle(t) for t in arr])
-
-
-def test_stand_in_visualizer_draws_a_padded_semantic_grid():
-    import matplotlib
-    matplotlib.use("Agg")
-    import matplotlib.pyplot as plt
-    from mppi_numba_amd.visualization import TDM_Visualizer
-
-    class Terr:
-        def __init__(self, rgb):
-            self.rgb = rgb
-
-    class FakeTDM:  # the attributes TDM_Numba exposes after set_TDM_from_semantic_grid
-        semantic_grid_initialized = True
-        semantic_grid = np.array([[0, 1, 0], [1, 1, 0]], dtype=np.int8)
-        id2name = {0: "dirt", 1: "veg"}
-        name2terrain = {"dirt": Terr((0.8, 0.7, 0.6)), "veg": Terr((0.0, 1.0, 0.0))}
-        terrain2pmf = {}
-        cell_dimensions = (0.5, 0.5)
-        xlimits, ylimits = (0.0, 1.5), (0.0, 1.0)
-        padded_xlimits, padded_ylimits = (-1.0, 2.5), (-1.0, 2.0)
-        num_pmf_bins, bin_values, bin_values_bounds = 3, np.array([0, 0.5, 1.0]), (0.0, 1.0)
-        pad_cells = 2
-
-        def id2terrain_fn(self, sid):
-            return self.name2terrain[self.id2name[sid]]
-
-        def get_padded_grid_xy_dim(self):
-            return (6, 7)
-
-    vis = TDM_Visualizer(FakeTDM())
-    assert vis.semantic_grid.shape == (6, 7) and (vis.semantic_grid[:2] == -1).all()
-    np.testing.assert_array_equal(vis.semantic_grid[2:4, 2:5], FakeTDM.semantic_grid)
-    fig, ax = vis.draw(figsize=(4, 4))
-    polys = [c for c in ax.collections if type(c).__name__ == "PolyCollection"]
-    assert len(polys) == 1 and len(polys[0].get_paths()) == 42
-    np.testing.assert_allclose(vis.get_all_cell_verts()[0], vis.cell_verts(0, 0))
-    np.testing.assert_allclose(vis.get_all_cell_verts()[7 + 3], vis.cell_verts(3, 1))
-    assert vis.get_terrain_rgbs()[2 * 7 + 3] == (0.0, 1.0, 0.0)
-    assert vis.cell_xy(0, 0) == (-0.75, -0.75)
-    plt.close(fig)
-    # a visualizer without its own grid draws a user-supplied one
-    bare = TDM_Visualizer(FakeTDM(), tdm_contains_semantic_grid=False)
-    assert bare.draw() is None
-    fig, ax = bare.draw(figsize=None, semantic_grid=FakeTDM.semantic_grid, id2rgb_map={0: (1, 1, 1), 1: (0, 0, 1), -1: (0, 0, 0)})
-    assert len(ax.collections) == 2
-    plt.close(fig)

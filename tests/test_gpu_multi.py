@@ -38,6 +38,23 @@ def test_bench_self_launches_two_ranks_on_one_device():
     assert res["value"] > 0 and res["scaling"] == "weak"
 
 
+def test_bench_eight_ranks_on_one_device_times_its_own_steps():
+    """The driver's 8-GPU line is `--gpus 8 --steps 20`: ~0.5 ms of GPU work.  ms_per_step must be
+    the slowest rank's own K steps (stream drained) -- the closing barrier, 2 x 7 TCP hops through
+    rank 0, is reported beside it, not inside it."""
+    res, err = run_bench("--gpus", "8", "--steps", "20", "--warmup", "5", "--n", "1024", "--no-cpu-baseline",
+                         "--exchange", "host", timeout=900)
+    assert res["n_gpus"] == 8 and res["config"]["global_rollouts"] == 8192
+    per_rank = res["ms_per_step_per_rank"]
+    assert len(per_rank) == 8 and min(per_rank) > 0
+    assert abs(res["ms_per_step"] - max(per_rank)) <= 1e-9 * max(per_rank)
+    assert res["closing_barrier_ms"] >= 0.0
+    # value = the whole job's rollouts over the slowest rank's time
+    assert abs(res["value"] - 8192 * 20 / (res["ms_per_step"] * 1e-3 * 20)) <= 1e-6 * res["value"]
+    # the ranks share one GPU and one hub: their own times agree within a quarter of the slowest
+    assert (max(per_rank) - min(per_rank)) <= 0.25 * max(per_rank), per_rank
+
+
 def test_bench_two_ranks_sharding_the_traction_samples():
     """north_star's other split: the M traction-map samples of the CVaR workload over the ranks
     (two processes on this box's one GPU, slabs exchanged through the host hub)."""

@@ -2,7 +2,7 @@
 (cells 2-4: terrain models -> semantic grid -> TDMs -> planner -> solve / simulate /
 shift_and_update until the goal, with the notebook's plots drawn headless), written against
 the `mppi_numba` ALIAS exactly as the notebook imports it.  The GPU box has no reference
-checkout, so the host helpers are this repository's stand-ins here; with a checkout beside it
+checkout, so the host helpers are the test suite's stand-ins (tests/standins/, found through MPPI_NUMBA_REFERENCE) here; with a checkout beside it
 `tools/run_reference_notebook.py` runs the notebook's own cells (tests/test_alias_notebooks.py
 does that for the cells that need no GPU)."""
 import numpy as np

@@ -29,15 +29,11 @@ def oracle_costs(w, params, lin, ang, noise, u):
 
 # which rollout kernel each BASELINE configuration must take (bench.py runs the same objects)
 EXPECTED_KERNEL = {"c2": "k_rollout_deep", "c3": "k_rollout_tdm_fast", "c4": "k_rollout_fused"}
-U_MARGINS = {}  # workload -> achieved max |du| / control range (printed by the last test of the file)
 
 
-@pytest.mark.parametrize("workload,n", [("c2", None), ("c4", None), ("c3", None), ("c4", 16384), ("c3", 192)])
-def test_costs_and_update_vs_oracle_at_scale(workload, n):
-    """BASELINE configs[1..3] at FULL size -- C2 N=8192, T=100; C4 N=65536, T=200 (the fused
-    throughput kernel); C3 N=4096 x M=128 -- the very objects bench.py times, against the C
-    restatement of mppi.py:613-755 / 916-1009 / 1113-1191; plus two reduced cases that take
-    other kernels (C4 at N=16384: pipelined kernel at T=200)."""
+def costs_and_update_margin(workload, n):
+    """One stage-level iteration of a bench workload against the C restatement of mppi.py:613-755 /
+    916-1009 / 1113-1191; returns the achieved max |du| / control range."""
     w, cfg, lin, ang, planner, params = build(workload, n)
     planner.solve()            # samples grids, one iteration
     planner.iterate_async(5)   # warm-start u away from zero
@@ -60,22 +56,28 @@ def test_costs_and_update_vs_oracle_at_scale(workload, n):
     scale = np.array([3.0, np.pi])
     margin = float((np.abs(planner.u_cur_d.copy_to_host() - u_ref) / scale).max())
     print("\n%s n=%s: exact costs %.5f, max |du|/range %.3e (bound 1e-5)" % (workload, n, (ulps == 0).mean(), margin))
-    if n is None:
-        U_MARGINS[workload] = margin
     assert margin <= 1e-5
     got_w = planner.weights_d.copy_to_host()
     assert abs(got_w.sum() - 1.0) < 1e-5
     assert np.abs(got_w - w_ref).max() <= 1e-5 * w_ref.max()
+    return margin
+
+
+@pytest.mark.parametrize("workload,n", [("c2", None), ("c4", None), ("c3", None), ("c4", 16384), ("c3", 192)])
+def test_costs_and_update_vs_oracle_at_scale(workload, n):
+    """BASELINE configs[1..3] at FULL size -- C2 N=8192, T=100; C4 N=65536, T=200 (the fused
+    throughput kernel); C3 N=4096 x M=128 -- the very objects bench.py times, against the C
+    restatement; plus two reduced cases that take other kernels (C4 at N=16384: pipelined kernel
+    at T=200)."""
+    costs_and_update_margin(workload, n)
 
 
 def test_u_margin_at_c2_has_headroom():
     """The 1e-5 bound on u is the north-star tolerance; the deterministic float64 tree should sit
     far inside it (it is MORE accurate than the reference's float32 atomics, whose own
     reordering noise is what the distance measures).  A regression towards the bound fails here
-    long before it fails the parity bar."""
-    if "c2" not in U_MARGINS:
-        pytest.skip("runs after test_costs_and_update_vs_oracle_at_scale[c2-None]")
-    assert U_MARGINS["c2"] <= 2e-6, U_MARGINS
+    long before it fails the parity bar.  (Computes its own margin: runs alone, under -k, under xdist.)"""
+    assert costs_and_update_margin("c2", None) <= 2e-6
 
 
 def test_fast_math_close_to_exact():

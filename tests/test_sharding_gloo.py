@@ -1,4 +1,4 @@
-"""world_size = 2 over gloo on CPU: the sharded control update.
+"""world_size = 2 over gloo on CPU: the ALGEBRA of the sharded control update (not the kernels).
 
 Each rank owns half of the control samples, reduces them to one packet
 {beta_g, den_g, num_g[T][2]} (what k_weights / k_wsum / k_finish produce on the
@@ -76,7 +76,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_update_over_gloo_world2():
+def test_packet_algebra_of_the_sharded_update_over_gloo_world2():
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     with socket.socket() as s:
