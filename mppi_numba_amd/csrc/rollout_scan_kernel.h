@@ -254,15 +254,9 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
   // ---------------------------------------------------------------- B: headings, position increments
   float lx[CHL], ly[CHL];  // position gained inside the chunk up to and including step j
   {
-    // (eight sums requested per wait: one LDS round trip per addition was a third of this stage)
     double tb = (double)Q.th0 * 0.15915494309189535;
-    for (int i0 = 0; i0 < k; i0 += 8) {
-      double v8[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) v8[q] = sumS[(size_t)min(i0 + q, K - 1) * R + r];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) tb += (i0 + q < k) ? v8[q] : 0.0;
-    }
+    for (int i = 0; i < c * S; ++i) tb += sumS[(size_t)i * R + r];  // (uniform trip count)
+    if (S > 1 && h > 0) tb += sumS[(size_t)(c * S) * R + r];
     const float fb = (float)__builtin_amdgcn_fract(tb);  // v_sin_f32 / v_cos_f32 take turns
     float sx = 0.0f, sy = 0.0f;
 #pragma unroll
@@ -287,18 +281,13 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
   uint32_t zero_bits = 0, mism_bits = 0, hit_bits = 0;
   {
     double bx = (double)Q.x0, by = (double)Q.y0;
-    for (int i0 = 0; i0 < k; i0 += 8) {
-      double vx[8], vy[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        vx[q] = sumS[(size_t)(K + min(i0 + q, K - 1)) * R + r];
-        vy[q] = sumS[(size_t)(2 * K + min(i0 + q, K - 1)) * R + r];
-      }
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        bx += (i0 + q < k) ? vx[q] : 0.0;
-        by += (i0 + q < k) ? vy[q] : 0.0;
-      }
+    for (int i = 0; i < c * S; ++i) {
+      bx += sumS[(size_t)(K + i) * R + r];
+      by += sumS[(size_t)(2 * K + i) * R + r];
+    }
+    if (S > 1 && h > 0) {
+      bx += sumS[(size_t)(K + c * S) * R + r];
+      by += sumS[(size_t)(2 * K + c * S) * R + r];
     }
     xa[0] = (float)bx;
     ya[0] = (float)by;

@@ -2,8 +2,8 @@
 # Host-side AddressSanitizer pass over the C ABI layer.
 #   make -C mppi_numba_amd/csrc asan          -> build/libmppi_asan.so (host code instrumented)
 #   bash tools/asan_abi.sh [pytest args]      -> the ABI / handle-lifetime / error-path tests under it
-# Without a GPU this covers library load, symbol export, struct layouts and every error path that
-# is taken before a device is touched; on a GPU box it adds the handle-lifetime, graph and edge tests.
+# Covers library load, symbol export, struct layouts and every error path that is taken before a
+# device is touched.
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 LIB=$ROOT/build/libmppi_asan.so
@@ -14,12 +14,11 @@ export LD_PRELOAD=$RT
 # (the interpreter and the HIP runtime are not instrumented: their one-time allocations are not leaks of ours)
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:halt_on_error=1:detect_odr_violation=0
 cd "$ROOT"
-if [ -e /dev/kfd ]; then
-  TESTS="tests/test_host_and_abi.py tests/test_gpu_edges.py tests/test_gpu_graph.py tests/test_gpu_scan.py"
-  MARK=""
-else
-  TESTS="tests/test_host_and_abi.py"
-  MARK="-m not\ gpu"
-fi
+# (The HIP runtime of this image cannot be initialised under the sanitizer -- hipGetDeviceCount dies inside
+#  libamdhip64 with an out-of-memory report, and there is no sanitizer build of the runtime under
+#  /opt/rocm/lib/asan -- so on a GPU box, too, the pass is over the tests that touch no device:
+#  profiles/r03_asan.md.)
+TESTS="tests/test_host_and_abi.py"
+MARK="-m not\ gpu"
 if [ $# -gt 0 ]; then TESTS="$@"; fi
 eval python -m pytest $TESTS -q -x -p no:cacheprovider $MARK

@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/${TAG:-r03q}
 mkdir -p $OUT
 cd $ROOT
-for f in ${FLAGS:-0 256}; do
+for f in ${FLAGS:-0}; do
   timeout 300 python bench.py --math fast --steps 200 --warmup 20 --no-cpu-baseline --debug-flags $f > $OUT/bench_fast_$f.json 2> $OUT/bench_fast_$f.err
   python - <<PY
 import json
