@@ -470,7 +470,7 @@ def main():
         return
 
     kernel_name = planner.last_rollout_kernel().split(" ")[0]
-    fused = kernel_name == "k_rollout_scan" and "noise=in-kernel" in planner.last_rollout_kernel()
+    fused = kernel_name.startswith("k_rollout_scan") and "noise=in-kernel" in planner.last_rollout_kernel()
     bytes_iter, bytes_roll = algorithmic_bytes(w, n_local * max(1, problems), rp, cp,
                                                rollout_writes_noise=(kernel_name in ("k_rollout_pipe", "k_rollout_spec", "k_rollout_deep")),
                                                fused=fused)
@@ -530,7 +530,8 @@ def main():
                      "fused": fused,
                      "fused_note": ("the launch samples the noise, rolls out and reduces the update per tile; the noise never "
                                     "exists in memory, so `traffic` is a small fraction of `algorithmic_bytes_per_launch` and "
-                                    "the kernel is bound by instruction issue (Philox blocks: half of it), not by HBM") if fused else None,
+                                    "the kernel is bound by instruction issue and by the walks of the float32-rounded running "
+                                    "sums, not by HBM (priced against the reference's dataflow as SURVEY.md 8d prescribes)") if fused else None,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "

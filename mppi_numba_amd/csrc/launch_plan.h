@@ -350,20 +350,27 @@ struct ScanPlan {
   int tile = 32;       // rollouts per workgroup: 32 (two lanes per rollout) or 64
   size_t lds = 0;
   bool pow2res = false;
+  bool exact = false;  // k_rollout_scan_exact: the three running sums walked with the reference's roundings
 };
 
 static bool scan_plan(const mppi_planner* p, ScanPlan* out) {
   static const bool disabled = getenv("MPPI_NO_SCAN") != nullptr;  // developer switch (ablation)
   if (disabled || (p->debug_flags & MPPI_DEBUG_NO_SCAN_KERNEL)) return false;
-  if (p->cfg.math != MPPI_MATH_FAST || p->cfg.mode != MPPI_MODE_DET) return false;
+  if (p->cfg.mode != MPPI_MODE_DET) return false;
   if (!p->cells16_valid || p->cells16_with_risk) return false;
   if (p->speculation_off && !(p->debug_flags & MPPI_DEBUG_KEEP_SPECULATING)) return false;
   const int T = p->cfg.num_steps;
   ScanPlan plan;
+  plan.exact = p->cfg.math == MPPI_MATH_EXACT;
   plan.waves = ceil_div(T, 8);
   if (plan.waves > 16) return false;
-  plan.tile = (p->debug_flags & MPPI_DEBUG_SCAN_FULL_TILES) ? 64 : 32;
-  plan.lds = plan.tile == 64 ? ScanLds<64>::total(plan.waves) : ScanLds<32>::total(plan.waves);
+  plan.tile = (!plan.exact && (p->debug_flags & MPPI_DEBUG_SCAN_FULL_TILES)) ? 64 : 32;
+  // one round of workgroups over the CUs: beyond that the kernels with one wave per tile win (a
+  // 32-rollout workgroup lasts ~10 us whatever N is: N = 16384 would be two rounds against 18 us
+  // of k_rollout_deep, N = 65536 eight against 78 us of k_rollout_fused)
+  if (ceil_div(p->n_local, plan.tile) > p->num_cus) return false;
+  plan.lds = plan.exact ? ScanExactLds::total(plan.waves)
+                        : (plan.tile == 64 ? ScanLds<64>::total(plan.waves) : ScanLds<32>::total(plan.waves));
   // (the accumulating wave reads up to two groups of records past the last one: keep that inside the allocation)
   plan.lds = std::max(plan.lds, (size_t)40 * 1024);
   if (plan.lds > (size_t)p->lds_per_cu - 1024) return false;
@@ -427,13 +434,22 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
     // the waves that idle while one wave accumulates the costs, was measured: the stage gained is lost
     // again to the slower accumulation and the noise reads -- profiles/r03_scan_notes.md.)
     static const bool no_fused_noise = getenv("MPPI_NO_FUSED_NOISE") != nullptr;  // developer switch
-    if (p->next_noise_wanted && tiles < p->num_cus && !no_fused_noise && p->cfg.rng == MPPI_RNG_PHILOX) {
+    if (p->next_noise_wanted && tiles < p->num_cus && !no_fused_noise && p->cfg.rng == MPPI_RNG_PHILOX && !plan.exact) {
       extra = p->num_cus - tiles;
       next_job = make_noise_job(p, p->noise_buf[p->noise_cur ^ 1]);
       p->next_noise_done = true;
     }
   }
   p->spec_tiles_launched += (uint64_t)tiles;
+#define MPPI_LAUNCH_SCAN_EXACT(P2, GEN)                                                                    \
+  do {                                                                                                    \
+    auto kern = k_rollout_scan_exact<P2, GEN>;                                                            \
+    if (plan.lds > 64 * 1024)                                                                             \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));            \
+    MPPI_KLAUNCH(kern, dim3(tiles), dim3(64 * plan.waves), plan.lds, p->stream, d, p->cells16, p->cells,  \
+                 p->noise, gen_job, p->u, p->costs, p->w_rel, pk);                                         \
+  } while (0)
 #define MPPI_LAUNCH_SCAN(RR, P2, GEN)                                                                      \
   do {                                                                                                    \
     auto kern = k_rollout_scan<RR, P2, GEN>;                                                              \
@@ -448,17 +464,23 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
     if (gen) MPPI_LAUNCH_SCAN(RR, P2, true);     \
     else MPPI_LAUNCH_SCAN(RR, P2, false);        \
   } while (0)
-  if (plan.tile == 64 && plan.pow2res) MPPI_LAUNCH_SCAN_G(64, true);
+  if (plan.exact) {
+    if (plan.pow2res && gen) MPPI_LAUNCH_SCAN_EXACT(true, true);
+    else if (plan.pow2res) MPPI_LAUNCH_SCAN_EXACT(true, false);
+    else if (gen) MPPI_LAUNCH_SCAN_EXACT(false, true);
+    else MPPI_LAUNCH_SCAN_EXACT(false, false);
+  } else if (plan.tile == 64 && plan.pow2res) MPPI_LAUNCH_SCAN_G(64, true);
   else if (plan.tile == 64) MPPI_LAUNCH_SCAN_G(64, false);
   else if (plan.pow2res) MPPI_LAUNCH_SCAN_G(32, true);
   else MPPI_LAUNCH_SCAN_G(32, false);
 #undef MPPI_LAUNCH_SCAN_G
 #undef MPPI_LAUNCH_SCAN
+#undef MPPI_LAUNCH_SCAN_EXACT
   HIP_TRY(hipGetLastError());
   char buf[256];
   snprintf(buf, sizeof(buf),
-           "k_rollout_scan tile=%d waves=%d pow2res=%d noise=%s lds=%zu noise_blocks=%d problems=%d",
-           plan.tile, plan.waves, (int)plan.pow2res, gen ? "in-kernel" : "read", plan.lds, extra, p->inst_set ? p->B : 0);
+           "k_rollout_scan%s tile=%d waves=%d pow2res=%d noise=%s lds=%zu noise_blocks=%d problems=%d",
+           plan.exact ? "_exact" : "", plan.tile, plan.waves, (int)plan.pow2res, gen ? "in-kernel" : "read", plan.lds, extra, p->inst_set ? p->B : 0);
   p->last_rollout = buf;
   p->tile_packets_fresh = false;  // (w_rel is relative to this kernel's own tiles: tbeta, not tile_beta)
   p->scan_packets_fresh = true;
@@ -812,7 +834,7 @@ static int launch_rollout_det(mppi_planner* p, DevParams d) {
   size_t lds_win = 0;
   bool have_window = plan_lds_window(p, d, &lds_win);
   TRY(upload_instances(p));
-  if (!EXACT) {
+  {
     ScanPlan plan;
     if (scan_plan(p, &plan)) return launch_scan(p, d, plan);
   }

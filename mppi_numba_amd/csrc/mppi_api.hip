@@ -23,6 +23,7 @@
 #include "rollout_spec_kernel.h"
 #include "rollout_deep_kernel.h"
 #include "rollout_scan_kernel.h"
+#include "rollout_scan_exact_kernel.h"
 #include "map_kernels.h"
 #include "update_kernels.h"
 #include "world_kernels.h"

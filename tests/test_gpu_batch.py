@@ -55,7 +55,8 @@ def single_problem(cfg, lin, ang, params, x0, goal):
 
 
 @pytest.mark.parametrize("workload,n,t_steps,m,count,token", [
-    ("c2", 1024, 60, 1, 5, "k_rollout_deep"),           # deterministic traction, LDS reach windows
+    ("c2", 1024, 60, 1, 5, "k_rollout_scan_exact"),     # deterministic traction: 160 tiles of 32, one round
+    ("c2", 2048, 60, 1, 6, "k_rollout_deep"),           # 192 tiles of 64: one tile per CU, LDS reach windows
     ("c2", 256, 250, 1, 3, "k_rollout_"),               # long horizon: whole map or global cells
     ("c2", 4096, 30, 1, 12, "k_rollout_fused"),  # throughput regime: fused kernel, LDS windows
     ("c3", 128, 40, 64, 3, "k_rollout_tdm"),            # CVaR over M sampled maps
@@ -70,7 +71,7 @@ def test_batch_matches_single_problem_handles_and_oracle(workload, n, t_steps, m
     useqs = batch.solve()  # samples the traction maps; the stage-level calls below reuse them
     assert useqs.shape == (count, t_steps, 2) and np.isfinite(useqs).all()
     assert token in batch.last_rollout_kernel()
-    if token == "k_rollout_deep":
+    if token in ("k_rollout_deep", "k_rollout_scan_exact"):
         assert "problems=%d" % count in batch.last_rollout_kernel()
     # a different warm start per problem, then injected noise
     u_in = (useqs + rng.normal(0, 0.05, useqs.shape)).astype(np.float32)

@@ -28,7 +28,7 @@ def oracle_costs(w, params, lin, ang, noise, u):
 
 
 # which rollout kernel each BASELINE configuration must take (bench.py runs the same objects)
-EXPECTED_KERNEL = {"c2": "k_rollout_deep", "c3": "k_rollout_tdm_fast", "c4": "k_rollout_fused"}
+EXPECTED_KERNEL = {"c2": "k_rollout_scan_exact", "c3": "k_rollout_tdm_fast", "c4": "k_rollout_fused"}
 
 
 def costs_and_update_margin(workload, n):
@@ -395,7 +395,9 @@ def test_det_rollout_variants_vs_oracle(label, rows, cols, res, n, t_steps, x0, 
     lin.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)
     ang.set_TDM_from_PMF_grid(pmf[:, ::-1].copy(), td, obstacle, unknown)
     planner = MPPI_Numba(cfg)
-    planner.set_debug_flags(flags | 16)  # (16: keep the speculative kernels where the planner would switch to k_rollout_pipe)
+    # (16: keep the speculative kernels where the planner would switch to k_rollout_pipe; 32: the kernels
+    #  this test pins are what runs beyond one round of the time-parallel kernel -- N > 8192, T > 120)
+    planner.set_debug_flags(flags | 16 | 32)
     params = bench.make_params("c2")
     params.update(x0=np.array(x0), xgoal=np.array([x0[0] + 3.0, x0[1] + 2.0]), lambda_weight=5.0)
     planner.setup(params, lin, ang)
@@ -471,7 +473,7 @@ def test_speculation_holds_then_fails_same_bits(kind, t_steps, n, flags):
     lin.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)
     ang.set_TDM_from_PMF_grid(ang_pmf, td, obstacle, unknown)
     planner = MPPI_Numba(cfg)
-    planner.set_debug_flags(flags | 16)  # (16: keep speculating where the planner would have given up, see below)
+    planner.set_debug_flags(flags | 16 | 32)  # (16: keep speculating where the planner would have given up, see below; 32: not the time-parallel kernel)
     params = bench.make_params("c2")
     params.update(x0=np.array([25.1, 24.9, 0.7]), xgoal=np.array([40.0, 38.0]), lambda_weight=5.0)
     if kind == "ring":
@@ -530,7 +532,7 @@ def test_planner_stops_speculating_on_a_map_where_it_does_not_pay():
     planner.setup(params, lin, ang)
     lin.sample_grids()  # (solve() does this; the stage-level calls do not)
     ang.sample_grids()
-    check(planner, lin, ang, "k_rollout_deep")  # nothing known about this map yet
+    check(planner, lin, ang, "k_rollout_scan_exact")  # nothing known about this map yet
     planner.solve()                             # ... the host synchronises, sees the failed tiles ...
     check(planner, lin, ang, "k_rollout_pipe")  # ... and stops speculating
     planner.iterate_async(3)
@@ -542,9 +544,9 @@ def test_planner_stops_speculating_on_a_map_where_it_does_not_pay():
     ang.set_TDM_from_PMF_grid(ang_pmf, td, obstacle, unknown)
     planner.setup(params, lin, ang)
     planner.solve()
-    check(planner, lin, ang, "k_rollout_deep")
+    check(planner, lin, ang, "k_rollout_scan_exact")
     planner.solve()
-    check(planner, lin, ang, "k_rollout_deep")
+    check(planner, lin, ang, "k_rollout_scan_exact")
 
 
 def test_overlapped_noise_generation_equals_in_line_generation():
@@ -653,7 +655,7 @@ def test_update_from_costs_has_the_bits_of_the_epilogue_path():
     a.sample_noise()
     noise = a.noise_samples_d.copy_to_host()
     a.rollout()
-    assert "k_rollout_deep" in a.last_rollout_kernel()
+    assert "k_rollout_scan_exact" in a.last_rollout_kernel()
     costs = a.costs_d.copy_to_host()
     a.update()
     b.set_u(u_in)

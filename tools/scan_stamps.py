@@ -24,11 +24,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--math", default="fast", choices=["fast", "exact"])
     args = ap.parse_args()
     from mppi_numba_amd import _lib
     with contextlib.redirect_stdout(io.StringIO()):
         from bench import build_planner as build
-        w, cfg, lin, ang, planner, params = build("c2", args.n, math="fast")
+        w, cfg, lin, ang, planner, params = build("c2", args.n, math=args.math)
         planner.set_debug_flags(args.flags)
         planner.solve()
         planner.iterate_async(20)
