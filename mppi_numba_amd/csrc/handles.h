@@ -109,6 +109,7 @@ struct mppi_planner {
   float* tile_beta = nullptr;  // [n_tiles] minimum cost of each tile of 64 rollouts
   int n_tiles = 0;
   bool tile_packets_fresh = false;  // w_rel / tile_beta written by the rollout kernel for the current costs
+  bool theta_bounded = false;  // |heading| < 5e4 rad over the horizon (decided per launch: launch_rollout)
   // k_rollout_scan (MPPI_MATH_FAST): per-tile sums of w_rel * noise, consumed by k_combine_tiles
   float2* tnum = nullptr;  // [T][tiles]
   float* tden = nullptr;   // [tiles]

@@ -504,6 +504,7 @@ struct DetRegime {
   size_t lds_win;         // ... bytes of {staged controls, window}
   bool rot_ok;            // incremental trig applies (|dt*w*traction| <= 0.36 rad, T <= 2000, exact math)
   bool pow2res;           // resolution is a power of two: four-instruction cell coordinates
+  bool rot_ok_fast;       // ... the same bound under MPPI_MATH_FAST (k_rollout_fused<one pass>)
   bool fast_deep_ok;      // MPPI_MATH_FAST: |theta| stays inside v_sin_f32's range
   bool keep_speculating;  // the map has not (yet) proved the traction assumption a loss
 };
@@ -792,16 +793,18 @@ static int launch_windowed_or_general(mppi_planner* p, DevParams& d, const DetRe
     const int waves = fused_waves_per_workgroup(p, N);
     int block = 64 * waves;
     static const bool no_fused = getenv("MPPI_NO_FUSED") != nullptr;  // developer switch (ablation)
-    if (rot_ok && !no_fused) {
-      auto fused = pow2res ? k_rollout_fused<true> : k_rollout_fused<false>;
+    if ((rot_ok || r.rot_ok_fast) && !no_fused) {
+      // (MPPI_MATH_FAST: one pass over the noise, the control cost added once)
+      auto fused = EXACT ? (pow2res ? k_rollout_fused<true> : k_rollout_fused<false>)
+                         : (pow2res ? k_rollout_fused<true, false, true> : k_rollout_fused<false, false, true>);
       if (lds_win > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fused),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
       MPPI_KLAUNCH(fused, dim3(ceil_div(N, block)), dim3(block), lds_win, p->stream, d, p->cells16,
                          p->noise, p->u, p->costs, p->w_rel, p->tile_beta);
       char buf[200];
-      snprintf(buf, sizeof(buf), "k_rollout_fused pow2res=%d waves_per_wg=%d window=%dx%d problems=%d",
-               (int)pow2res, waves, d.win_rows, d.win_cols, p->inst_set ? p->B : 0);
+      snprintf(buf, sizeof(buf), "k_rollout_fused%s pow2res=%d waves_per_wg=%d window=%dx%d problems=%d",
+               EXACT ? "" : "<one pass>", (int)pow2res, waves, d.win_rows, d.win_cols, p->inst_set ? p->B : 0);
       p->last_rollout = buf;
       p->tile_packets_fresh = true;
             return MPPI_OK;
@@ -839,13 +842,14 @@ static int launch_rollout_det(mppi_planner* p, DevParams d) {
     if (scan_plan(p, &plan)) return launch_scan(p, d, plan);
   }
   // incremental trig: needs a heading increment |dt*w*traction| <= 0.36 rad and T <= 2000
-  bool rot_ok = false, pow2res = false;
+  bool rot_ok = false, rot_ok_fast = false, pow2res = false;
   {
     const mppi_params& a = p->params;
     double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
     double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
     double dmax = (double)a.dt * wmax * trmax;
     rot_ok = EXACT && BOUNDED && std::isfinite(dmax) && dmax <= 0.36 && T <= 2000;
+    rot_ok_fast = !EXACT && p->theta_bounded && std::isfinite(dmax) && dmax <= 0.36 && T <= 2000;
     int res_exp = 0;
     pow2res = std::frexp((double)a.res, &res_exp) == 0.5;  // res == 2^k exactly
   }
@@ -863,7 +867,7 @@ static int launch_rollout_det(mppi_planner* p, DevParams d) {
   }
   const bool keep_speculating = !p->speculation_off || (p->debug_flags & MPPI_DEBUG_KEEP_SPECULATING);
   DetRegime r;
-  r.have_window = have_window; r.lds_win = lds_win; r.rot_ok = rot_ok; r.pow2res = pow2res;
+  r.have_window = have_window; r.lds_win = lds_win; r.rot_ok = rot_ok; r.rot_ok_fast = rot_ok_fast; r.pow2res = pow2res;
   r.fast_deep_ok = fast_deep_ok; r.keep_speculating = keep_speculating;
   bool launched = false;
   TRY(try_launch_deep<EXACT>(p, d, r, &launched));
@@ -889,19 +893,20 @@ static int launch_rollout_speed_map(mppi_planner* p, DevParams d) {
   double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
   double dmax = (double)a.dt * wmax * trmax;
   static const bool no_fused = getenv("MPPI_NO_FUSED") != nullptr;  // developer switch (ablation)
-  if (have_window && EXACT && BOUNDED && std::isfinite(dmax) && dmax <= 0.36 && T <= 2000 && !no_fused) {
+  if (have_window && (BOUNDED || (!EXACT && p->theta_bounded)) && std::isfinite(dmax) && dmax <= 0.36 && T <= 2000 && !no_fused) {
     const int waves = fused_waves_per_workgroup(p, N);
     int res_exp = 0;
     const bool pow2res = std::frexp((double)a.res, &res_exp) == 0.5;
-    auto fused = pow2res ? k_rollout_fused<true, true> : k_rollout_fused<false, true>;
+    auto fused = EXACT ? (pow2res ? k_rollout_fused<true, true> : k_rollout_fused<false, true>)
+                       : (pow2res ? k_rollout_fused<true, true, true> : k_rollout_fused<false, true, true>);
     if (lds_win > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fused),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
     MPPI_KLAUNCH(fused, dim3(ceil_div(N, 64 * waves)), dim3(64 * waves), lds_win, p->stream, d, p->cells16,
                        p->noise, p->u, p->costs, p->w_rel, p->tile_beta);
     char buf[200];
-    snprintf(buf, sizeof(buf), "k_rollout_fused speed_map pow2res=%d waves_per_wg=%d window=%dx%d problems=%d",
-             (int)pow2res, waves, d.win_rows, d.win_cols, p->inst_set ? p->B : 0);
+    snprintf(buf, sizeof(buf), "k_rollout_fused%s speed_map pow2res=%d waves_per_wg=%d window=%dx%d problems=%d",
+             EXACT ? "" : "<one pass>", (int)pow2res, waves, d.win_rows, d.win_cols, p->inst_set ? p->B : 0);
     p->last_rollout = buf;
     p->tile_packets_fresh = true;
     HIP_TRY(hipGetLastError());
@@ -942,7 +947,7 @@ static int launch_rollout_tdm(mppi_planner* p, DevParams d) {
     double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
     double dmax = (double)a.dt * wmax * trmax;
     const size_t lds_fast = (sizeof(double2) + sizeof(double)) * (size_t)T + sizeof(float) * (size_t)mp2;
-    if (EXACT && BOUNDED && std::isfinite(dmax) && dmax <= 0.36 && T <= 2000 && lds_fast <= 64 * 1024) {
+    if ((BOUNDED || (!EXACT && p->theta_bounded)) && std::isfinite(dmax) && dmax <= 0.36 && T <= 2000 && lds_fast <= 64 * 1024) {
       int res_exp = 0;
       const bool pow2res = std::frexp((double)a.res, &res_exp) == 0.5;
       float* sc_out = sc_dst;
@@ -960,13 +965,13 @@ static int launch_rollout_tdm(mppi_planner* p, DevParams d) {
         }
       }
       if (pow2res)
-        MPPI_KLAUNCH((k_rollout_tdm_fast<true>), dim3(N + extra), dim3(threads), lds_fast, p->stream, d, p->cells,
+        MPPI_KLAUNCH((k_rollout_tdm_fast<true, !EXACT>), dim3(N + extra), dim3(threads), lds_fast, p->stream, d, p->cells,
                            p->noise, p->u, p->costs, sc_out, mp2, N, next_job);
       else
-        MPPI_KLAUNCH((k_rollout_tdm_fast<false>), dim3(N + extra), dim3(threads), lds_fast, p->stream, d, p->cells,
+        MPPI_KLAUNCH((k_rollout_tdm_fast<false, !EXACT>), dim3(N + extra), dim3(threads), lds_fast, p->stream, d, p->cells,
                            p->noise, p->u, p->costs, sc_out, mp2, N, next_job);
-      p->last_rollout = std::string("k_rollout_tdm_fast pow2res=") + (pow2res ? "1" : "0") +
-                        " noise_blocks=" + std::to_string(extra);
+      p->last_rollout = std::string(EXACT ? "k_rollout_tdm_fast" : "k_rollout_tdm_fast<cost f32>") + " pow2res=" +
+                        (pow2res ? "1" : "0") + " noise_blocks=" + std::to_string(extra);
       HIP_TRY(hipGetLastError());
       return MPPI_OK;
     }
@@ -1020,6 +1025,7 @@ static int launch_rollout(mppi_planner* p, const DevParams& d) {
   }
   double theta_bound = th0_max + (double)p->cfg.num_steps * (double)a.dt * wmax * trmax;
   bool bounded = std::isfinite(theta_bound) && theta_bound < 5.0e4;
+  p->theta_bounded = bounded;
   if (p->cfg.math != MPPI_MATH_EXACT) return launch_rollout_t<false, false>(p, d);
   return bounded ? launch_rollout_t<true, true>(p, d) : launch_rollout_t<true, false>(p, d);
 }
@@ -1323,7 +1329,8 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
       (void)plan_lds_window(p, plan, &unused);
       TRY(upload_instances(p));
     }
-    if ((!have_noise || !p->graph_warm) && k < iterations) {
+    // (a rollout kernel that computes its own noise has nothing to prime: its iterations are alike from the start)
+    if (((!have_noise && !scan_generates_noise(p)) || !p->graph_warm) && k < iterations) {
       TRY(launch_iteration(p, d, have_noise, true, false));
       p->graph_warm = true;
       ++k;

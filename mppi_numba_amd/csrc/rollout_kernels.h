@@ -341,8 +341,20 @@ __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
 // float32 stores of x, y, theta and of the running cost.  After the goal is reached the
 // state keeps integrating (harmless: only the cost is frozen), as in the pipelined kernel.
 // LDS: [T] double2 control ratios | [T] float2 u | window of 16-bit cells.
+//
+// ONEPASS (MPPI_MATH_FAST): state AND stage costs keep the reference's rounding points -- on a map
+// whose traction changes from cell to cell a trajectory one ulp off reads another cell once in ~10^5
+// steps, and a rollout stopped in a zero-traction cell adds the SAME stage cost for the rest of the
+// horizon, so a float32 addend that rounds the other way does so on every one of those steps (measured:
+// 0.4 % of the costs up to 50 ulp off, tests/test_gpu_fast_throughput.py) -- but the control cost is ONE
+// float32 accumulator filled while the noise goes by and added after the terminal cost: the second
+// pass over the noise (the reference's order, mppi.py:1005-1009) disappears.  The price is the
+// reference's own rounding noise: its T float32-rounded additions of control-cost terms are not
+// reproduced (sqrt(T / 12) ulp rms: 99.9 % of the costs within 7e-7 at T = 100, 1.2e-6 at T = 200;
+// the floor of ANY single-pass design, tests/test_cost_order_noise.py).
+// LDS (ONEPASS): [T] float2 control ratios in the double2 area.
 // -------------------------------------------------------------------------
-template <bool POW2RES, bool SPEED = false>
+template <bool POW2RES, bool SPEED = false, bool ONEPASS = false>
 __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells16,
                                 const float2* __restrict__ noise, const float2* __restrict__ u,
                                 float* __restrict__ costs, float* __restrict__ w_rel,
@@ -355,13 +367,23 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
   uint16_t* lds_map = reinterpret_cast<uint16_t*>(uos + T + (T + 1) / 2);
   copy_window_to_lds<SPEED ? 4 : 2>(P, cells16, lds_map, 0, (int)blockDim.x);
   for (int t = threadIdx.x; t < T; t += blockDim.x) us[t] = u[t];
-  stage_control_ratios(P, u, uos);  // ends with a barrier
+  float2* ratio32 = reinterpret_cast<float2*>(uos);
+  if constexpr (ONEPASS) {
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+      const float2 ut = u[t];
+      ratio32[t] = make_float2((float)((double)ut.x / P.s0sq), (float)((double)ut.y / P.s1sq));
+    }
+    __syncthreads();
+  } else {
+    stage_control_ratios(P, u, uos);  // ends with a barrier
+  }
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = n < N;
   const int nn = live ? n : N - 1;
   const float2* col = noise + tile_index(0, nn, T);  // this lane's column; rows are 64 apart
 
   float x = P.x0, y = P.y0, th = P.th0, cost = 0.0f;
+  [[maybe_unused]] float cc32 = 0.0f;
   double x64 = (double)x, y64 = (double)y, th64 = (double)th, d2 = 1e9;
   double s, c;
   sincos_f64<false>(th64, s, c);
@@ -372,7 +394,7 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
   const int win_pitch_bytes = (SPEED ? 4 : 2) * P.win_cols;
   const char* lds_bytes = reinterpret_cast<const char*>(lds_map);
 
-  auto step = [&](float2 ut, float2 e) {
+  auto step = [&](float2 ut, float2 e, [[maybe_unused]] int t) {
     int xi, yi;
     if (POW2RES) {  // res is a power of two: see cell_coord_pow2
       xi = cell_coord_pow2(x, P.xlo, P.inv_res, win_c0f, win_last_col);
@@ -404,16 +426,22 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
     const double th_new = (double)th;
     rotate_sincos_f64(th_new - th64, s, c);  // exact increment of the ROUNDED heading
     th64 = th_new;
-    const double dx = (double)(P.xg - x), dy = (double)(P.yg - y);
-    const double nd2 = fma(dx, dx, dy * dy);
-    float c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(nd2), step_time));
-    c1 = c1 + ((c16 & 0x4000u) ? P.obs_cost : 0.0f);  // cell the step STARTED in (mppi.py:971-998)
-    c1 = c1 + ((c16 & 0x8000u) ? P.unk_cost : 0.0f);
-    const bool hit = nd2 <= gt2, act = !done;
-    cost = act ? c1 : cost;
-    d2 = act ? nd2 : d2;
-    reached = reached || (act && hit);
-    done = done || hit;
+    if constexpr (ONEPASS) {
+      const float2 rt = ratio32[t];  // every step's term, also past the goal (mppi.py:1007-1009)
+      cc32 = fmaf(rt.x, e.x, fmaf(rt.y, e.y, cc32));
+    }
+    {
+      const double dx = (double)(P.xg - x), dy = (double)(P.yg - y);
+      const double nd2 = fma(dx, dx, dy * dy);
+      float c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(nd2), step_time));
+      c1 = c1 + ((c16 & 0x4000u) ? P.obs_cost : 0.0f);  // cell the step STARTED in (mppi.py:971-998)
+      c1 = c1 + ((c16 & 0x8000u) ? P.unk_cost : 0.0f);
+      const bool hit = nd2 <= gt2, act = !done;
+      cost = act ? c1 : cost;
+      d2 = act ? nd2 : d2;
+      reached = reached || (act && hit);
+      done = done || hit;
+    }
   };
 
   float2 e_cur[kNoiseBatch], e_nxt[kNoiseBatch];
@@ -424,17 +452,23 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
 #pragma unroll
     for (int j = 0; j < kNoiseBatch; ++j) e_nxt[j] = col[(size_t)min(t0 + kNoiseBatch + j, T - 1) * 64];
 #pragma unroll
-    for (int j = 0; j < kNoiseBatch; ++j) step(us[t0 + j], e_cur[j]);
+    for (int j = 0; j < kNoiseBatch; ++j) step(us[t0 + j], e_cur[j], t0 + j);
 #pragma unroll
     for (int j = 0; j < kNoiseBatch; ++j) e_cur[j] = e_nxt[j];
-    if (__all(done)) break;
+    if (!ONEPASS && __all(done)) break;  // (ONEPASS: the control cost needs every step's noise)
   }
-  if (!__all(done))
-    for (int t = t0; t < T; ++t) step(us[t], e_cur[t - t0]);
+  if (ONEPASS || !__all(done))
+    for (int t = t0; t < T; ++t) step(us[t], e_cur[t - t0], t);
 
   // terminal cost, then the control cost of all T steps (mppi.py:1005-1009): the float32-rounded
   // accumulation is sequential, loads and products are batched
   cost = (float)((double)cost + (reached ? 0.0 : 1.0) * sqrt(d2) / P.v_post_den);
+  if constexpr (ONEPASS) {
+    cost = (float)fma((double)P.lambda, (double)cc32, (double)cost);
+    if (live) costs[n] = cost;
+    if ((n & ~63) < N) emit_tile_weights(cost, live, P.lambda, n, n >> 6, w_rel, tile_beta);
+    return;
+  }
   for (t0 = 0; t0 + kNoiseBatch <= T; t0 += kNoiseBatch) {
     double cc[kNoiseBatch];
 #pragma unroll
@@ -859,7 +893,11 @@ __global__ void k_rollout_tdm(DevParams P, const uint32_t* __restrict__ cellsM,
 // Workgroups past the N control samples (the end of the grid: they start as the first rollout
 // workgroups retire) generate the noise of the NEXT iteration into the other buffer, which saves
 // the stand-alone generator's launch (5.9 us of 161 at C3).
-template <bool POW2RES>
+// COSTF32 (MPPI_MATH_FAST): as in k_rollout_fused<cost f32> the state keeps the reference's rounding
+// points (every lane walks its OWN sampled map: an ulp of drift is another cell) and the cost side is
+// float32; the control cost of a control sample is the same for its M traction samples: one float64
+// sum per workgroup, added once (the reference adds its T terms to every sample's running cost).
+template <bool POW2RES, bool COSTF32 = false>
 __global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cellsM,
                                    const float2* __restrict__ noise, const float2* __restrict__ u,
                                    float* __restrict__ costs, float* __restrict__ sample_costs, int m_pow2,
@@ -886,6 +924,13 @@ __global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cel
     cc_sh[t] = control_cost(P, make_double2((double)ut.x / P.s0sq, (double)ut.y / P.s1sq), e);
   }
   __syncthreads();
+  [[maybe_unused]] float cc_total = 0.0f;
+  if constexpr (COSTF32) {  // (every wave sums for itself: T/64 reads per lane, no second barrier)
+    double part = 0.0;
+    for (int t = threadIdx.x & 63; t < T; t += 64) part += cc_sh[t];
+    cc_total = (float)wave_sum_f64(part);
+  }
+  [[maybe_unused]] const float dwf = (float)P.dist_weight, gt2f = P.gt2;
   const double gt2 = (double)P.gt2;
   const float last_col = (float)(P.cols - 1), last_row = (float)(P.rows - 1);
   for (int m = threadIdx.x; m < m_pow2; m += blockDim.x) {
@@ -898,6 +943,7 @@ __global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cel
     double s, c;
     sincos_f64<false>(th64, s, c);
     bool done = false, reached = false;
+    [[maybe_unused]] float d2f = 1e9f;
     auto step = [&](int t) {
       double2 qd = qd_sh[t];
       int xi, yi;
@@ -914,12 +960,23 @@ __global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cel
       float nx = (float)fma(vtr, qd.x * c, x64);
       float ny = (float)fma(vtr, qd.x * s, y64);
       float nth = (float)fma(wtr, qd.y, th64);
-      double dx = (double)(P.xg - nx), dy = (double)(P.yg - ny);
-      double nd2 = fma(dx, dx, dy * dy);
-      float c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(nd2), dt64));
+      double nd2 = 0.0;
+      float c1;
+      bool hit;
+      [[maybe_unused]] float nd2f = 0.0f;
+      if constexpr (COSTF32) {
+        const float dxf = P.xg - nx, dyf = P.yg - ny;
+        nd2f = fmaf(dxf, dxf, dyf * dyf);
+        c1 = cost + fmaf(dwf, __builtin_sqrtf(nd2f), P.dt);
+        hit = nd2f <= gt2f;
+      } else {
+        double dx = (double)(P.xg - nx), dy = (double)(P.yg - ny);
+        nd2 = fma(dx, dx, dy * dy);
+        c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(nd2), dt64));
+        hit = nd2 <= gt2;
+      }
       c1 = c1 + (float)(int8_t)((cell >> 16) & 0xff) * P.obs_cost;
       c1 = c1 + (float)(int8_t)(cell >> 24) * P.unk_cost;
-      bool hit = nd2 <= gt2;
       bool act = !done;
       // the state may run on after the goal: only cost, d2 and the flags are frozen
       x = nx; y = ny; th = nth;
@@ -928,7 +985,8 @@ __global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cel
       rotate_sincos_f64<true>(th_new - th64, s, c);
       th64 = th_new;
       cost = act ? c1 : cost;
-      d2 = act ? nd2 : d2;
+      if constexpr (COSTF32) d2f = act ? nd2f : d2f;
+      else d2 = act ? nd2 : d2;
       reached = reached || (act && hit);
       done = done || hit;
     };
@@ -945,9 +1003,14 @@ __global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cel
     if (!__all(done))
       for (; t < T; ++t) step(t);
     // control cost of all T steps, then the terminal cost (mppi.py:706-713)
-    for (int t = 0; t < T; ++t) cost = (float)((double)cost + cc_sh[t]);
-    double term = (reached ? 0.0 : 1.0) * sqrt(d2) / P.v_post_den;
-    cost = (float)((double)cost + term);
+    if constexpr (COSTF32) {
+      cost = cost + cc_total;
+      cost = cost + (reached ? 0.0f : __builtin_sqrtf(d2f) * (float)P.inv_v_post_den);
+    } else {
+      for (int t = 0; t < T; ++t) cost = (float)((double)cost + cc_sh[t]);
+      double term = (reached ? 0.0 : 1.0) * sqrt(d2) / P.v_post_den;
+      cost = (float)((double)cost + term);
+    }
     sc[m] = cost;
     if (sample_costs) sample_costs[(size_t)n * M + m] = cost;
   }

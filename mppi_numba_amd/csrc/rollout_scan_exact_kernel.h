@@ -111,7 +111,10 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   double* p1 = p0 + (size_t)Tp * R;                                              // [Tp][R]
   char* rec = reinterpret_cast<char*>(p0);                                       // [K][R] {double sg[CHL], float po[CHL], float pu[CHL]}
   float2* pos = reinterpret_cast<float2*>(p1 + (size_t)Tp * R);                  // [Tp + 1][R]
-  float* th_sh = reinterpret_cast<float*>(pos);                                  // [Tp][R] (before the positions exist)
+  // the headings live in the UPPER half of the position rows: the position walk, which starts while
+  // other waves still read headings, overwrites heading t' = 2t - Tp <= t when it stores position t,
+  // and it gets to step t only after every wave up to step t's has finished with its headings
+  float* th_sh = reinterpret_cast<float*>(pos) + (size_t)Tp * R;                 // [Tp][R]
   char* small = reinterpret_cast<char*>(pos) + L::p2(W);
   double2* uos = reinterpret_cast<double2*>(small);                              // [Tp] u / std^2
   double* fz_k = reinterpret_cast<double*>(uos + Tp);                            // [R]
@@ -122,12 +125,26 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   int* fz_count = reinterpret_cast<int*>(fz_pu + R);                             // [R]
   float* wsh = reinterpret_cast<float*>(fz_count + R);                           // [R]
   uint32_t* flags = reinterpret_cast<uint32_t*>(wsh + R);
+  // The walks start before the stage that feeds them has ended everywhere: wave g raises done_a[g]
+  // when the increments of ITS 8 steps are in LDS (done_b[g]: its position increments), and the
+  // walking wave waits for the flag of the group it is about to read -- the waves finish their
+  // Philox blocks a SIMD's worth at a time, and the walk of the first groups fits in between.
+  int* done_a = reinterpret_cast<int*>(flags + 4);  // [16]
+  int* done_b = done_a + 16;                        // [16]
   if (c == 0 && lane < R) {
     evw[2 * lane] = 0u;
     evw[2 * lane + 1] = 0u;
     fz_count[lane] = 0;
-    if (lane == 0) flags[0] = 0u;
+    if (lane < 2) flags[lane] = 0u;  // [0] a failed vote, [1] a penalty somewhere in the tile
+    done_a[lane] = 0;  // (R = 32 >= the two arrays of 16)
   }
+  lds_barrier();  // (every wave has only just started)
+  auto raise = [&](int* flag) {
+    if (lane == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto wait_for = [&](const int* flag) {
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+  };
 
   // ---------------------------------------------------------------- A
   float2 ut[CHL];
@@ -169,8 +186,8 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   }
   const double vtr0 = fma(Q.lin_ratio, (double)(int)(ref & 127u), Q.lin_lo);
   const double wtr0 = fma(Q.ang_ratio, (double)(int)((ref >> 7) & 127u), Q.ang_lo);
+  raise(&done_a[c]);
   MPPI_STAMP(stamp_wg && c < 16, stamp_base + 1);
-  lds_barrier();
 
   // ---------------------------------------------------------------- W1: the heading walk
   // one running sum rounded to float32 after every fma (a lone wave issues an instruction per ~5
@@ -178,12 +195,15 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   // OUT: float rows of `out_stride` floats per step (R for the headings, 2 R for the float2
   // positions); every lane stores (lanes 32..63 mirror 0..31: the same value to the same address),
   // at immediate offsets from one pointer that moves once per 8 steps
-  auto walk = [&](const double* inc, double coeff, float start, float* out, auto out_stride_tag) {
+  auto walk = [&](const double* inc, const int* ready, double coeff, float start, float* out, auto out_stride_tag) {
     constexpr int OS = decltype(out_stride_tag)::value;
     const double* at = inc + r;
     float* to = out + r * (OS / R);
     double a[8], b[8];
-    auto load = [&](double (&dst)[8]) {
+    int g_next = 0;
+    auto load = [&](double (&dst)[8]) {  // the increments of the next group of 8 steps, once its wave has stored them
+      if (g_next < W) wait_for(&ready[g_next]);
+      ++g_next;
 #pragma unroll
       for (int q = 0; q < 8; ++q) dst[q] = at[(size_t)q * R];
       at += 8 * R;
@@ -211,7 +231,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   };
   if (c == 0) {
     __builtin_amdgcn_s_setprio(3);
-    (void)walk(p0, wtr0, Q.th0, th_sh, PhaseTag<R>());
+    (void)walk(p0, done_a, wtr0, Q.th0, th_sh, PhaseTag<R>());
     __builtin_amdgcn_s_setprio(0);
   } else {
     // meanwhile: lambda * (u0/s0^2 * e0 + u1/s1^2 * e1) in float64   (mppi.py:1007-1009)
@@ -246,20 +266,20 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
       }
     }
   }
+  raise(&done_b[c]);
   MPPI_STAMP(stamp_wg && c < 16, stamp_base + 3);
-  lds_barrier();
 
   // ---------------------------------------------------------------- W2: the position walks
   if (c == 0) {
     __builtin_amdgcn_s_setprio(3);
     float* px = reinterpret_cast<float*>(pos);
-    px[(size_t)Tp * 2 * R + 2 * r] = walk(p0, vtr0, Q.x0, px, PhaseTag<2 * R>());
-    if (W == 1) px[(size_t)Tp * 2 * R + 2 * r + 1] = walk(p1, vtr0, Q.y0, px + 1, PhaseTag<2 * R>());
+    px[(size_t)Tp * 2 * R + 2 * r] = walk(p0, done_b, vtr0, Q.x0, px, PhaseTag<2 * R>());
+    if (W == 1) px[(size_t)Tp * 2 * R + 2 * r + 1] = walk(p1, done_b, vtr0, Q.y0, px + 1, PhaseTag<2 * R>());
     __builtin_amdgcn_s_setprio(0);
   } else if (c == 1) {
     __builtin_amdgcn_s_setprio(3);
     float* py = reinterpret_cast<float*>(pos) + 1;
-    py[(size_t)Tp * 2 * R + 2 * r] = walk(p1, vtr0, Q.y0, py, PhaseTag<2 * R>());
+    py[(size_t)Tp * 2 * R + 2 * r] = walk(p1, done_b, vtr0, Q.y0, py, PhaseTag<2 * R>());
     __builtin_amdgcn_s_setprio(0);
   }
   MPPI_STAMP(stamp_wg && c < 16, stamp_base + 4);
@@ -326,6 +346,12 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     f_hit = f_d2 <= gt2;
   }
   if (ev != 0u) atomicOr(&evw[2 * r + ((2 * k) >> 5)], ev << ((2 * k) & 31));
+  {
+    bool pen = false;
+#pragma unroll
+    for (int j = 0; j < CHL; ++j) pen = pen || (j < nvalid && (po[j] != 0.0f || pu[j] != 0.0f));
+    if (__any(pen) && lane == 0) atomicOr(&flags[1], 1u);
+  }
   MPPI_STAMP(stamp_wg && c < 16, stamp_base + 5);
   lds_barrier();
 
@@ -373,53 +399,69 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     const bool failed = flags[0] != 0u;
     float cost = 0.0f;
     if (!failed) {
-      // records of 4 steps: {double sg[4]; float po[4]; float pu[4]} = 4 x 16 bytes, two records per group
-      constexpr int G = 2;
-      double2 ga[G * 2], gb[G * 2];
-      float4 fa[G * 2], fb[G * 2];
-      const char* at = rec + (size_t)r * 64;
-      auto load = [&](double2 (&d)[G * 2], float4 (&f)[G * 2]) {
+      // records of 4 steps: {double sg[4]; float po[4]; float pu[4]} = 4 x 16 bytes, two records per group.
+      // A tile that met no obstacle or unknown cell (flags[1] clear) adds +0.0f twice per step, which
+      // leaves a cost >= +0 as it is: its walk is the three instructions of the float64 add alone.
+      auto stage_walk = [&](auto pen_tag) {
+        constexpr bool PEN = decltype(pen_tag)::value != 0;
+        constexpr int G = 2;
+        double2 ga[G * 2], gb[G * 2];
+        float4 fa[G * 2], fb[G * 2];
+        const char* at = rec + (size_t)r * 64;
+        auto load = [&](double2 (&d)[G * 2], float4 (&f)[G * 2]) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const char* in = at + (size_t)g * R * 64;
-          d[2 * g] = reinterpret_cast<const double2*>(in)[0];
-          d[2 * g + 1] = reinterpret_cast<const double2*>(in)[1];
-          f[2 * g] = reinterpret_cast<const float4*>(in + 32)[0];
-          f[2 * g + 1] = reinterpret_cast<const float4*>(in + 32)[1];
-        }
-        at += (size_t)G * R * 64;
-      };
-      auto add_record = [&](const double2 (&d)[G * 2], const float4 (&f)[G * 2], int g) {
-        const double2 s01 = d[2 * g], s23 = d[2 * g + 1];
-        const float4 o = f[2 * g], q = f[2 * g + 1];
-        cost = (float)((double)cost + s01.x); cost = cost + o.x; cost = cost + q.x;  // mppi.py:994, 997, 998
-        cost = (float)((double)cost + s01.y); cost = cost + o.y; cost = cost + q.y;
-        cost = (float)((double)cost + s23.x); cost = cost + o.z; cost = cost + q.z;
-        cost = (float)((double)cost + s23.y); cost = cost + o.w; cost = cost + q.w;
-      };
-      load(ga, fa);
-      int i = 0;
-      for (; i + 2 * G <= K; i += 2 * G) {
-        load(gb, fb);
-#pragma unroll
-        for (int g = 0; g < G; ++g) add_record(ga, fa, g);
+          for (int g = 0; g < G; ++g) {
+            const char* in = at + (size_t)g * R * 64;
+            d[2 * g] = reinterpret_cast<const double2*>(in)[0];
+            d[2 * g + 1] = reinterpret_cast<const double2*>(in)[1];
+            if constexpr (PEN) {
+              f[2 * g] = reinterpret_cast<const float4*>(in + 32)[0];
+              f[2 * g + 1] = reinterpret_cast<const float4*>(in + 32)[1];
+            }
+          }
+          at += (size_t)G * R * 64;
+        };
+        auto step = [&](double sgv, float ov, float qv) {  // mppi.py:994, 997, 998
+          cost = (float)((double)cost + sgv);
+          if constexpr (PEN) {
+            cost = cost + ov;
+            cost = cost + qv;
+          }
+        };
+        auto add_record = [&](const double2 (&d)[G * 2], const float4 (&f)[G * 2], int g) {
+          const double2 s01 = d[2 * g], s23 = d[2 * g + 1];
+          const float4 o = f[2 * g], q = f[2 * g + 1];
+          step(s01.x, o.x, q.x);
+          step(s01.y, o.y, q.y);
+          step(s23.x, o.z, q.z);
+          step(s23.y, o.w, q.w);
+        };
         load(ga, fa);
+        int i = 0;
+        for (; i + 2 * G <= K; i += 2 * G) {
+          load(gb, fb);
 #pragma unroll
-        for (int g = 0; g < G; ++g) add_record(gb, fb, g);
-      }
-      if (i + G <= K) {
-        load(gb, fb);
+          for (int g = 0; g < G; ++g) add_record(ga, fa, g);
+          load(ga, fa);
 #pragma unroll
-        for (int g = 0; g < G; ++g) add_record(ga, fa, g);
-        i += G;
+          for (int g = 0; g < G; ++g) add_record(gb, fb, g);
+        }
+        if (i + G <= K) {
+          load(gb, fb);
 #pragma unroll
-        for (int g = 0; g < G - 1; ++g)
-          if (i + g < K) add_record(gb, fb, g);
-      } else {
+          for (int g = 0; g < G; ++g) add_record(ga, fa, g);
+          i += G;
 #pragma unroll
-        for (int g = 0; g < G - 1; ++g)
-          if (i + g < K) add_record(ga, fa, g);
-      }
+          for (int g = 0; g < G - 1; ++g)
+            if (i + g < K) add_record(gb, fb, g);
+        } else {
+#pragma unroll
+          for (int g = 0; g < G - 1; ++g)
+            if (i + g < K) add_record(ga, fa, g);
+        }
+      };
+      if (flags[1] != 0u) stage_walk(PhaseTag<1>());
+      else stage_walk(PhaseTag<0>());
       MPPI_STAMP(stamp_wg, stamp_base + 9);
       const int cnt = fz_count[r];
       if (__any(cnt > 0)) cost = frozen_block_exact(cost, fz_k[r], fz_po[r], fz_pu[r], cnt);
