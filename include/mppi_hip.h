@@ -295,6 +295,7 @@ int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity)
 #define MPPI_DEBUG_NO_SCAN_KERNEL 32     /* the float32 five-stage pipeline (k_rollout_deep<f32>) instead */
 #define MPPI_DEBUG_SCAN_READ_NOISE 64    /* the iteration loop stores its noise and the kernel reads it (as the stage-level calls do) */
 #define MPPI_DEBUG_SCAN_FULL_TILES 128   /* workgroups of 64 rollouts (one lane per rollout) instead of 32 (two) */
+#define MPPI_DEBUG_NO_FOLDED_APPLY 256   /* sharded handle: every iteration's update by its own k_apply launch, never by the next rollout launch */
 int mppi_planner_set_debug_flags(mppi_planner* p, int flags);
 int mppi_selftest_philox(int device, int* mismatches);
 /* developer instrumentation: in-kernel clock stamps of a -DMPPI_STAMPS build
@@ -391,6 +392,14 @@ int mppi_planner_sample_costs_local(mppi_planner* p, float* slab);
 int mppi_planner_sample_costs_apply(mppi_planner* p, const float* slabs, int count);
 int mppi_planner_update_local(mppi_planner* p, double* packet);
 int mppi_planner_update_apply(mppi_planner* p, const double* packets, int count);
+/* update_apply followed by the NEXT iteration's rollout (its noise already sampled) as one call: when
+ * that rollout is one of the time-parallel kernels its launch forms u from the packets itself (every
+ * wave the 8 steps it owns, k_apply's expressions and order: same bits) and no k_apply is launched --
+ * what mppi_planner_iterate_async does between the iterations of a sharded handle (a sharded iteration
+ * is then rollout, rank packet, all-gather: three launches instead of four).  Otherwise exactly
+ * update_apply + rollout. */
+int mppi_planner_update_apply_and_rollout(mppi_planner* p, const double* packets, int count, mppi_tdm* lin,
+                                          mppi_tdm* ang);
 
 #ifdef __cplusplus
 }

@@ -22,6 +22,7 @@ DEBUG_NO_SPEC_KERNEL, DEBUG_NO_SPECULATION, DEBUG_NO_DEEP_KERNEL, DEBUG_CC_GLOBA
 DEBUG_KEEP_SPECULATING = 16
 # MPPI_MATH_FAST, the time-parallel rollout kernel (include/mppi_hip.h)
 DEBUG_NO_SCAN_KERNEL, DEBUG_SCAN_READ_NOISE, DEBUG_SCAN_FULL_TILES = 32, 64, 128
+DEBUG_NO_FOLDED_APPLY = 256
 ABI_VERSION = 1
 
 
@@ -147,6 +148,7 @@ SIGNATURES = {
     "mppi_planner_packet_len": [_vp, C.POINTER(C.c_int)],
     "mppi_planner_update_local": [_vp, _f64p],
     "mppi_planner_update_apply": [_vp, _f64p, C.c_int],
+    "mppi_planner_update_apply_and_rollout": [_vp, _f64p, C.c_int, _vp, _vp],
 }
 
 _lib = None

@@ -103,6 +103,9 @@ struct mppi_planner {
   float2* staging = nullptr;  // (n_local,T) host-layout staging for set/get_noise
   float2* u = nullptr;        // [T]
   float2* u_prev = nullptr;   // [T]
+  float2* u_alt = nullptr;    // [T] the other control buffer of a sharded handle (launch_apply, PendingApply)
+  bool apply_pending = false; // the all-gathered packets hold an update the next rollout launch applies
+  uint64_t folded_applies = 0;
   float* costs = nullptr;     // [n_local]
   float* weights_out = nullptr;  // [n_local] normalised weights, filled on request
   float* w_rel = nullptr;      // [n_local] exp(-(c - beta_tile)/lambda)

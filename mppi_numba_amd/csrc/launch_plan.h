@@ -440,6 +440,21 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
       p->next_noise_done = true;
     }
   }
+  // a sharded iteration whose update has not been applied yet: this launch does it (PendingApply)
+  PendingApply pend;
+  memset(&pend, 0, sizeof(pend));
+  if (p->apply_pending) {
+    const mppi_params& a = p->params;
+    pend.packets = p->packets;
+    pend.u_out = p->u_alt;
+    pend.u_prev = p->u_prev;
+    pend.stats = p->stats;
+    pend.world = p->cfg.world_size;
+    pend.stride = p->B * packet_len(T);
+    pend.lambda = a.lambda_weight;
+    pend.v_lo = a.vrange[0]; pend.v_hi = a.vrange[1];
+    pend.w_lo = a.wrange[0]; pend.w_hi = a.wrange[1];
+  }
   p->spec_tiles_launched += (uint64_t)tiles;
 #define MPPI_LAUNCH_SCAN_EXACT(P2, GEN)                                                                    \
   do {                                                                                                    \
@@ -448,7 +463,7 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));            \
     MPPI_KLAUNCH(kern, dim3(tiles), dim3(64 * plan.waves), plan.lds, p->stream, d, p->cells16, p->cells,  \
-                 p->noise, gen_job, p->u, p->costs, p->w_rel, pk);                                         \
+                 p->noise, gen_job, p->u, p->costs, p->w_rel, pk, pend);                                   \
   } while (0)
 #define MPPI_LAUNCH_SCAN(RR, P2, GEN)                                                                      \
   do {                                                                                                    \
@@ -457,7 +472,7 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));            \
     MPPI_KLAUNCH(kern, dim3(tiles + extra), dim3(64 * plan.waves), plan.lds, p->stream, d, p->cells16,    \
-                 p->noise, gen_job, p->u, p->costs, p->w_rel, pk, tiles, next_job);                        \
+                 p->noise, gen_job, p->u, p->costs, p->w_rel, pk, tiles, next_job, pend);                  \
   } while (0)
 #define MPPI_LAUNCH_SCAN_G(RR, P2)               \
   do {                                           \
@@ -477,10 +492,17 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
 #undef MPPI_LAUNCH_SCAN
 #undef MPPI_LAUNCH_SCAN_EXACT
   HIP_TRY(hipGetLastError());
+  const bool applied_here = p->apply_pending;
+  if (applied_here) {  // the first tile's workgroup has written the updated sequence into the other buffer
+    std::swap(p->u, p->u_alt);
+    p->apply_pending = false;
+    ++p->folded_applies;
+  }
   char buf[256];
   snprintf(buf, sizeof(buf),
-           "k_rollout_scan%s tile=%d waves=%d pow2res=%d noise=%s lds=%zu noise_blocks=%d problems=%d",
-           plan.exact ? "_exact" : "", plan.tile, plan.waves, (int)plan.pow2res, gen ? "in-kernel" : "read", plan.lds, extra, p->inst_set ? p->B : 0);
+           "k_rollout_scan%s tile=%d waves=%d pow2res=%d noise=%s lds=%zu noise_blocks=%d problems=%d%s",
+           plan.exact ? "_exact" : "", plan.tile, plan.waves, (int)plan.pow2res, gen ? "in-kernel" : "read", plan.lds, extra,
+           p->inst_set ? p->B : 0, applied_here ? " applies_update=1" : "");
   p->last_rollout = buf;
   p->tile_packets_fresh = false;  // (w_rel is relative to this kernel's own tiles: tbeta, not tile_beta)
   p->scan_packets_fresh = true;
@@ -1007,11 +1029,15 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
 }
 
 
+static int launch_apply(mppi_planner* p);
+
 static int launch_rollout(mppi_planner* p, const DevParams& d) {
   REQUIRE(p->B == 1 || p->inst_set, MPPI_ERR_STATE,
           "num_instances = %d: call mppi_planner_set_instances before solving", p->B);
   REQUIRE((size_t)p->cfg.num_steps * sizeof(double2) <= 64 * 1024, MPPI_ERR_INVALID, "num_steps %d too large",
           p->cfg.num_steps);
+  // an update left to its consumer (launch_update) and a rollout kernel that will not take it
+  if (p->apply_pending && !(p->cfg.mode == MPPI_MODE_DET && scan_plan(p, nullptr))) TRY(launch_apply(p));
   // |theta| can never exceed |theta0| + T*dt*max|w|*max(traction): when that is far
   // inside the range of the two-term pi/2 reduction, the kernels drop the libm branch
   const mppi_params& a = p->params;
@@ -1124,18 +1150,31 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
   return MPPI_OK;
 }
 
+// (out of place into the handle's other control buffer, like an update applied by its consumer: every
+//  sharded iteration flips the two, and an even number of iterations -- a graph -- restores them)
 static int launch_apply(mppi_planner* p) {
   const mppi_params& a = p->params;
   hipLaunchKernelGGL(k_apply, dim3(p->B), dim3(kUpdateThreads), 0, p->stream, p->packets, p->cfg.world_size,
-                     p->cfg.rank, p->cfg.num_steps, a.lambda_weight, p->u, p->u_prev, (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0],
+                     p->cfg.rank, p->cfg.num_steps, a.lambda_weight, p->u, p->u_alt, p->u_prev,
+                     (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0],
                      a.vrange[1], a.wrange[0], a.wrange[1], p->stats);
   HIP_TRY(hipGetLastError());
+  std::swap(p->u, p->u_alt);
+  p->apply_pending = false;
   return MPPI_OK;
+}
+
+// Whether the NEXT rollout launch of this handle can apply a sharded update itself (PendingApply).
+static bool next_rollout_applies_updates(const mppi_planner* p) {
+  static const bool disabled = getenv("MPPI_NO_FOLDED_APPLY") != nullptr;  // developer switch (ablation)
+  return !disabled && !(p->debug_flags & MPPI_DEBUG_NO_FOLDED_APPLY) && p->B == 1 && !p->inst_set && p->m_count == 1 &&
+         p->cfg.world_size <= kMaxFoldedRanks && p->cfg.mode == MPPI_MODE_DET && !p->mirror_now && scan_plan(p, nullptr);
 }
 
 // `defer_exchange` (mppi_group_iterate_async): stop after this rank's packet; the caller issues the
 // all-gathers of all its devices inside one RCCL group and then launches k_apply on each
-static int launch_update(mppi_planner* p, bool prof, bool defer_exchange = false) {
+// `may_leave_apply`: another iteration follows on this stream: the update may be left to its rollout launch
+static int launch_update(mppi_planner* p, bool prof, bool defer_exchange = false, bool may_leave_apply = false) {
   p->mirror_done = p->mirror_now;
   if (defer_exchange) return launch_update_local(p, false);
   // (a communicator on a single rank is honoured too: it exercises the same path as N ranks)
@@ -1159,6 +1198,10 @@ static int launch_update(mppi_planner* p, bool prof, bool defer_exchange = false
   RCCL_TRY(g_rccl.AllGather(p->packets + (size_t)p->cfg.rank * len, p->packets, (size_t)len, ncclDouble, p->comm,
                             p->stream));
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[4], p->stream));
+  if (may_leave_apply && !prof && next_rollout_applies_updates(p)) {
+    p->apply_pending = true;
+    return MPPI_OK;
+  }
   return launch_apply(p);
 }
 
@@ -1166,7 +1209,7 @@ static int launch_update(mppi_planner* p, bool prof, bool defer_exchange = false
 // `want_next`), update}.  `have_noise`: noise_buf[noise_cur ^ 1] already holds this iteration's
 // noise; on return it says the same for the following iteration.
 static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_noise, bool want_next, bool prof,
-                            bool defer_exchange = false) {
+                            bool defer_exchange = false, bool may_leave_apply = false) {
   // (below ~4M rollout-steps the generator takes less than the ~12 us a cross-stream dependency costs)
   static const bool no_side_stream = getenv("MPPI_NO_SIDE_STREAM") != nullptr;  // developer switch
   // and above 8 rollout waves per CU the register file has no room for the generator's waves: it
@@ -1236,7 +1279,7 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
     ++p->ktime_index;
   }
   {
-    const int rc = launch_update(p, prof, defer_exchange);
+    const int rc = launch_update(p, prof, defer_exchange, may_leave_apply);
     p->kev_start = p->kev_stop = nullptr;
     TRY(rc);
   }
@@ -1251,7 +1294,7 @@ static void graph_signature(const mppi_planner* p, const DevParams& d, const mpp
   struct Sig {
     DevParams d;
     mppi_params params;
-    const void *lin, *ang, *cells, *cells16, *cc, *sample_costs;
+    const void *lin, *ang, *cells, *cells16, *cc, *sample_costs, *u;
     uint64_t lin_grid, ang_grid, lin_maps, epoch_bias;
     int noise_cur, inst_set, want_sample_costs, speculation_off, debug_flags, pad;
   } sig;
@@ -1264,7 +1307,7 @@ static void graph_signature(const mppi_planner* p, const DevParams& d, const mpp
     memset(sig.params.xgoal, 0, sizeof(sig.params.xgoal));
   }
   sig.lin = lin; sig.ang = ang; sig.cells = p->cells; sig.cells16 = p->cells16; sig.cc = p->cc_scratch;
-  sig.sample_costs = p->sample_costs;
+  sig.sample_costs = p->sample_costs; sig.u = p->u;
   sig.lin_grid = p->packed_lin_grid; sig.ang_grid = p->packed_ang_grid; sig.lin_maps = p->packed_lin_maps;
   sig.epoch_bias = p->noise_epoch - p->bumps_launched;
   sig.noise_cur = p->noise_cur; sig.inst_set = p->inst_set; sig.want_sample_costs = p->want_sample_costs;
@@ -1310,7 +1353,7 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
       // profiled iteration: a steady-state one when there is one, else the last
       bool prof = p->profile_stages && k == (iterations >= 3 ? iterations - 2 : iterations - 1);
       p->mirror_now = mirror_last && k == iterations - 1;
-      const int rc = launch_iteration(p, d, have_noise, true, prof);
+      const int rc = launch_iteration(p, d, have_noise, true, prof, false, k + 1 < iterations);
       p->mirror_now = false;
       TRY(rc);
     }
@@ -1349,7 +1392,9 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
         const uint64_t spec_before = p->spec_tiles_launched;
         HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
         int rc = MPPI_OK;
-        for (int j = 0; j < chunk && rc == MPPI_OK; ++j) rc = launch_iteration(p, d, have_noise, true, false);
+        // (the last iteration of a graph applies its update itself: a graph starts and ends with nothing pending)
+        for (int j = 0; j < chunk && rc == MPPI_OK; ++j)
+          rc = launch_iteration(p, d, have_noise, true, false, false, j + 1 < chunk);
         hipError_t end = hipStreamEndCapture(p->stream, &p->graph[slot]);
         if (rc != MPPI_OK) return rc;
         HIP_TRY(end);
@@ -1370,7 +1415,7 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
       ++p->graph_replays;
       k += chunk;
     }
-    for (; k < iterations; ++k) TRY(launch_iteration(p, d, have_noise, true, false));
+    for (; k < iterations; ++k) TRY(launch_iteration(p, d, have_noise, true, false, false, k + 1 < iterations));
     p->primed = have_noise;
   }
   if (timed) {

@@ -470,6 +470,7 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   dev_free(p->staging);
   dev_free(p->u);
   dev_free(p->u_prev);
+  dev_free(p->u_alt);
   dev_free(p->costs);
   dev_free(p->weights_out);
   dev_free(p->w_rel);
@@ -541,6 +542,7 @@ static int planner_alloc(mppi_planner* p) {
   const size_t B = (size_t)p->B;
   TRY(dev_alloc(&p->u, B * T));
   TRY(dev_alloc(&p->u_prev, B * T));
+  TRY(dev_alloc(&p->u_alt, B * T));
   TRY(dev_alloc(&p->inst_dev, B));
   HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&p->u_host), B * T * sizeof(float2), hipHostMallocMapped));
   HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&p->u_host_dev), p->u_host, 0));
@@ -558,6 +560,7 @@ static int planner_alloc(mppi_planner* p) {
   TRY(dev_alloc(&p->state_rollout, (size_t)c.num_vis_state_rollouts * (T + 1) * 3));
   HIP_TRY(hipMemsetAsync(p->u, 0, B * T * sizeof(float2), p->stream));  // u_seq0 = zeros (mppi.py:93)
   HIP_TRY(hipMemsetAsync(p->u_prev, 0, B * T * sizeof(float2), p->stream));
+  HIP_TRY(hipMemsetAsync(p->u_alt, 0, B * T * sizeof(float2), p->stream));
   HIP_TRY(hipMemsetAsync(p->costs, 0, N * sizeof(float), p->stream));
   {
     std::vector<double> initial_stats(2 * B);
@@ -1209,6 +1212,27 @@ extern "C" int mppi_planner_update_apply(mppi_planner* p, const double* packets,
   HIP_TRY(hipMemcpyAsync(p->packets, packets, sizeof(double) * (size_t)len * (size_t)count,
                          hipMemcpyHostToDevice, p->stream));
   TRY(launch_apply(p));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_update_apply_and_rollout(mppi_planner* p, const double* packets, int count,
+                                                     mppi_tdm* lin, mppi_tdm* ang) {
+  REQUIRE(p && packets, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
+  REQUIRE(count == p->cfg.world_size, MPPI_ERR_INVALID, "expected %d packets, got %d", p->cfg.world_size, count);
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  TRY(check_tdms(p, lin, ang));
+  TRY(ensure_packed(p, lin, ang));
+  const int len = p->B * packet_len(p->cfg.num_steps);
+  HIP_TRY(hipMemcpyAsync(p->packets, packets, sizeof(double) * (size_t)len * (size_t)count,
+                         hipMemcpyHostToDevice, p->stream));
+  DevParams d = make_dev_params(p, lin, ang);
+  // the rollout launch applies the update when it is one that can (launch_rollout settles it otherwise)
+  if (next_rollout_applies_updates(p)) p->apply_pending = true;
+  else TRY(launch_apply(p));
+  TRY(launch_rollout(p, d));
+  REQUIRE(!p->apply_pending, MPPI_ERR_STATE, "internal: the update was left unapplied");
   HIP_TRY(hipStreamSynchronize(p->stream));
   return MPPI_OK;
 }

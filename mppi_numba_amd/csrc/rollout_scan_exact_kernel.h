@@ -57,7 +57,7 @@ struct ScanExactLds {
   __host__ __device__ static constexpr size_t e2(int W) { return plane(W); }
   __host__ __device__ static constexpr size_t ccr(int W) { return plane(W); }
   __host__ __device__ static constexpr size_t p2(int W) { return (size_t)(W * 8 + 1) * R * 8; }
-  __host__ __device__ static constexpr size_t small(int W) { return (size_t)W * 8 * 16 + R * 64 + 64; }
+  __host__ __device__ static constexpr size_t small(int W) { return (size_t)W * 8 * (16 + 8) + R * 64 + 64 + 8 * (kMaxFoldedRanks + 2); }
   __host__ __device__ static constexpr size_t total(int W) { return e2(W) + ccr(W) + 2 * plane(W) + p2(W) + small(W); }
 };
 
@@ -81,7 +81,8 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
                                                              const uint32_t* __restrict__ cells,
                                                              const float2* __restrict__ noise, NoiseJob gen,
                                                              const float2* __restrict__ u, float* __restrict__ costs,
-                                                             float* __restrict__ w_rel, ScanPackets pk) {
+                                                             float* __restrict__ w_rel, ScanPackets pk,
+                                                             PendingApply pend) {
   extern __shared__ double2 scan_lds[];
   using L = ScanExactLds;
   constexpr int R = L::R, CHL = L::CHL, S = 64 / R;
@@ -131,6 +132,11 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   // Philox blocks a SIMD's worth at a time, and the walk of the first groups fits in between.
   int* done_a = reinterpret_cast<int*>(flags + 4);  // [16]
   int* done_b = done_a + 16;                        // [16]
+  // a sharded iteration's update applied here (update_kernels.h, PendingApply): the updated sequence
+  double* scale_sh = reinterpret_cast<double*>(small + (size_t)Tp * 16 + R * 64 + 64);  // [kMaxFoldedRanks + 2]
+  float2* u_sh = reinterpret_cast<float2*>(scale_sh + kMaxFoldedRanks + 2);              // [Tp]
+  const bool folded = pend.packets != nullptr;
+  if (folded && c == 0) pending_apply_prepare(pend, lane, scale_sh);
   if (c == 0 && lane < R) {
     evw[2 * lane] = 0u;
     evw[2 * lane + 1] = 0u;
@@ -148,11 +154,29 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
 
   // ---------------------------------------------------------------- A
   float2 ut[CHL];
+  if (folded) {  // (wave-uniform) the 8 controls of this wave's steps from the ranks' packets
+    if (lane < 8) {
+      const int t = 8 * c + lane;
+      const float2 v = t < T ? pending_apply_control(pend, scale_sh, uq, t) : make_float2(0.0f, 0.0f);
+      u_sh[t] = v;
+      if (tile == 0 && t < T) {
+        pend.u_out[t] = v;
+        pend.u_prev[t] = v;
+      }
+    }
+    if (tile == 0 && c == 0 && lane == 0) {
+      pend.stats[0] = scale_sh[kMaxFoldedRanks + 1];
+      pend.stats[1] = scale_sh[kMaxFoldedRanks];
+    }
 #pragma unroll
-  for (int j = 0; j < CHL; ++j) ut[j] = uq[min(t0 + j, T - 1)];
+    for (int j = 0; j < CHL; ++j) ut[j] = u_sh[t0 + j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < CHL; ++j) ut[j] = uq[min(t0 + j, T - 1)];
+  }
   const uint32_t ref = scan_lookup<POW2RES>(Q, cells16, Q.x0, Q.y0) & 0x3fffu;
   if (lane < 8) {  // the control ratios of this wave's 8 steps (float64 quotients: mppi.py:709)
-    const float2 ul = uq[min(8 * c + lane, T - 1)];
+    const float2 ul = folded ? u_sh[8 * c + lane] : uq[min(8 * c + lane, T - 1)];
     uos[8 * c + lane] = make_double2((double)ul.x / Q.s0sq, (double)ul.y / Q.s1sq);
   }
   float2 e[CHL];
@@ -475,7 +499,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
       }
       RolloutState st = {Q.x0, Q.y0, Q.th0, 0.0f, 1e9, false, false};
       for (int t = 0; t < T; ++t) {
-        map_step<MAP_DET, true, false, false>(Q, cells, nullptr, nullptr, uq[t], e2[t * R + (r ^ (t & (R - 1)))], st);
+        map_step<MAP_DET, true, false, false>(Q, cells, nullptr, nullptr, folded ? u_sh[t] : uq[t], e2[t * R + (r ^ (t & (R - 1)))], st);
         if (__all(st.done)) break;
       }
       cost = (float)((double)st.cost + (st.reached ? 0.0 : 1.0) * sqrt(st.d2) / Q.v_post_den);

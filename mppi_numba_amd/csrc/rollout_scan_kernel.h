@@ -69,8 +69,12 @@ struct ScanLds {
   __host__ __device__ static constexpr size_t rec(int W) { return (size_t)W * 64 * CHL * 8; }   // {sg, pen}[CHL] per (chunk, rollout)
   __host__ __device__ static constexpr size_t ccr(int W) { return (size_t)W * 64 * CHL * 4; }   // cc[CHL]
   __host__ __device__ static constexpr size_t e2(int W) { return (size_t)W * 8 * R * 8; }       // noise [Tp][R] float2
-  __host__ __device__ static constexpr size_t small() { return (size_t)R * (16 + 8 + 8 + 4) + 64; }
-  __host__ __device__ static constexpr size_t total(int W) { return rec(W) + ccr(W) + e2(W) + small(); }
+  // + (a sharded iteration's update applied in this launch: update_kernels.h, PendingApply) the ranks'
+  //   scales and the updated controls [Tp] float2
+  __host__ __device__ static constexpr size_t small(int W) {
+    return (size_t)R * (16 + 8 + 8 + 4) + 64 + 8 * (kMaxFoldedRanks + 2) + (size_t)W * 64;
+  }
+  __host__ __device__ static constexpr size_t total(int W) { return rec(W) + ccr(W) + e2(W) + small(W); }
   // the three float64 sums of phases A-C, [3][K][R], live where the records of phase D' go
   static_assert(3 * 8 <= CHL * 8, "sums alias the records");
 };
@@ -143,7 +147,8 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
                                                        const float2* __restrict__ noise, NoiseJob gen,
                                                        const float2* __restrict__ u, float* __restrict__ costs,
                                                        float* __restrict__ w_rel, ScanPackets pk,
-                                                       int n_rollout_blocks, NoiseJob next_noise) {
+                                                       int n_rollout_blocks, NoiseJob next_noise,
+                                                       PendingApply pend) {
   extern __shared__ double2 scan_lds[];
   if ((int)blockIdx.x >= n_rollout_blocks) {
     if (next_noise.out)
@@ -185,18 +190,44 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
   int* fz_count = reinterpret_cast<int*>(fz_pen + R);                  // [R]
   float* wsh = reinterpret_cast<float*>(fz_count + R);                 // [R] weights (phase F)
   uint32_t* flags = reinterpret_cast<uint32_t*>(wsh + R);              // [0] failed vote
+  double* scale_sh = reinterpret_cast<double*>(small + (size_t)R * 36 + 64);  // [kMaxFoldedRanks + 2]
+  float2* u_sh = reinterpret_cast<float2*>(scale_sh + kMaxFoldedRanks + 2);   // [Tp]
   if (c == 0 && lane < R) {
     evw[2 * lane] = 0u;
     evw[2 * lane + 1] = 0u;
     fz_count[lane] = 0;
     if (lane == 0) flags[0] = 0u;
   }
+  // a sharded iteration's update applied here (update_kernels.h, PendingApply)
+  const bool folded = pend.packets != nullptr;
+  if (folded) {
+    if (c == 0) pending_apply_prepare(pend, lane, scale_sh);
+    lds_barrier();
+  }
 
   // ---------------------------------------------------------------- A: noise, controls, heading increments
   // (requested before the Philox blocks: their first touch is a trip to memory)
   float2 ut[CHL];
+  if (folded) {  // (wave-uniform) the 8 controls of this wave's steps from the ranks' packets
+    if (lane < 8) {
+      const int t = 8 * c + lane;
+      const float2 v = t < T ? pending_apply_control(pend, scale_sh, uq, t) : make_float2(0.0f, 0.0f);
+      u_sh[t] = v;
+      if (tile == 0 && t < T) {
+        pend.u_out[t] = v;
+        pend.u_prev[t] = v;
+      }
+    }
+    if (tile == 0 && c == 0 && lane == 0) {
+      pend.stats[0] = scale_sh[kMaxFoldedRanks + 1];
+      pend.stats[1] = scale_sh[kMaxFoldedRanks];
+    }
 #pragma unroll
-  for (int j = 0; j < CHL; ++j) ut[j] = uq[min(t0 + j, T - 1)];
+    for (int j = 0; j < CHL; ++j) ut[j] = u_sh[t0 + j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < CHL; ++j) ut[j] = uq[min(t0 + j, T - 1)];
+  }
   // the assumption: every visited cell carries the traction bytes of the start cell
   const uint32_t ref = scan_lookup<POW2RES>(Q, cells16, Q.x0, Q.y0) & 0x3fffu;
   float2 e[CHL];
@@ -463,7 +494,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
       bool done = false, reached = false;
       for (int t = 0; t < T; ++t) {
         const uint32_t cl = scan_lookup<POW2RES>(Q, cells16, x, y);
-        const float2 en = e2[t * R + (r ^ (t & (R - 1)))], un = uq[t];
+        const float2 en = e2[t * R + (r ^ (t & (R - 1)))], un = folded ? u_sh[t] : uq[t];
         const float vv = __builtin_amdgcn_fmed3f(un.x + en.x, Q.v_lo, Q.v_hi);
         const float ww = __builtin_amdgcn_fmed3f(un.y + en.y, Q.w_lo, Q.w_hi);
         const float vtr = (float)fma(Q.lin_ratio, (double)(int)(cl & 127u), Q.lin_lo);

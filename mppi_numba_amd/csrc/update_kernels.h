@@ -28,15 +28,67 @@ __host__ __device__ inline int packet_len(int n_steps) { return 2 + 2 * n_steps;
 // u_prev_d to u_cur_d before the update, mppi.py:362)
 // u_mirror: the same sequence in host-mapped pinned memory (posted PCIe writes), so that solve()
 // only has to wait for the stream instead of queueing a device-to-host copy behind it
+__device__ __forceinline__ float2 updated_control(float2 ut, double nx, double ny, double den, float v_lo,
+                                                  float v_hi, float w_lo, float w_hi) {
+  ut.x = clip_f32(ut.x + (float)(nx / den), v_lo, v_hi);
+  ut.y = clip_f32(ut.y + (float)(ny / den), w_lo, w_hi);
+  return ut;
+}
+
 __device__ __forceinline__ void apply_update(float2* u, float2* u_prev, float2* u_mirror, int t, double nx,
                                              double ny, double den, float v_lo, float v_hi, float w_lo,
                                              float w_hi) {
-  float2 ut = u[t];
-  ut.x = clip_f32(ut.x + (float)(nx / den), v_lo, v_hi);
-  ut.y = clip_f32(ut.y + (float)(ny / den), w_lo, w_hi);
+  const float2 ut = updated_control(u[t], nx, ny, den, v_lo, v_hi, w_lo, w_hi);
   u[t] = ut;
   u_prev[t] = ut;
   if (u_mirror) u_mirror[t] = ut;
+}
+
+// ---- the update of a sharded iteration, applied by its CONSUMER ---------------------------------
+// With the control samples sharded over G GPUs an iteration ends with every rank holding the G
+// packets {beta_g, den_g, num_g[t]} (one all-gather).  Turning them into u is k_apply below: one
+// tiny dependent launch, ~2-4 us on a 20 us iteration.  The time-parallel rollout kernels
+// (rollout_scan*.h) take the packets instead and form u[t] themselves -- every wave the 8 steps it
+// owns, with k_apply's expressions in k_apply's order (same bits on every rank); the first tile's
+// workgroup also stores the sequence, into the OTHER control buffer (the rest of the grid is still
+// reading the old one).  packets == nullptr: nothing pending, u is read as it is.
+constexpr int kMaxFoldedRanks = 16;
+struct PendingApply {
+  const double* packets;  // [world][stride] as all-gathered; nullptr: none
+  float2* u_out;          // the other control buffer
+  float2* u_prev;
+  double* stats;          // {beta, den} of the update
+  int world, stride;      // stride: doubles per rank (= packet_len(T) for the single-problem handle)
+  float lambda, v_lo, v_hi, w_lo, w_hi;
+};
+
+// wave 0 of a workgroup, before the workgroup's first barrier: the scale of every rank's packet and
+// the common denominator (k_apply's lines) -> scale_sh[0 .. world), scale_sh[kMaxFoldedRanks] = den
+__device__ __forceinline__ void pending_apply_prepare(const PendingApply& A, int lane, double* scale_sh) {
+  const double mine = A.packets[(size_t)min(lane, A.world - 1) * A.stride];
+  double beta = A.packets[0];
+  for (int g = 1; g < A.world; ++g) beta = fmin(beta, A.packets[(size_t)g * A.stride]);
+  const double neg_inv_lambda = -1.0 / (double)A.lambda;
+  if (lane < A.world) scale_sh[lane] = exp(neg_inv_lambda * (mine - beta));
+  if (lane == 0) {  // (the wave's own LDS writes are visible to it in order)
+    double den = 0.0;
+    for (int g = 0; g < A.world; ++g) den += scale_sh[g] * A.packets[(size_t)g * A.stride + 1];  // (as k_apply: product, then sum)
+    scale_sh[kMaxFoldedRanks] = den;
+    scale_sh[kMaxFoldedRanks + 1] = beta;
+  }
+}
+
+// one control of the updated sequence (any lane, after the barrier that follows pending_apply_prepare)
+__device__ __forceinline__ float2 pending_apply_control(const PendingApply& A, const double* scale_sh,
+                                                        const float2* __restrict__ u_old, int t) {
+  double nx = 0.0, ny = 0.0;
+  for (int g = 0; g < A.world; ++g) {
+    const double sg = scale_sh[g];
+    const double2 num = *reinterpret_cast<const double2*>(A.packets + (size_t)g * A.stride + 2 + 2 * t);
+    nx = fma(sg, num.x, nx);
+    ny = fma(sg, num.y, ny);
+  }
+  return updated_control(u_old[t], nx, ny, scale_sh[kMaxFoldedRanks], A.v_lo, A.v_hi, A.w_lo, A.w_hi);
 }
 
 // ---- stage 1: weights relative to the minimum of each tile of 64 rollouts ----------
@@ -333,15 +385,18 @@ __global__ __launch_bounds__(64) void k_combine_tiles(const float* __restrict__ 
 
 // combine the packets of all ranks (identical on every GPU, fixed g order).
 // Batched handle: blockIdx.x = problem b; rank g's packet for it is packets[(g*B + b)*len].
+// u_in / u: the sequence before and after (the same buffer, or the handle's two control buffers: a
+// sharded handle alternates them so that a rollout launch can apply the update itself, PendingApply)
 __global__ __launch_bounds__(kUpdateThreads) void k_apply(const double* __restrict__ packets, int world,
                                                           int rank, int n_steps, float lambda,
-                                                          float2* __restrict__ u, float2* __restrict__ u_prev,
+                                                          const float2* u_in, float2* u, float2* __restrict__ u_prev,
                                                           float2* __restrict__ u_mirror, float v_lo, float v_hi,
                                                           float w_lo, float w_hi, double* __restrict__ stats) {
   const int len = packet_len(n_steps);
   const size_t stride = (size_t)gridDim.x * len;  // doubles per rank
   packets += (size_t)blockIdx.x * len;
   u += (size_t)blockIdx.x * n_steps;
+  u_in += (size_t)blockIdx.x * n_steps;
   u_prev += (size_t)blockIdx.x * n_steps;
   if (u_mirror) u_mirror += (size_t)blockIdx.x * n_steps;
   stats += 2 * blockIdx.x;
@@ -361,7 +416,10 @@ __global__ __launch_bounds__(kUpdateThreads) void k_apply(const double* __restri
       nx = fma(sg, packets[g * stride + 2 + 2 * t], nx);
       ny = fma(sg, packets[g * stride + 3 + 2 * t], ny);
     }
-    apply_update(u, u_prev, u_mirror, t, nx, ny, den, v_lo, v_hi, w_lo, w_hi);
+    const float2 ut = updated_control(u_in[t], nx, ny, den, v_lo, v_hi, w_lo, w_hi);
+    u[t] = ut;
+    u_prev[t] = ut;
+    if (u_mirror) u_mirror[t] = ut;
   }
 }
 

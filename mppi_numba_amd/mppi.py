@@ -507,6 +507,15 @@ class MPPI_Numba(object):
                   int(packets.shape[0]))
         self.u_prev_d = self._u_prev_view
 
+    def update_apply_and_rollout(self, packets):
+        """update_apply(packets) and the next iteration's rollout() in one call (sample_noise() first):
+        a time-parallel rollout launch applies the update itself, no k_apply launch in between."""
+        packets = np.ascontiguousarray(packets, dtype=np.float64)
+        self.move_mppi_task_vars_to_device()
+        _lib.call("mppi_planner_update_apply_and_rollout", self._handle, _lib.ptr(packets, C.c_double),
+                  int(packets.shape[0]), self.lin_tdm._handle, self.ang_tdm._handle)
+        self.u_prev_d = self._u_prev_view
+
 
 def comm_unique_id():
     """128-byte RCCL id: create on rank 0, broadcast to the other ranks by any

@@ -222,3 +222,124 @@ def test_sample_shards_need_the_counter_based_generator_and_even_offsets():
         _lib.call("mppi_tdm_set_sample_shard", tdm._handle, 3)
     with pytest.raises(AssertionError):
         TDM_Numba(cfg, sample_shard=(0, 3))  # 8 samples do not split into 3 shards of whole pairs
+
+
+# ---- the update of a sharded iteration applied by the NEXT rollout launch (update_kernels.h, PendingApply) ----
+
+@pytest.mark.parametrize("math", ["exact", "fast"])
+@pytest.mark.parametrize("world", [2, 8])
+def test_rollout_launch_applies_the_gathered_update_same_bits(world, math):
+    """Control samples over 2 / 8 ranks on the one GPU, packets gathered by hand.  One set of shards
+    runs rollout -> rank packet -> k_apply; the other hands the gathered packets to its next rollout
+    launch (update_apply_and_rollout): every wave forms the 8 controls it owns with k_apply's
+    expressions.  Same costs every iteration, same u on every rank, bit for bit."""
+    import bench
+
+    def shards():
+        out = [bench.build_planner("c2", 8192 // world, rank=r, world=world, math=math)[4] for r in range(world)]
+        for s in out:
+            s.lin_tdm.sample_grids()  # (solve() does this; the stage-level calls do not)
+            s.ang_tdm.sample_grids()
+        return out
+
+    classic, folded = shards(), shards()
+    packets_folded = None
+    for it in range(4):
+        packets = []
+        for s in classic:
+            s.sample_noise()
+            s.rollout()
+            packets.append(s.update_local())
+        for s in classic:
+            s.update_apply(np.stack(packets))
+        gathered = []
+        for s in folded:
+            s.sample_noise()
+            if packets_folded is None:
+                s.rollout()
+            else:
+                s.update_apply_and_rollout(packets_folded)
+                assert "applies_update=1" in s.last_rollout_kernel(), s.last_rollout_kernel()
+            gathered.append(s.update_local())
+        packets_folded = np.stack(gathered)
+        assert np.array_equal(packets_folded, np.stack(packets)), "iteration %d: rank packets differ" % it
+        for a, b in zip(classic, folded):
+            assert np.array_equal(a.costs_d.copy_to_host(), b.costs_d.copy_to_host())
+    for s in folded:
+        s.update_apply(packets_folded)
+    for a, b in zip(classic, folded):
+        assert np.array_equal(a.u_cur_d.copy_to_host(), b.u_cur_d.copy_to_host())
+        assert np.array_equal(a.u_prev_d.copy_to_host(), b.u_cur_d.copy_to_host())
+    assert np.array_equal(folded[0].u_cur_d.copy_to_host(), folded[-1].u_cur_d.copy_to_host())
+    w_a, w_b = classic[0].weights_d.copy_to_host(), folded[0].weights_d.copy_to_host()
+    assert np.array_equal(w_a, w_b)
+
+
+def test_a_rollout_that_cannot_apply_the_update_gets_it_applied_first():
+    """update_apply_and_rollout on a map the time-parallel kernels do not take (traction changes from
+    cell to cell, many tiles per CU): plain k_apply, then the rollout."""
+    import bench
+    world = 2
+    a = [bench.build_planner("c4", 32768, rank=r, world=world)[4] for r in range(world)]
+    b = [bench.build_planner("c4", 32768, rank=r, world=world)[4] for r in range(world)]
+    for s in a + b:
+        s.lin_tdm.sample_grids()
+        s.ang_tdm.sample_grids()
+        s.sample_noise()
+        s.rollout()
+    pa, pb = np.stack([s.update_local() for s in a]), np.stack([s.update_local() for s in b])
+    assert np.array_equal(pa, pb)
+    for s in a:
+        s.update_apply(pa)
+        s.sample_noise()
+        s.rollout()
+    for s in b:
+        s.sample_noise()
+        s.update_apply_and_rollout(pb)
+        assert "applies_update" not in s.last_rollout_kernel()
+    for x, y in zip(a, b):
+        assert np.array_equal(x.u_cur_d.copy_to_host(), y.u_cur_d.copy_to_host())
+        assert np.array_equal(x.costs_d.copy_to_host(), y.costs_d.copy_to_host())
+
+
+@pytest.mark.parametrize("math", ["exact", "fast"])
+def test_loop_with_a_communicator_leaves_the_update_to_the_next_rollout(math):
+    """iterate_async() of a handle with a communicator (one rank is all this box can give RCCL): between
+    iterations no k_apply is launched -- rollout, rank packet, all-gather -- and u has the bits of the
+    loop that launches k_apply every iteration, ordinary and graph-replayed."""
+    import time
+    from mppi_numba_amd import _lib
+    from mppi_numba_amd.mppi import comm_unique_id
+    handles = {}
+    for name, flags, graph in [("local", 0, False), ("folded", 0, False), ("k_apply", _lib.DEBUG_NO_FOLDED_APPLY, False),
+                               ("folded graph", 0, True)]:
+        _, _, _, _, pl, _ = build("c2", None, math=math)
+        if name != "local":
+            pl.comm_init(comm_unique_id())
+        pl.set_debug_flags(flags)
+        if graph:
+            pl.set_graph_replay(True, 4)
+        pl.solve()
+        pl.iterate_async(13)
+        pl.synchronize()
+        handles[name] = pl
+    assert "applies_update=1" in handles["folded"].last_rollout_kernel(), handles["folded"].last_rollout_kernel()
+    assert "applies_update" not in handles["k_apply"].last_rollout_kernel()
+    assert handles["folded graph"].graph_stats()["replays"] >= 2
+    u = {k: v.u_cur_d.copy_to_host() for k, v in handles.items()}
+    for k in ("folded", "k_apply", "folded graph"):
+        assert np.array_equal(u[k], u["local"]), k
+        assert np.array_equal(handles[k].costs_d.copy_to_host(), handles["local"].costs_d.copy_to_host()), k
+    # and what it buys: microseconds per iteration of the three loops
+    times = {}
+    for k in ("local", "folded", "k_apply"):
+        pl = handles[k]
+        pl.iterate_async(50)
+        pl.synchronize()
+        t0 = time.perf_counter()
+        pl.iterate_async(400)
+        pl.synchronize()
+        times[k] = (time.perf_counter() - t0) / 400 * 1e6
+    print("\n%s: us per iteration -- unsharded %.2f, 1-rank communicator with the update left to the rollout %.2f, "
+          "with k_apply %.2f" % (math, times["local"], times["folded"], times["k_apply"]))
+    assert times["folded"] <= times["k_apply"] + 0.5
