@@ -346,7 +346,8 @@ static int upload_instances(mppi_planner* p) {
 // Eligible: deterministic-dynamics mode, 16-bit cells (the reference's own maps always are), a horizon
 // of at most 16 waves of 8 steps, LDS for the per-step records, and a map the speculation pays on.
 struct ScanPlan {
-  int waves = 0;       // 8 steps each = waves per workgroup
+  int waves = 0;       // waves per workgroup: one per 8 steps (+ the three walkers of the exact kernel)
+  int chunk_waves = 0; // ... of which work on 8 steps each
   int tile = 32;       // rollouts per workgroup: 32 (two lanes per rollout) or 64
   size_t lds = 0;
   bool pow2res = false;
@@ -362,14 +363,16 @@ static bool scan_plan(const mppi_planner* p, ScanPlan* out) {
   const int T = p->cfg.num_steps;
   ScanPlan plan;
   plan.exact = p->cfg.math == MPPI_MATH_EXACT;
-  plan.waves = ceil_div(T, 8);
+  plan.chunk_waves = ceil_div(T, 8);
+  if (plan.exact && plan.chunk_waves > ScanExactLds::kMaxChunkWaves) return false;  // (T <= 104; beyond, k_rollout_deep)
+  plan.waves = plan.exact ? ScanExactLds::waves(plan.chunk_waves) : plan.chunk_waves;
   if (plan.waves > 16) return false;
   plan.tile = (!plan.exact && (p->debug_flags & MPPI_DEBUG_SCAN_FULL_TILES)) ? 64 : 32;
   // one round of workgroups over the CUs: beyond that the kernels with one wave per tile win (a
   // 32-rollout workgroup lasts ~10 us whatever N is: N = 16384 would be two rounds against 18 us
   // of k_rollout_deep, N = 65536 eight against 78 us of k_rollout_fused)
   if (ceil_div(p->n_local, plan.tile) > p->num_cus) return false;
-  plan.lds = plan.exact ? ScanExactLds::total(plan.waves)
+  plan.lds = plan.exact ? ScanExactLds::total(plan.chunk_waves)
                         : (plan.tile == 64 ? ScanLds<64>::total(plan.waves) : ScanLds<32>::total(plan.waves));
   // (the accumulating wave reads up to two groups of records past the last one: keep that inside the allocation)
   plan.lds = std::max(plan.lds, (size_t)40 * 1024);

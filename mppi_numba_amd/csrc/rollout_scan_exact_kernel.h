@@ -17,48 +17,70 @@
 // Everything else -- the Philox blocks, clipping, the products dt*v, dt*w, sin / cos of every
 // (rounded) heading, the cell lookups, distances, square roots, stage costs, the vote, goal and
 // freeze events -- depends only on those sums' VALUES and is computed for all steps side by side:
-// lane = (rollout, 4 consecutive steps), 13 waves per tile of 32 rollouts at T = 100.  The three
-// sums are WALKED, one after the other, by one wave each (x and y by two waves at once): three
-// dependent instructions per step (v_fma_f64, v_cvt_f32_f64, v_cvt_f64_f32) instead of the ~53 of
-// the pipelined kernels' state wave.  Same operations on the same operands in the same order as the
-// oracle: the same bits, by construction.
+// lane = (rollout, 4 consecutive steps), one CHUNK WAVE per 8 steps of a tile of 32 rollouts.  The
+// three sums are WALKED by one wave each (x and y in the two halves of one wave): three dependent
+// instructions per step (v_fma_f64 / v_add_f64, v_cvt_f32_f64, v_cvt_f64_f32) instead of the ~53
+// of the pipelined kernels' state wave.  Same operations on the same operands in the same order as
+// the oracle: the same bits, by construction.
 //
-// Phases (workgroup barriers between them):
-//   A   noise (GEN: Philox blocks; else read) -> LDS; clipped controls; dt*w -> LDS; the float64
-//       control ratios u/std^2 of the wave's 8 steps -> LDS
-//   W1  wave 0 walks theta over the horizon -> LDS (float32 heading BEFORE every step);
-//       the other waves meanwhile: control-cost terms (float64, mppi.py:1007-1009) -> LDS
-//   B   sin / cos of every heading (sincos_f64, as the other exact kernels), (dt*v)*cos, (dt*v)*sin -> LDS
-//   W2  wave 0 walks x, wave 1 walks y -> LDS (float32 positions, T + 1 of them)
-//   C   lookups (exact floor division), squared goal distances, square roots, stage costs (float64);
-//       per lane the first freeze / goal hit among its steps, the vote; events -> LDS word (ds_or)
-//   D'  first event wins; per-step addends -> LDS; frozen addend, terminal cost
-//   E   wave 0 walks the cost: stage, obstacle, unknown per step (mppi.py:994-998), the frozen
-//       steps, the terminal cost, the T control-cost terms (mppi.py:1005-1009); cost, tile weights
-//   F   per-tile update sums, lane = step (as k_rollout_scan)
-// A failed vote: the tile is rolled out sequentially by one wave with the arithmetic of
-// k_rollout_map<DET, exact> (unicycle_step / add_stage_cost) -- the same bits again, slowly; the
-// host stops launching this kernel on a map where most tiles fail (review_speculation).
+// The walks follow each other down the horizon, one group of 8 steps apart, and the chunk waves work
+// between them -- no workgroup barrier between entry and the update sums, only flags in LDS
+// (release store by the producer, acquire poll by the consumer):
+//
+//   chunk wave g                      walker
+//   A  noise (GEN: Philox; else read), clipped controls, dt*w          -> a_done[g]
+//                                     theta walk over group g          -> th_done[g]
+//      (meanwhile: the control-cost products, mppi.py:1007-1009)
+//   B  sin / cos of the 8 headings, (dt*v)*cos, (dt*v)*sin             -> b_done[g]
+//                                     x | y walk over group g          -> xy_done[g]
+//   C  lookups, goal distances, sqrt, stage costs; freeze / goal events, the vote
+//      (after ev_done[g-1]: all earlier events are known)              -> ev_done[g]
+//   D' first event wins, per-step addends                              -> c_done[g]
+//                                     cost walk over group g (stage, obstacle, unknown per step)
+//   ... then, by the cost wave: frozen steps, terminal cost, the T control-cost terms
+//   (mppi.py:1005-1009), cost, tile weights; barrier; F: per-tile update sums, lane = step.
+//
+// Workgroup = 3 walkers + ceil(T / 8) chunk waves: T <= 104.  Waves go to the four SIMDs of a CU
+// round robin (wave & 3).  A walk keeps a SIMD's float64 pipe busy for about half of its ~55 cycles
+// per step: the theta and the x | y walks share SIMD 0 (waves 0, 4; all three on one SIMD were
+// measured at 87 cycles per step, throughput-bound), the cost walk, which runs last, is wave 1.  The
+// chunk waves fill the remaining slots -- 2, 3, 4, 4 per SIMD -- and carry falling priorities in the
+// order their groups are needed, so that on every SIMD the Philox blocks of the early groups finish
+// first (kGroupOfWave); the two on SIMD 0 own the last groups.
+// A failed vote: the tile is rolled out sequentially by the cost wave with the arithmetic of
+// k_rollout_map<DET, exact> (map_step) -- the same bits again, slowly; the host stops launching this
+// kernel on a map where most tiles fail (review_speculation).
 #pragma once
 #include "rollout_scan_kernel.h"
 
 namespace mppi {
 
-// LDS of one workgroup of W waves over R = 32 rollouts, Tp = 8 W steps, per (step, rollout):
-//   e2   float2        noise (swizzled columns: phase F reads it lane = step)
-//   ccr  double        control-cost term
-//   p0   double        dt*w (A -> W1), then (dt*v)*cos (B -> W2);      later the records' first half
-//   p1   double        (dt*v)*sin (B -> W2);                           later the records' second half
-//   p2   float / float2  heading before the step (W1 -> B), then position (W2 -> C), Tp + 1 rows
-// records (D' -> E), 16 bytes per step over p0 | p1: {double stage addend, float obstacle, float unknown}
+// LDS of one workgroup with W chunk waves over R = 32 rollouts, Tp = 8 W steps:
+//   e2   [Tp][R] float2   noise (swizzled columns: phase F reads it lane = step)
+//   ccr  [2W][R][4] double control-cost terms
+//   grp  [W] x 4 KiB      per group of 8 steps: [8][R] double dt*w, overwritten by (dt*v)*cos once the
+//                         theta walk has passed | [8][R] double (dt*v)*sin; both overwritten, once the
+//                         position walk has passed, by the group's two records
+//                         [R] {double stage[4]; float obstacle[4]; float unknown[4]}
+//   p2   [Tp + 1][R] float2 positions (row t = before step t); the float32 headings [Tp + 1][R]
+//                         live in its upper half until the positions overwrite them (see th_sh)
+//   small: control ratios, frozen / terminal data, event words, weights, flags
 struct ScanExactLds {
-  static constexpr int R = 32, CHL = 4;
+  static constexpr int R = 32, CHL = 4, kMaxChunkWaves = 13;
+  // the waves a workgroup needs for W groups (walkers: waves 0, 4, 1; chunk waves: kWaveOfGroup below)
+  __host__ __device__ static constexpr int waves(int W) {
+    constexpr int need[kMaxChunkWaves] = {6, 6, 6, 10, 10, 10, 14, 14, 14, 15, 16, 16, 16};  // 1 + the highest wave among groups 0 .. W-1 and the walkers
+    return need[W - 1];
+  }
   __host__ __device__ static constexpr size_t plane(int W) { return (size_t)W * 8 * R * 8; }
   __host__ __device__ static constexpr size_t e2(int W) { return plane(W); }
   __host__ __device__ static constexpr size_t ccr(int W) { return plane(W); }
+  __host__ __device__ static constexpr size_t grp(int W) { return 2 * plane(W); }
   __host__ __device__ static constexpr size_t p2(int W) { return (size_t)(W * 8 + 1) * R * 8; }
-  __host__ __device__ static constexpr size_t small(int W) { return (size_t)W * 8 * (16 + 8) + R * 64 + 64 + 8 * (kMaxFoldedRanks + 2); }
-  __host__ __device__ static constexpr size_t total(int W) { return e2(W) + ccr(W) + 2 * plane(W) + p2(W) + small(W); }
+  __host__ __device__ static constexpr size_t small(int W) {
+    return (size_t)W * 8 * (16 + 8) + R * 64 + 64 + 8 * (kMaxFoldedRanks + 2) + 6 * 16 * 4;
+  }
+  __host__ __device__ static constexpr size_t total(int W) { return e2(W) + ccr(W) + grp(W) + p2(W) + small(W); }
 };
 
 // the frozen steps of an exact walk: the closed form of frozen_block when there is no penalty
@@ -76,6 +98,7 @@ __device__ __forceinline__ float frozen_block_exact(float acc, double k, float p
   return frozen_block(acc, k, 0.0f, count);
 }
 
+
 template <bool POW2RES, bool GEN>
 __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const uint16_t* __restrict__ cells16,
                                                              const uint32_t* __restrict__ cells,
@@ -85,13 +108,28 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
                                                              PendingApply pend) {
   extern __shared__ double2 scan_lds[];
   using L = ScanExactLds;
-  constexpr int R = L::R, CHL = L::CHL, S = 64 / R;
-  const int c = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave = 8 steps
+  constexpr int R = L::R, CHL = L::CHL;
+  const int c = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int r = lane & (R - 1), h = lane / R;
-  const int W = (int)(blockDim.x >> 6);
-  const int K = W * S;
-  const int k = c * S + h;
+  const int W = (P.n_steps + 7) >> 3;  // groups of 8 steps = chunk waves
+  // role of this wave: walker 0 (theta), 1 (x | y), 2 (cost); or the chunk wave of group g; or none.
+  // groups in the order their increments are needed x the order in which a SIMD's chunk waves finish
+  // their Philox blocks: on SIMDs 1..3 first finishers waves 5, 2, 3; second 9, 6, 7; third 13, 10, 11;
+  // fourth 14, 15.  The two chunk waves on SIMD 0 (8, 12) take the LAST groups: their Philox blocks run
+  // while the walks still wait for input, their lookups when the theta walk is through.
+  //                                   wave:   0   1  2  3   4  5  6  7   8  9 10 11  12 13 14  15
+  constexpr int kGroupOfWave[16] =          {-1, -1, 1, 2, -1, 0, 4, 5, 11, 3, 7, 8, 12, 6, 9, 10};
+  constexpr int kPrioOfWave[16] =           { 3,  3, 3, 3,  3, 3, 2, 2,  3, 2, 1, 1,  3, 1, 0,  0};
+  const int walker = c == 0 ? 0 : (c == 4 ? 1 : (c == 1 ? 2 : -1));
+  int g = -1, prio = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    g = c == i ? kGroupOfWave[i] : g;
+    prio = c == i ? kPrioOfWave[i] : prio;
+  }
+  g = g < W ? g : -1;
+  const int k = 2 * g + h;  // this lane's chunk of 4 steps
   [[maybe_unused]] const bool stamp_wg = blockIdx.x == 5;
   [[maybe_unused]] const int stamp_base = 64 + 16 * c;
   MPPI_STAMP(stamp_wg && c < 16, stamp_base + 0);
@@ -107,15 +145,14 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
 
   char* base = reinterpret_cast<char*>(scan_lds);
   float2* e2 = reinterpret_cast<float2*>(base);                                  // [Tp][R] (swizzled)
-  double* ccr = reinterpret_cast<double*>(base + L::e2(W));                      // [K][R][CHL]
-  double* p0 = reinterpret_cast<double*>(base + L::e2(W) + L::ccr(W));           // [Tp][R]
-  double* p1 = p0 + (size_t)Tp * R;                                              // [Tp][R]
-  char* rec = reinterpret_cast<char*>(p0);                                       // [K][R] {double sg[CHL], float po[CHL], float pu[CHL]}
-  float2* pos = reinterpret_cast<float2*>(p1 + (size_t)Tp * R);                  // [Tp + 1][R]
-  // the headings live in the UPPER half of the position rows: the position walk, which starts while
-  // other waves still read headings, overwrites heading t' = 2t - Tp <= t when it stores position t,
-  // and it gets to step t only after every wave up to step t's has finished with its headings
-  float* th_sh = reinterpret_cast<float*>(pos) + (size_t)Tp * R;                 // [Tp][R]
+  double* ccr = reinterpret_cast<double*>(base + L::e2(W));                      // [2W][R][CHL]
+  char* grp = base + L::e2(W) + L::ccr(W);                                       // [W] x 4 KiB
+  float2* pos = reinterpret_cast<float2*>(grp + L::grp(W));                      // [Tp + 1][R]
+  // The headings live in the UPPER half of the position rows.  Position row p covers heading rows
+  // 2p - Tp and 2p - Tp + 1: when the position walk stores row t + 1 (step t) it overwrites headings
+  // of steps <= t, which the chunk waves up to step t's have consumed (b_done); and a heading row is
+  // written (the theta walk runs ahead) into a position row of a LATER step, not yet written.
+  float* th_sh = reinterpret_cast<float*>(pos) + (size_t)Tp * R;                 // [Tp + 1][R]
   char* small = reinterpret_cast<char*>(pos) + L::p2(W);
   double2* uos = reinterpret_cast<double2*>(small);                              // [Tp] u / std^2
   double* fz_k = reinterpret_cast<double*>(uos + Tp);                            // [R]
@@ -125,371 +162,178 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   float* fz_pu = fz_po + R;                                                      // [R]
   int* fz_count = reinterpret_cast<int*>(fz_pu + R);                             // [R]
   float* wsh = reinterpret_cast<float*>(fz_count + R);                           // [R]
-  uint32_t* flags = reinterpret_cast<uint32_t*>(wsh + R);
-  // The walks start before the stage that feeds them has ended everywhere: wave g raises done_a[g]
-  // when the increments of ITS 8 steps are in LDS (done_b[g]: its position increments), and the
-  // walking wave waits for the flag of the group it is about to read -- the waves finish their
-  // Philox blocks a SIMD's worth at a time, and the walk of the first groups fits in between.
-  int* done_a = reinterpret_cast<int*>(flags + 4);  // [16]
-  int* done_b = done_a + 16;                        // [16]
+  uint32_t* flags = reinterpret_cast<uint32_t*>(wsh + R);                        // [0] a failed vote
   // a sharded iteration's update applied here (update_kernels.h, PendingApply): the updated sequence
   double* scale_sh = reinterpret_cast<double*>(small + (size_t)Tp * 16 + R * 64 + 64);  // [kMaxFoldedRanks + 2]
   float2* u_sh = reinterpret_cast<float2*>(scale_sh + kMaxFoldedRanks + 2);              // [Tp]
+  // hand-over flags, one per group of 8 steps: raised by the wave that has stored the group's data
+  int* a_done = reinterpret_cast<int*>(u_sh + Tp);  // [16] heading increments (chunk wave)
+  int* th_done = a_done + 16;                       // [16] headings (theta walk)
+  int* b_done = th_done + 16;                       // [16] position increments (chunk wave)
+  int* xy_done = b_done + 16;                       // [16] positions (position walk)
+  int* ev_done = xy_done + 16;                      // [16] freeze / goal events of the group and of all before it (chunk wave)
+  int* c_done = ev_done + 16;                       // [16] records (chunk wave): 1, or 3 = a penalty in the group
   const bool folded = pend.packets != nullptr;
   if (folded && c == 0) pending_apply_prepare(pend, lane, scale_sh);
-  if (c == 0 && lane < R) {
-    evw[2 * lane] = 0u;
-    evw[2 * lane + 1] = 0u;
-    fz_count[lane] = 0;
-    if (lane < 2) flags[lane] = 0u;  // [0] a failed vote, [1] a penalty somewhere in the tile
-    done_a[lane] = 0;  // (R = 32 >= the two arrays of 16)
+  if (c == 4) {
+    if (lane < R) {
+      evw[2 * lane] = 0u;
+      evw[2 * lane + 1] = 0u;
+      fz_count[lane] = 0;
+      if (lane == 0) flags[0] = 0u;
+    }
+    for (int i = lane; i < 6 * 16; i += 64) a_done[i] = 0;
   }
   lds_barrier();  // (every wave has only just started)
-  auto raise = [&](int* flag) {
-    if (lane == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // Everything a flag guards is in LDS, and the LDS executes one wave's instructions in the order they
+  // were issued: a flag written after the data IS after the data for every other wave.  No s_waitcnt
+  // before the flag store (a release would drain the wave's outstanding LDS stores first: ~100 cycles
+  // between two groups of a walk); the compiler just must not move it.
+  auto raise = [&](int* flag, int value) {
+    pin_memory_order();
+    if (lane == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    pin_memory_order();
+  };
+  auto peek = [&](const int* flag) {  // wave-uniform
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
   };
   auto wait_for = [&](const int* flag) {
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+    int v;
+    while ((v = peek(flag)) == 0) __builtin_amdgcn_s_sleep(2);
+    return v;
   };
-
-  // ---------------------------------------------------------------- A
-  float2 ut[CHL];
-  if (folded) {  // (wave-uniform) the 8 controls of this wave's steps from the ranks' packets
-    if (lane < 8) {
-      const int t = 8 * c + lane;
-      const float2 v = t < T ? pending_apply_control(pend, scale_sh, uq, t) : make_float2(0.0f, 0.0f);
-      u_sh[t] = v;
-      if (tile == 0 && t < T) {
-        pend.u_out[t] = v;
-        pend.u_prev[t] = v;
-      }
-    }
-    if (tile == 0 && c == 0 && lane == 0) {
-      pend.stats[0] = scale_sh[kMaxFoldedRanks + 1];
-      pend.stats[1] = scale_sh[kMaxFoldedRanks];
-    }
-#pragma unroll
-    for (int j = 0; j < CHL; ++j) ut[j] = u_sh[t0 + j];
-  } else {
-#pragma unroll
-    for (int j = 0; j < CHL; ++j) ut[j] = uq[min(t0 + j, T - 1)];
-  }
-  const uint32_t ref = scan_lookup<POW2RES>(Q, cells16, Q.x0, Q.y0) & 0x3fffu;
-  if (lane < 8) {  // the control ratios of this wave's 8 steps (float64 quotients: mppi.py:709)
-    const float2 ul = folded ? u_sh[8 * c + lane] : uq[min(8 * c + lane, T - 1)];
-    uos[8 * c + lane] = make_double2((double)ul.x / Q.s0sq, (double)ul.y / Q.s1sq);
-  }
-  float2 e[CHL];
-  if constexpr (GEN) {
-    const uint64_t epoch = gen.epoch + (gen.gen_counter ? *gen.gen_counter : 0ull);
-    const unsigned int pairs = (unsigned int)(T + 1) / 2u;
-    const unsigned int n_global = (unsigned int)(gen.n_offset + min(n, N - 1));
-#pragma unroll
-    for (int jp = 0; jp < CHL / 2; ++jp) {
-      const unsigned int tp = (unsigned int)(t0 / 2 + jp);
-      scan_noise_pair(gen, epoch, n_global, pairs, min(tp, pairs - 1u), e[2 * jp], e[2 * jp + 1]);
-    }
-  } else {
-    const float2* col = noise + (size_t)(n >> 6) * T * 64 + (n & 63);
-#pragma unroll
-    for (int j = 0; j < CHL; ++j) e[j] = col[(size_t)min(t0 + j, T - 1) * 64];
-  }
   const double dt64 = (double)Q.dt;
-  double qx[CHL];  // dt * clipped speed: exact products of float32 factors
-#pragma unroll
-  for (int j = 0; j < CHL; ++j) {
-    const bool valid = j < nvalid;
-    ut[j] = valid ? ut[j] : make_float2(0.0f, 0.0f);
-    e[j] = valid ? e[j] : make_float2(0.0f, 0.0f);
-    const int t = t0 + j;
-    e2[t * R + (r ^ (t & (R - 1)))] = e[j];
-    const float v = clip_f32(ut[j].x + e[j].x, Q.v_lo, Q.v_hi);
-    const float w = clip_f32(ut[j].y + e[j].y, Q.w_lo, Q.w_hi);
-    qx[j] = dt64 * (double)v;
-    p0[(size_t)t * R + r] = dt64 * (double)w;
-  }
-  const double vtr0 = fma(Q.lin_ratio, (double)(int)(ref & 127u), Q.lin_lo);
-  const double wtr0 = fma(Q.ang_ratio, (double)(int)((ref >> 7) & 127u), Q.ang_lo);
-  raise(&done_a[c]);
-  MPPI_STAMP(stamp_wg && c < 16, stamp_base + 1);
 
-  // ---------------------------------------------------------------- W1: the heading walk
-  // one running sum rounded to float32 after every fma (a lone wave issues an instruction per ~5
-  // cycles: what counts is the instruction count -- one pointer bump and a group of reads per 8 steps)
-  // OUT: float rows of `out_stride` floats per step (R for the headings, 2 R for the float2
-  // positions); every lane stores (lanes 32..63 mirror 0..31: the same value to the same address),
-  // at immediate offsets from one pointer that moves once per 8 steps
-  auto walk = [&](const double* inc, const int* ready, double coeff, float start, float* out, auto out_stride_tag) {
-    constexpr int OS = decltype(out_stride_tag)::value;
-    const double* at = inc + r;
-    float* to = out + r * (OS / R);
-    double a[8], b[8];
-    int g_next = 0;
-    auto load = [&](double (&dst)[8]) {  // the increments of the next group of 8 steps, once its wave has stored them
-      if (g_next < W) wait_for(&ready[g_next]);
-      ++g_next;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) dst[q] = at[(size_t)q * R];
-      at += 8 * R;
-    };
-    float vf = start;
-    double v64 = (double)start;
-    auto run = [&](const double (&src)[8]) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        to[q * OS] = vf;  // the value BEFORE the step
-        vf = (float)fma(coeff, src[q], v64);
-        v64 = (double)vf;
-      }
-      to += 8 * OS;
-    };
-    load(a);
-    for (int g = 0; g + 2 <= W; g += 2) {
-      load(b);
-      run(a);
-      load(a);
-      run(b);
-    }
-    if (W & 1) run(a);
-    return vf;  // the value after the last of the 8 W steps
+  // Groups handed to a walker.  Two register sets: while one group is walked the next one's operands
+  // are already on their way, and the flag of the one after is read WITHOUT waiting (the answer is
+  // looked at after the walk): neither the flag's nor the operands' LDS latency sits between two groups
+  // unless the producers are behind.
+  //   fetch(set, group)               loads the group's operands into register set 0 / 1
+  //   run(set, group, flag value)     walks its 8 steps and publishes them
+  auto glance = [&](const int* flag) {  // issues the read; settle() looks at it
+    return __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
-  if (c == 0) {
-    __builtin_amdgcn_s_setprio(3);
-    (void)walk(p0, done_a, wtr0, Q.th0, th_sh, PhaseTag<R>());
-    __builtin_amdgcn_s_setprio(0);
-  } else {
-    // meanwhile: lambda * (u0/s0^2 * e0 + u1/s1^2 * e1) in float64   (mppi.py:1007-1009)
-#pragma unroll
-    for (int j = 0; j < CHL; ++j) ccr[((size_t)k * R + r) * CHL + j] = control_cost(Q, uos[min(t0 + j, Tp - 1)], e[j]);
-  }
-  if (c == 0) {
-#pragma unroll
-    for (int j = 0; j < CHL; ++j) ccr[((size_t)k * R + r) * CHL + j] = control_cost(Q, uos[min(t0 + j, Tp - 1)], e[j]);
-  }
-  MPPI_STAMP(stamp_wg && c < 16, stamp_base + 2);
-  lds_barrier();
-
-  // ---------------------------------------------------------------- B: sin / cos of every heading
-  {
-    // (one full evaluation per lane; its other three headings by the exact-increment rotation of the
-    //  pipelined kernels when the increment is small enough for it -- |delta| <= 0.36 rad, else in full)
-    float thv[CHL];
-#pragma unroll
-    for (int j = 0; j < CHL; ++j) thv[j] = th_sh[(size_t)(t0 + j) * R + r];
-    double s, cs;
-    sincos_f64<false>((double)thv[0], s, cs);
-#pragma unroll
-    for (int j = 0; j < CHL; ++j) {
-      const int t = t0 + j;
-      p0[(size_t)t * R + r] = qx[j] * cs;
-      p1[(size_t)t * R + r] = qx[j] * s;
-      if (j + 1 < CHL) {
-        const double delta = (double)thv[j + 1] - (double)thv[j];  // exact: both are float32 values
-        if (__all(fabs(delta) <= 0.36)) rotate_sincos_f64(delta, s, cs);
-        else sincos_f64<false>((double)thv[j + 1], s, cs);
+  auto settle = [&](int raw) {
+    const int v = __builtin_amdgcn_readfirstlane(raw);
+    pin_memory_order();  // (reads issued after the flag's value is here are served after it: in-order LDS)
+    return v;
+  };
+  auto walk_groups = [&](const int* in_flags, auto&& fetch, auto&& run) {
+    int v0 = wait_for(&in_flags[0]);
+    fetch(PhaseTag<0>(), 0);
+    int v1 = W > 1 ? peek(&in_flags[1]) : 0;
+    if (v1) fetch(PhaseTag<1>(), 1);
+    for (int gi = 0; gi < W; gi += 2) {
+      // set 0 holds group gi; set 1 holds group gi + 1 if v1
+      const int raw2 = gi + 2 < W ? glance(&in_flags[gi + 2]) : 0;
+      run(PhaseTag<0>(), gi, v0);
+      if (gi + 1 >= W) break;
+      if (!v1) {
+        v1 = wait_for(&in_flags[gi + 1]);
+        fetch(PhaseTag<1>(), gi + 1);
       }
-    }
-  }
-  raise(&done_b[c]);
-  MPPI_STAMP(stamp_wg && c < 16, stamp_base + 3);
-
-  // ---------------------------------------------------------------- W2: the position walks
-  if (c == 0) {
-    __builtin_amdgcn_s_setprio(3);
-    float* px = reinterpret_cast<float*>(pos);
-    px[(size_t)Tp * 2 * R + 2 * r] = walk(p0, done_b, vtr0, Q.x0, px, PhaseTag<2 * R>());
-    if (W == 1) px[(size_t)Tp * 2 * R + 2 * r + 1] = walk(p1, done_b, vtr0, Q.y0, px + 1, PhaseTag<2 * R>());
-    __builtin_amdgcn_s_setprio(0);
-  } else if (c == 1) {
-    __builtin_amdgcn_s_setprio(3);
-    float* py = reinterpret_cast<float*>(pos) + 1;
-    py[(size_t)Tp * 2 * R + 2 * r] = walk(p1, done_b, vtr0, Q.y0, py, PhaseTag<2 * R>());
-    __builtin_amdgcn_s_setprio(0);
-  }
-  MPPI_STAMP(stamp_wg && c < 16, stamp_base + 4);
-  lds_barrier();
-
-  // ---------------------------------------------------------------- C: lookups, stage costs, events
-  double sg[CHL], n2[CHL];
-  float xa[CHL + 1], ya[CHL + 1];
-  float po[CHL], pu[CHL];
-  uint32_t zero_bits = 0, mism_bits = 0, hit_bits = 0;
-  const double gt2 = (double)Q.gt2;
-  {
-#pragma unroll
-    for (int j = 0; j <= CHL; ++j) {
-      const float2 pj = pos[(size_t)min(t0 + j, Tp) * R + r];
-      xa[j] = pj.x;
-      ya[j] = pj.y;
-    }
-    uint32_t cell[CHL];
-#pragma unroll
-    for (int j = 0; j < CHL; ++j) cell[j] = scan_lookup<POW2RES>(Q, cells16, xa[j], ya[j]);  // the cell step j STARTS in
-#pragma unroll
-    for (int j = 0; j < CHL; ++j) {
-      const double dx = (double)(Q.xg - xa[j + 1]), dy = (double)(Q.yg - ya[j + 1]);
-      n2[j] = fma(dx, dx, dy * dy);
-      sg[j] = fma(Q.dist_weight, sqrt_newton_nz_f64(n2[j]), dt64);
-      hit_bits |= (n2[j] <= gt2 ? 1u : 0u) << j;
-    }
-    pin_memory_order();
-#pragma unroll
-    for (int j = 0; j < CHL; ++j) {
-      const uint32_t cl = cell[j];
-      zero_bits |= ((int)(cl & 127u) == Q.lin_zero_byte ? 1u : 0u) << j;
-      mism_bits |= (((cl ^ ref) & 0x3fffu) != 0u ? 1u : 0u) << j;
-      po[j] = (cl & 0x4000u) ? Q.obs_cost : 0.0f;
-      pu[j] = (cl & 0x8000u) ? Q.unk_cost : 0.0f;
-    }
-  }
-  const uint32_t vmask = (1u << nvalid) - 1u;
-  const int s = __builtin_ctz((zero_bits & vmask) | (1u << CHL));
-  const int hh = __builtin_ctz((hit_bits & vmask & ((1u << s) - 1u)) | (1u << CHL));
-  const bool is_hit = hh < CHL, froze = !is_hit && s < nvalid;
-  int n_act = is_hit ? hh + 1 : min(s, nvalid);
-  const bool bad = (mism_bits & ((1u << n_act) - 1u)) != 0u;
-  const uint32_t ev = is_hit ? 1u : (froze ? 2u : 0u);
-  double f_k = 0.0, f_d2 = 1e9;
-  float f_po = 0.0f, f_pu = 0.0f;
-  bool f_hit = false;
-  if (__any(froze)) {
-    float fx = xa[0], fy = ya[0];
-    f_po = po[0];
-    f_pu = pu[0];
-#pragma unroll
-    for (int j = 1; j < CHL; ++j) {
-      fx = s == j ? xa[j] : fx;
-      fy = s == j ? ya[j] : fy;
-      f_po = s == j ? po[j] : f_po;
-      f_pu = s == j ? pu[j] : f_pu;
-    }
-    // a rollout in a cell of zero linear traction stays where it is: x = float32(fma(0, ., x))
-    const double dx = (double)(Q.xg - fx), dy = (double)(Q.yg - fy);
-    f_d2 = fma(dx, dx, dy * dy);
-    f_k = fma(Q.dist_weight, sqrt_newton_nz_f64(f_d2), dt64);
-    f_hit = f_d2 <= gt2;
-  }
-  if (ev != 0u) atomicOr(&evw[2 * r + ((2 * k) >> 5)], ev << ((2 * k) & 31));
-  {
-    bool pen = false;
-#pragma unroll
-    for (int j = 0; j < CHL; ++j) pen = pen || (j < nvalid && (po[j] != 0.0f || pu[j] != 0.0f));
-    if (__any(pen) && lane == 0) atomicOr(&flags[1], 1u);
-  }
-  MPPI_STAMP(stamp_wg && c < 16, stamp_base + 5);
-  lds_barrier();
-
-  // ---------------------------------------------------------------- D'
-  {
-    const uint32_t w0 = evw[2 * r], w1 = evw[2 * r + 1];
-    const uint64_t word = ((uint64_t)w1 << 32) | w0;
-    const bool dead = (word & ((1ull << (2 * k)) - 1ull)) != 0ull;
-    n_act = dead ? 0 : n_act;
-    const bool owner = !dead && ev != 0u;
-    const bool last = t0 < T && t0 + CHL >= T;
-    if (owner || (!dead && last)) {
-      double term = 0.0;  // (1 - reached) * sqrt(d2) / (v_post + 1e-6)   (mppi.py:26-28, 1005)
-      if (ev == 2u) {
-        term = f_hit ? 0.0 : sqrt(f_d2) / Q.v_post_den;
-      } else if (ev == 0u) {
-        double n2l = n2[0];
-#pragma unroll
-        for (int j = 1; j < CHL; ++j) n2l = (nvalid - 1 == j) ? n2[j] : n2l;
-        term = sqrt(n2l) / Q.v_post_den;
+      int v2 = settle(raw2);
+      if (v2) fetch(PhaseTag<0>(), gi + 2);
+      const int raw3 = gi + 3 < W ? glance(&in_flags[gi + 3]) : 0;
+      run(PhaseTag<1>(), gi + 1, v1);
+      if (gi + 2 >= W) break;
+      if (!v2) {
+        v2 = wait_for(&in_flags[gi + 2]);
+        fetch(PhaseTag<0>(), gi + 2);
       }
-      term_sh[r] = term;
-      if (ev == 2u) {
-        fz_k[r] = f_k;
-        fz_po[r] = f_po;
-        fz_pu[r] = f_pu;
-        fz_count[r] = f_hit ? 1 : T - (t0 + s);
-      }
+      v0 = v2;
+      v1 = settle(raw3);
+      if (v1) fetch(PhaseTag<1>(), gi + 3);
     }
-    if (__any(!dead && bad) && lane == 0) atomicOr(&flags[0], 1u);
-    char* out = rec + ((size_t)k * R + r) * (CHL * 16);
-    double2* o2 = reinterpret_cast<double2*>(out);
-    o2[0] = make_double2(0 < n_act ? sg[0] : 0.0, 1 < n_act ? sg[1] : 0.0);
-    o2[1] = make_double2(2 < n_act ? sg[2] : 0.0, 3 < n_act ? sg[3] : 0.0);
-    float4* o4 = reinterpret_cast<float4*>(out + CHL * 8);
-    o4[0] = make_float4(0 < n_act ? po[0] : 0.0f, 1 < n_act ? po[1] : 0.0f, 2 < n_act ? po[2] : 0.0f, 3 < n_act ? po[3] : 0.0f);
-    o4[1] = make_float4(0 < n_act ? pu[0] : 0.0f, 1 < n_act ? pu[1] : 0.0f, 2 < n_act ? pu[2] : 0.0f, 3 < n_act ? pu[3] : 0.0f);
-  }
-  MPPI_STAMP(stamp_wg && c < 16, stamp_base + 6);
-  lds_barrier();
+  };
 
-  // ---------------------------------------------------------------- E: the cost walk
-  if (c == 0) {
+  if (walker == 0 || walker == 1) {
+    // ================================================================ the theta walk (wave 0), the x | y walk (wave 4)
+    // one running sum rounded to float32 after every fma; a lone wave issues an instruction per ~5
+    // cycles: what counts is the instruction count -- one pointer per group, immediate offsets
     __builtin_amdgcn_s_setprio(3);
-    const bool failed = flags[0] != 0u;
+    const uint32_t ref = scan_lookup<POW2RES>(Q, cells16, Q.x0, Q.y0) & 0x3fffu;
+    const double coeff = walker == 0 ? fma(Q.ang_ratio, (double)(int)((ref >> 7) & 127u), Q.ang_lo)
+                                : fma(Q.lin_ratio, (double)(int)(ref & 127u), Q.lin_lo);
+    // theta: rows of R floats; positions: rows of R float2, x in lanes 0..31, y in lanes 32..63
+    // (the theta walk's upper lanes mirror the lower ones: the same value to the same address)
+    const int OS = walker == 0 ? R : 2 * R;
+    float* out = walker == 0 ? th_sh + r : reinterpret_cast<float*>(pos) + 2 * r + h;
+    const size_t half = walker == 0 ? 0 : (size_t)h * (8 * R * 8);  // y increments: the group's second half
+    float vf = walker == 0 ? Q.th0 : (h == 0 ? Q.x0 : Q.y0);
+    double v64 = (double)vf;
+    out[0] = vf;  // row 0: the value before step 0
+    double inc[2][8];
+    int* const out_flags = walker == 0 ? th_done : xy_done;
+    walk_groups(
+        walker == 0 ? a_done : b_done,
+        [&](auto set, int gi) {
+          const double* at = reinterpret_cast<const double*>(grp + (size_t)gi * 4096 + half) + r;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) inc[decltype(set)::value][q] = at[(size_t)q * R];
+        },
+        [&](auto set, int gi, int) {
+          float* to = out + (size_t)(8 * gi + 1) * OS;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            vf = (float)fma(coeff, inc[decltype(set)::value][q], v64);
+            v64 = (double)vf;
+            to[q * OS] = vf;  // row t + 1: the value after step t
+          }
+          raise(&out_flags[gi], 1);
+        });
+    __builtin_amdgcn_s_setprio(0);
+    MPPI_STAMP(stamp_wg, stamp_base + 1);
+  } else if (walker == 2) {
+    // ================================================================ the cost walk (wave 1)
+    __builtin_amdgcn_s_setprio(3);
     float cost = 0.0f;
-    if (!failed) {
-      // records of 4 steps: {double sg[4]; float po[4]; float pu[4]} = 4 x 16 bytes, two records per group.
-      // A tile that met no obstacle or unknown cell (flags[1] clear) adds +0.0f twice per step, which
-      // leaves a cost >= +0 as it is: its walk is the three instructions of the float64 add alone.
-      auto stage_walk = [&](auto pen_tag) {
-        constexpr bool PEN = decltype(pen_tag)::value != 0;
-        constexpr int G = 2;
-        double2 ga[G * 2], gb[G * 2];
-        float4 fa[G * 2], fb[G * 2];
-        const char* at = rec + (size_t)r * 64;
-        auto load = [&](double2 (&d)[G * 2], float4 (&f)[G * 2]) {
+    double2 sg[2][4];  // [set][chunk of the group * 2 + half]
+    float4 fo[2][2], fu[2][2];
+    walk_groups(
+        c_done,
+        [&](auto set, int gi) {
+          constexpr int S = decltype(set)::value;
+          const char* in = grp + (size_t)gi * 4096 + (size_t)r * 64;
 #pragma unroll
-          for (int g = 0; g < G; ++g) {
-            const char* in = at + (size_t)g * R * 64;
-            d[2 * g] = reinterpret_cast<const double2*>(in)[0];
-            d[2 * g + 1] = reinterpret_cast<const double2*>(in)[1];
-            if constexpr (PEN) {
-              f[2 * g] = reinterpret_cast<const float4*>(in + 32)[0];
-              f[2 * g + 1] = reinterpret_cast<const float4*>(in + 32)[1];
+          for (int hh = 0; hh < 2; ++hh) {
+            sg[S][2 * hh] = reinterpret_cast<const double2*>(in + hh * 2048)[0];
+            sg[S][2 * hh + 1] = reinterpret_cast<const double2*>(in + hh * 2048)[1];
+            fo[S][hh] = reinterpret_cast<const float4*>(in + hh * 2048 + 32)[0];
+            fu[S][hh] = reinterpret_cast<const float4*>(in + hh * 2048 + 32)[1];
+          }
+        },
+        [&](auto set, int, int flag_value) {
+          constexpr int S = decltype(set)::value;
+          // (a group that met no obstacle or unknown cell adds +0.0f twice per step, which leaves a
+          //  cost >= +0 as it is: its walk is the three instructions of the float64 add alone)
+          if (flag_value & 2) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const double2 s01 = sg[S][2 * hh], s23 = sg[S][2 * hh + 1];
+              const float4 o = fo[S][hh], q = fu[S][hh];
+              cost = (float)((double)cost + s01.x); cost = cost + o.x; cost = cost + q.x;  // mppi.py:994, 997, 998
+              cost = (float)((double)cost + s01.y); cost = cost + o.y; cost = cost + q.y;
+              cost = (float)((double)cost + s23.x); cost = cost + o.z; cost = cost + q.z;
+              cost = (float)((double)cost + s23.y); cost = cost + o.w; cost = cost + q.w;
+            }
+          } else {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const double2 s01 = sg[S][2 * hh], s23 = sg[S][2 * hh + 1];
+              cost = (float)((double)cost + s01.x);
+              cost = (float)((double)cost + s01.y);
+              cost = (float)((double)cost + s23.x);
+              cost = (float)((double)cost + s23.y);
             }
           }
-          at += (size_t)G * R * 64;
-        };
-        auto step = [&](double sgv, float ov, float qv) {  // mppi.py:994, 997, 998
-          cost = (float)((double)cost + sgv);
-          if constexpr (PEN) {
-            cost = cost + ov;
-            cost = cost + qv;
-          }
-        };
-        auto add_record = [&](const double2 (&d)[G * 2], const float4 (&f)[G * 2], int g) {
-          const double2 s01 = d[2 * g], s23 = d[2 * g + 1];
-          const float4 o = f[2 * g], q = f[2 * g + 1];
-          step(s01.x, o.x, q.x);
-          step(s01.y, o.y, q.y);
-          step(s23.x, o.z, q.z);
-          step(s23.y, o.w, q.w);
-        };
-        load(ga, fa);
-        int i = 0;
-        for (; i + 2 * G <= K; i += 2 * G) {
-          load(gb, fb);
-#pragma unroll
-          for (int g = 0; g < G; ++g) add_record(ga, fa, g);
-          load(ga, fa);
-#pragma unroll
-          for (int g = 0; g < G; ++g) add_record(gb, fb, g);
-        }
-        if (i + G <= K) {
-          load(gb, fb);
-#pragma unroll
-          for (int g = 0; g < G; ++g) add_record(ga, fa, g);
-          i += G;
-#pragma unroll
-          for (int g = 0; g < G - 1; ++g)
-            if (i + g < K) add_record(gb, fb, g);
-        } else {
-#pragma unroll
-          for (int g = 0; g < G - 1; ++g)
-            if (i + g < K) add_record(ga, fa, g);
-        }
-      };
-      if (flags[1] != 0u) stage_walk(PhaseTag<1>());
-      else stage_walk(PhaseTag<0>());
-      MPPI_STAMP(stamp_wg, stamp_base + 9);
+        });
+    MPPI_STAMP(stamp_wg, stamp_base + 1);
+    const bool failed = flags[0] != 0u;  // (every chunk wave has published its vote before its c_done)
+    if (!failed) {
       const int cnt = fz_count[r];
       if (__any(cnt > 0)) cost = frozen_block_exact(cost, fz_k[r], fz_po[r], fz_pu[r], cnt);
-      MPPI_STAMP(stamp_wg, stamp_base + 10);
+      MPPI_STAMP(stamp_wg, stamp_base + 2);
       cost = (float)((double)cost + term_sh[r]);
     } else {
       // ---- the tile step by step, with the tractions of the visited cells: k_rollout_map's arithmetic
@@ -499,56 +343,42 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
       }
       RolloutState st = {Q.x0, Q.y0, Q.th0, 0.0f, 1e9, false, false};
       for (int t = 0; t < T; ++t) {
-        map_step<MAP_DET, true, false, false>(Q, cells, nullptr, nullptr, folded ? u_sh[t] : uq[t], e2[t * R + (r ^ (t & (R - 1)))], st);
+        map_step<MAP_DET, true, false, false>(Q, cells, nullptr, nullptr, folded ? u_sh[t] : uq[t],
+                                              e2[t * R + (r ^ (t & (R - 1)))], st);
         if (__all(st.done)) break;
       }
       cost = (float)((double)st.cost + (st.reached ? 0.0 : 1.0) * sqrt(st.d2) / Q.v_post_den);
     }
-    // the control cost of all T steps, also after an early goal break (mppi.py:1007-1009)
+    // the control cost of all T steps, also after an early goal break (mppi.py:1007-1009); steps past
+    // the horizon hold zero noise: their terms are +0.0
     {
-      constexpr int G = 4;  // records of 4 doubles
-      double2 ga[G * 2], gb[G * 2];
       const double* at = ccr + (size_t)r * CHL;
-      auto load = [&](double2 (&d)[G * 2]) {
+      double2 ca[2][4];
+      auto load = [&](auto set, int gi) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          d[2 * g] = reinterpret_cast<const double2*>(at + (size_t)g * R * CHL)[0];
-          d[2 * g + 1] = reinterpret_cast<const double2*>(at + (size_t)g * R * CHL)[1];
+        for (int hh = 0; hh < 2; ++hh) {
+          const double* in = at + (size_t)(2 * gi + hh) * R * CHL;
+          ca[decltype(set)::value][2 * hh] = reinterpret_cast<const double2*>(in)[0];
+          ca[decltype(set)::value][2 * hh + 1] = reinterpret_cast<const double2*>(in)[1];
         }
-        at += (size_t)G * R * CHL;
       };
-      auto add_record = [&](const double2 (&d)[G * 2], int g) {
-        cost = (float)((double)cost + d[2 * g].x);
-        cost = (float)((double)cost + d[2 * g].y);
-        cost = (float)((double)cost + d[2 * g + 1].x);
-        cost = (float)((double)cost + d[2 * g + 1].y);
+      auto add = [&](auto set) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          cost = (float)((double)cost + ca[decltype(set)::value][i].x);
+          cost = (float)((double)cost + ca[decltype(set)::value][i].y);
+        }
       };
-      // (steps past the horizon hold zero noise: their terms are +0.0)
-      load(ga);
-      int i = 0;
-      for (; i + 2 * G <= K; i += 2 * G) {
-        load(gb);
-#pragma unroll
-        for (int g = 0; g < G; ++g) add_record(ga, g);
-        load(ga);
-#pragma unroll
-        for (int g = 0; g < G; ++g) add_record(gb, g);
-      }
-      if (i + G <= K) {
-        load(gb);
-#pragma unroll
-        for (int g = 0; g < G; ++g) add_record(ga, g);
-        i += G;
-#pragma unroll
-        for (int g = 0; g < G - 1; ++g)
-          if (i + g < K) add_record(gb, g);
-      } else {
-#pragma unroll
-        for (int g = 0; g < G - 1; ++g)
-          if (i + g < K) add_record(ga, g);
+      load(PhaseTag<0>(), 0);
+      for (int gi = 0; gi < W; gi += 2) {
+        if (gi + 1 < W) load(PhaseTag<1>(), gi + 1);
+        add(PhaseTag<0>());
+        if (gi + 1 >= W) break;
+        if (gi + 2 < W) load(PhaseTag<0>(), gi + 2);
+        add(PhaseTag<1>());
       }
     }
-    MPPI_STAMP(stamp_wg, stamp_base + 7);
+    MPPI_STAMP(stamp_wg, stamp_base + 3);
     const bool mine = live && lane < R;
     if (mine) costs[n] = cost;
     // first half of the control update (update_kernels.h): weights relative to the tile's minimum,
@@ -562,13 +392,223 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
       pk.tbeta[tile] = beta;
       pk.tden[tile] = den;
     }
-    MPPI_STAMP(stamp_wg, stamp_base + 11);
+    __builtin_amdgcn_s_setprio(0);
+    MPPI_STAMP(stamp_wg, stamp_base + 4);
+  } else if (g >= 0) {
+    // ================================================================ chunk wave g: steps 8 g .. 8 g + 7
+    switch (prio) {  // (earlier groups first on their SIMD)
+      case 3: __builtin_amdgcn_s_setprio(3); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      default: break;
+    }
+    double* const inc_x = reinterpret_cast<double*>(grp + (size_t)g * 4096);  // [8][R]: dt*w, then (dt*v)*cos
+    double* const inc_y = inc_x + 8 * R;                                      // [8][R]: (dt*v)*sin
+    // ---------------------------------------------------------------- A
+    float2 ut[CHL];
+    if (folded) {  // (wave-uniform) the 8 controls of this wave's steps from the ranks' packets
+      if (lane < 8) {
+        const int t = 8 * g + lane;
+        const float2 v = t < T ? pending_apply_control(pend, scale_sh, uq, t) : make_float2(0.0f, 0.0f);
+        u_sh[t] = v;
+        if (tile == 0 && t < T) {
+          pend.u_out[t] = v;
+          pend.u_prev[t] = v;
+        }
+      }
+      if (tile == 0 && g == 0 && lane == 0) {
+        pend.stats[0] = scale_sh[kMaxFoldedRanks + 1];
+        pend.stats[1] = scale_sh[kMaxFoldedRanks];
+      }
+#pragma unroll
+      for (int j = 0; j < CHL; ++j) ut[j] = u_sh[t0 + j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < CHL; ++j) ut[j] = uq[min(t0 + j, T - 1)];
+    }
+    const uint32_t ref = scan_lookup<POW2RES>(Q, cells16, Q.x0, Q.y0) & 0x3fffu;
+    if (lane < 8) {  // the control ratios of this wave's 8 steps (float64 quotients: mppi.py:709)
+      const float2 ul = folded ? u_sh[8 * g + lane] : uq[min(8 * g + lane, T - 1)];
+      uos[8 * g + lane] = make_double2((double)ul.x / Q.s0sq, (double)ul.y / Q.s1sq);
+    }
+    float2 e[CHL];
+    if constexpr (GEN) {
+      const uint64_t epoch = gen.epoch + (gen.gen_counter ? *gen.gen_counter : 0ull);
+      const unsigned int pairs = (unsigned int)(T + 1) / 2u;
+      const unsigned int n_global = (unsigned int)(gen.n_offset + min(n, N - 1));
+#pragma unroll
+      for (int jp = 0; jp < CHL / 2; ++jp) {
+        const unsigned int tp = (unsigned int)(t0 / 2 + jp);
+        scan_noise_pair(gen, epoch, n_global, pairs, min(tp, pairs - 1u), e[2 * jp], e[2 * jp + 1]);
+      }
+    } else {
+      const float2* col = noise + (size_t)(n >> 6) * T * 64 + (n & 63);
+#pragma unroll
+      for (int j = 0; j < CHL; ++j) e[j] = col[(size_t)min(t0 + j, T - 1) * 64];
+    }
+    double qx[CHL];  // dt * clipped speed: exact products of float32 factors
+#pragma unroll
+    for (int j = 0; j < CHL; ++j) {
+      const bool valid = j < nvalid;
+      ut[j] = valid ? ut[j] : make_float2(0.0f, 0.0f);
+      e[j] = valid ? e[j] : make_float2(0.0f, 0.0f);
+      const int t = t0 + j;
+      e2[t * R + (r ^ (t & (R - 1)))] = e[j];
+      const float v = clip_f32(ut[j].x + e[j].x, Q.v_lo, Q.v_hi);
+      const float w = clip_f32(ut[j].y + e[j].y, Q.w_lo, Q.w_hi);
+      qx[j] = dt64 * (double)v;
+      inc_x[(size_t)(CHL * h + j) * R + r] = dt64 * (double)w;
+    }
+    raise(&a_done[g], 1);
+    if ((c & 3) == 0) __builtin_amdgcn_s_setprio(0);  // (beside the theta and x | y walks from here on)
+    MPPI_STAMP(stamp_wg && c < 16, stamp_base + 1);
+    // meanwhile: lambda * (u0/s0^2 * e0 + u1/s1^2 * e1) in float64   (mppi.py:1007-1009)
+#pragma unroll
+    for (int j = 0; j < CHL; ++j) ccr[((size_t)k * R + r) * CHL + j] = control_cost(Q, uos[min(t0 + j, Tp - 1)], e[j]);
+    MPPI_STAMP(stamp_wg && c < 16, stamp_base + 2);
+
+    // ---------------------------------------------------------------- B: sin / cos of this wave's headings
+    (void)wait_for(&th_done[g]);
+    {
+      // (one full evaluation per lane; its other three headings by the exact-increment rotation of the
+      //  pipelined kernels when the increment is small enough for it -- |delta| <= 0.36 rad, else in full)
+      float thv[CHL];
+#pragma unroll
+      for (int j = 0; j < CHL; ++j) thv[j] = th_sh[(size_t)(t0 + j) * R + r];
+      double s, cs;
+      sincos_f64<false>((double)thv[0], s, cs);
+#pragma unroll
+      for (int j = 0; j < CHL; ++j) {
+        inc_x[(size_t)(CHL * h + j) * R + r] = qx[j] * cs;
+        inc_y[(size_t)(CHL * h + j) * R + r] = qx[j] * s;
+        if (j + 1 < CHL) {
+          const double delta = (double)thv[j + 1] - (double)thv[j];  // exact: both are float32 values
+          if (__all(fabs(delta) <= 0.36)) rotate_sincos_f64(delta, s, cs);
+          else sincos_f64<false>((double)thv[j + 1], s, cs);
+        }
+      }
+    }
+    raise(&b_done[g], 1);
+    MPPI_STAMP(stamp_wg && c < 16, stamp_base + 3);
+
+    // ---------------------------------------------------------------- C: lookups, stage costs, events
+    (void)wait_for(&xy_done[g]);
+    MPPI_STAMP(stamp_wg && c < 16, stamp_base + 4);
+    double sg[CHL], n2[CHL];
+    float xa[CHL + 1], ya[CHL + 1];
+    float po[CHL], pu[CHL];
+    uint32_t zero_bits = 0, mism_bits = 0, hit_bits = 0;
+    const double gt2 = (double)Q.gt2;
+    {
+#pragma unroll
+      for (int j = 0; j <= CHL; ++j) {
+        const float2 pj = pos[(size_t)(t0 + j) * R + r];  // (row t0 + 4 <= 8 g + 8: stored with this group)
+        xa[j] = pj.x;
+        ya[j] = pj.y;
+      }
+      uint32_t cell[CHL];
+#pragma unroll
+      for (int j = 0; j < CHL; ++j) cell[j] = scan_lookup<POW2RES>(Q, cells16, xa[j], ya[j]);  // the cell step j STARTS in
+#pragma unroll
+      for (int j = 0; j < CHL; ++j) {
+        const double dx = (double)(Q.xg - xa[j + 1]), dy = (double)(Q.yg - ya[j + 1]);
+        n2[j] = fma(dx, dx, dy * dy);
+        sg[j] = fma(Q.dist_weight, sqrt_newton_nz_f64(n2[j]), dt64);
+        hit_bits |= (n2[j] <= gt2 ? 1u : 0u) << j;
+      }
+      pin_memory_order();
+#pragma unroll
+      for (int j = 0; j < CHL; ++j) {
+        const uint32_t cl = cell[j];
+        zero_bits |= ((int)(cl & 127u) == Q.lin_zero_byte ? 1u : 0u) << j;
+        mism_bits |= (((cl ^ ref) & 0x3fffu) != 0u ? 1u : 0u) << j;
+        po[j] = (cl & 0x4000u) ? Q.obs_cost : 0.0f;
+        pu[j] = (cl & 0x8000u) ? Q.unk_cost : 0.0f;
+      }
+    }
+    const uint32_t vmask = (1u << nvalid) - 1u;
+    const int s = __builtin_ctz((zero_bits & vmask) | (1u << CHL));
+    const int hh = __builtin_ctz((hit_bits & vmask & ((1u << s) - 1u)) | (1u << CHL));
+    const bool is_hit = hh < CHL, froze = !is_hit && s < nvalid;
+    int n_act = is_hit ? hh + 1 : min(s, nvalid);
+    const bool bad = (mism_bits & ((1u << n_act) - 1u)) != 0u;
+    const uint32_t ev = is_hit ? 1u : (froze ? 2u : 0u);
+    double f_k = 0.0, f_d2 = 1e9;
+    float f_po = 0.0f, f_pu = 0.0f;
+    bool f_hit = false;
+    if (__any(froze)) {
+      float fx = xa[0], fy = ya[0];
+      f_po = po[0];
+      f_pu = pu[0];
+#pragma unroll
+      for (int j = 1; j < CHL; ++j) {
+        fx = s == j ? xa[j] : fx;
+        fy = s == j ? ya[j] : fy;
+        f_po = s == j ? po[j] : f_po;
+        f_pu = s == j ? pu[j] : f_pu;
+      }
+      // a rollout in a cell of zero linear traction stays where it is: x = float32(fma(0, ., x))
+      const double dx = (double)(Q.xg - fx), dy = (double)(Q.yg - fy);
+      f_d2 = fma(dx, dx, dy * dy);
+      f_k = fma(Q.dist_weight, sqrt_newton_nz_f64(f_d2), dt64);
+      f_hit = f_d2 <= gt2;
+    }
+    bool pen = false;
+#pragma unroll
+    for (int j = 0; j < CHL; ++j) pen = pen || (j < nvalid && (po[j] != 0.0f || pu[j] != 0.0f));
+    const bool group_pen = __any(pen);
+    // the events of ALL earlier chunks must be in evw when this wave looks: then the first event wins
+    // (a short chain from wave to wave: publish, pass the baton, only then the records)
+    if (g > 0) (void)wait_for(&ev_done[g - 1]);
+    if (ev != 0u) atomicOr(&evw[2 * r + ((2 * k) >> 5)], ev << ((2 * k) & 31));
+    raise(&ev_done[g], 1);
+    MPPI_STAMP(stamp_wg && c < 16, stamp_base + 5);
+
+    // ---------------------------------------------------------------- D'
+    {
+      // (the lower half's event of this very wave is in evw: LDS operations of a wave complete in order)
+      const uint32_t w0 = evw[2 * r], w1 = evw[2 * r + 1];
+      const uint64_t word = ((uint64_t)w1 << 32) | w0;
+      const bool dead = (word & ((1ull << (2 * k)) - 1ull)) != 0ull;
+      n_act = dead ? 0 : n_act;
+      const bool owner = !dead && ev != 0u;
+      const bool last = t0 < T && t0 + CHL >= T;
+      if (owner || (!dead && last)) {
+        double term = 0.0;  // (1 - reached) * sqrt(d2) / (v_post + 1e-6)   (mppi.py:26-28, 1005)
+        if (ev == 2u) {
+          term = f_hit ? 0.0 : sqrt(f_d2) / Q.v_post_den;
+        } else if (ev == 0u) {
+          double n2l = n2[0];
+#pragma unroll
+          for (int j = 1; j < CHL; ++j) n2l = (nvalid - 1 == j) ? n2[j] : n2l;
+          term = sqrt(n2l) / Q.v_post_den;
+        }
+        term_sh[r] = term;
+        if (ev == 2u) {
+          fz_k[r] = f_k;
+          fz_po[r] = f_po;
+          fz_pu[r] = f_pu;
+          fz_count[r] = f_hit ? 1 : T - (t0 + s);
+        }
+      }
+      if (__any(!dead && bad) && lane == 0) atomicOr(&flags[0], 1u);
+      // the group's records over its (consumed) position increments
+      char* out = grp + (size_t)g * 4096 + (size_t)h * 2048 + (size_t)r * 64;
+      double2* o2 = reinterpret_cast<double2*>(out);
+      o2[0] = make_double2(0 < n_act ? sg[0] : 0.0, 1 < n_act ? sg[1] : 0.0);
+      o2[1] = make_double2(2 < n_act ? sg[2] : 0.0, 3 < n_act ? sg[3] : 0.0);
+      float4* o4 = reinterpret_cast<float4*>(out + CHL * 8);
+      o4[0] = make_float4(0 < n_act ? po[0] : 0.0f, 1 < n_act ? po[1] : 0.0f, 2 < n_act ? po[2] : 0.0f, 3 < n_act ? po[3] : 0.0f);
+      o4[1] = make_float4(0 < n_act ? pu[0] : 0.0f, 1 < n_act ? pu[1] : 0.0f, 2 < n_act ? pu[2] : 0.0f, 3 < n_act ? pu[3] : 0.0f);
+    }
+    raise(&c_done[g], group_pen ? 3 : 1);
+    MPPI_STAMP(stamp_wg && c < 16, stamp_base + 6);
   }
   lds_barrier();
 
   // ---------------------------------------------------------------- F: the tile's share of the update
-  if (c < 2) {
-    const int t = 64 * c + lane;
+  if (c == 2 || c == 3) {
+    const int t = 64 * (c - 2) + lane;
     if (t < T) {
       const float2* row = e2 + (size_t)t * R;
       const int sw = t & (R - 1);

@@ -4,9 +4,14 @@
     make -C mppi_numba_amd/csrc stamps
     MPPI_HIP_LIB=$PWD/build/libmppi_stamps.so python tools/scan_stamps.py [--n 8192] [--flags N]
 
-Workgroup 5: per wave (chunk) the cycles, from the workgroup's first stamp, at which it entered the
-kernel (0), had its noise and controls (1), reached barrier 1 (2), barrier 2 (3), had its stage costs
-(4), reached barrier 3 (5), barrier 4 (6); wave 0 also: costs written (7); every wave: end (8); wave 0: stage additions done (9), frozen steps done (10), weights written (11)."""
+Workgroup 5, cycles from the workgroup's first stamp, one row per wave.
+k_rollout_scan (math fast): per wave (chunk): entered (0), had its noise and controls (1), reached
+barrier 1 (2), barrier 2 (3), had its stage costs (4), reached barrier 3 (5), barrier 4 (6); wave 0 also:
+costs written (7); every wave: end (8); wave 0: stage additions done (9), frozen steps done (10), weights (11).
+k_rollout_scan_exact: wave 0 = heading walk, wave 1 = position walk: entered (0), walk done (1); wave 2 =
+cost walk: stage walk done (1), frozen steps (2), control-cost walk (3), weights written (4); waves 3.. =
+chunk waves: increments stored (1), control-cost products (2), sin / cos + position increments (3),
+positions arrived (4), events published (5), records stored (6); every wave: end (8)."""
 import argparse
 import contextlib
 import ctypes as C
@@ -44,7 +49,7 @@ def main():
     print(planner.last_rollout_kernel())
     rows = [st[64 + 16 * c: 64 + 16 * c + 12] for c in range(16)]
     t0 = min(int(r[0]) for r in rows if r[0])
-    print("chunk  " + "".join("%8d" % k for k in range(12)))
+    print(" wave  " + "".join("%8d" % k for k in range(12)))
     for c, r in enumerate(rows):
         if r[0]:
             print("%5d  " % c + "".join("%8s" % (int(v - t0) if v else "-") for v in r))
