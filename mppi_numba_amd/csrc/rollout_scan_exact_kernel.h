@@ -250,38 +250,43 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   if (walker == 0 || walker == 1) {
     // ================================================================ the theta walk (wave 0), the x | y walk (wave 4)
     // one running sum rounded to float32 after every fma; a lone wave issues an instruction per ~5
-    // cycles: what counts is the instruction count -- one pointer per group, immediate offsets
+    // cycles: what counts is the instruction count -- one pointer per group, immediate offsets (the
+    // row stride is a compile-time constant of each of the two instances below)
     __builtin_amdgcn_s_setprio(3);
     const uint32_t ref = scan_lookup<POW2RES>(Q, cells16, Q.x0, Q.y0) & 0x3fffu;
-    const double coeff = walker == 0 ? fma(Q.ang_ratio, (double)(int)((ref >> 7) & 127u), Q.ang_lo)
-                                : fma(Q.lin_ratio, (double)(int)(ref & 127u), Q.lin_lo);
-    // theta: rows of R floats; positions: rows of R float2, x in lanes 0..31, y in lanes 32..63
-    // (the theta walk's upper lanes mirror the lower ones: the same value to the same address)
-    const int OS = walker == 0 ? R : 2 * R;
-    float* out = walker == 0 ? th_sh + r : reinterpret_cast<float*>(pos) + 2 * r + h;
-    const size_t half = walker == 0 ? 0 : (size_t)h * (8 * R * 8);  // y increments: the group's second half
-    float vf = walker == 0 ? Q.th0 : (h == 0 ? Q.x0 : Q.y0);
-    double v64 = (double)vf;
-    out[0] = vf;  // row 0: the value before step 0
-    double inc[2][8];
-    int* const out_flags = walker == 0 ? th_done : xy_done;
-    walk_groups(
-        walker == 0 ? a_done : b_done,
-        [&](auto set, int gi) {
-          const double* at = reinterpret_cast<const double*>(grp + (size_t)gi * 4096 + half) + r;
+    auto walk = [&](auto stride_tag, double coeff, float start, float* out, size_t half, const int* in_flags,
+                    int* out_flags) {
+      constexpr int OS = decltype(stride_tag)::value;  // floats per row
+      float vf = start;
+      double v64 = (double)vf;
+      out[0] = vf;  // row 0: the value before step 0
+      double inc[2][8];
+      walk_groups(
+          in_flags,
+          [&](auto set, int gi) {
+            const double* at = reinterpret_cast<const double*>(grp + (size_t)gi * 4096 + half) + r;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) inc[decltype(set)::value][q] = at[(size_t)q * R];
-        },
-        [&](auto set, int gi, int) {
-          float* to = out + (size_t)(8 * gi + 1) * OS;
+            for (int q = 0; q < 8; ++q) inc[decltype(set)::value][q] = at[(size_t)q * R];
+          },
+          [&](auto set, int gi, int) {
+            float* to = out + (size_t)(8 * gi + 1) * OS;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            vf = (float)fma(coeff, inc[decltype(set)::value][q], v64);
-            v64 = (double)vf;
-            to[q * OS] = vf;  // row t + 1: the value after step t
-          }
-          raise(&out_flags[gi], 1);
-        });
+            for (int q = 0; q < 8; ++q) {
+              vf = (float)fma(coeff, inc[decltype(set)::value][q], v64);
+              v64 = (double)vf;
+              to[q * OS] = vf;  // row t + 1: the value after step t
+            }
+            raise(&out_flags[gi], 1);
+          });
+    };
+    if (walker == 0) {
+      // theta: rows of R floats (the upper lanes mirror the lower ones: the same value to the same address)
+      walk(PhaseTag<R>(), fma(Q.ang_ratio, (double)(int)((ref >> 7) & 127u), Q.ang_lo), Q.th0, th_sh + r, 0, a_done, th_done);
+    } else {
+      // positions: rows of R float2, x in lanes 0..31, y in lanes 32..63 (the group's second half of increments)
+      walk(PhaseTag<2 * R>(), fma(Q.lin_ratio, (double)(int)(ref & 127u), Q.lin_lo), h == 0 ? Q.x0 : Q.y0,
+           reinterpret_cast<float*>(pos) + 2 * r + h, (size_t)h * (8 * R * 8), b_done, xy_done);
+    }
     __builtin_amdgcn_s_setprio(0);
     MPPI_STAMP(stamp_wg, stamp_base + 1);
   } else if (walker == 2) {
