@@ -30,12 +30,12 @@
 //   chunk wave g                      walker
 //   A  noise (GEN: Philox; else read), clipped controls, dt*w          -> a_done[g]
 //                                     theta walk over group g          -> th_done[g]
-//      (meanwhile: the control-cost products, mppi.py:1007-1009)
 //   B  sin / cos of the 8 headings, (dt*v)*cos, (dt*v)*sin             -> b_done[g]
 //                                     x | y walk over group g          -> xy_done[g]
 //   C  lookups, goal distances, sqrt, stage costs; freeze / goal events, the vote
 //      (after ev_done[g-1]: all earlier events are known)              -> ev_done[g]
 //   D' first event wins, per-step addends                              -> c_done[g]
+//      last of all: the control-cost products (mppi.py:1007-1009)      -> cc_done[g]
 //                                     cost walk over group g (stage, obstacle, unknown per step)
 //   ... then, by the cost wave: frozen steps, terminal cost, the T control-cost terms
 //   (mppi.py:1005-1009), cost, tile weights; barrier; F: per-tile update sums, lane = step.
@@ -78,7 +78,7 @@ struct ScanExactLds {
   __host__ __device__ static constexpr size_t grp(int W) { return 2 * plane(W); }
   __host__ __device__ static constexpr size_t p2(int W) { return (size_t)(W * 8 + 1) * R * 8; }
   __host__ __device__ static constexpr size_t small(int W) {
-    return (size_t)W * 8 * (16 + 8) + R * 64 + 64 + 8 * (kMaxFoldedRanks + 2) + 6 * 16 * 4;
+    return (size_t)W * 8 * (16 + 8) + R * 64 + 64 + 8 * (kMaxFoldedRanks + 2) + 7 * 16 * 4;
   }
   __host__ __device__ static constexpr size_t total(int W) { return e2(W) + ccr(W) + grp(W) + p2(W) + small(W); }
 };
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   //                                   wave:   0   1  2  3   4  5  6  7   8  9 10 11  12 13 14  15
   constexpr int kGroupOfWave[16] =          {-1, -1, 1, 2, -1, 0, 4, 5, 11, 3, 7, 8, 12, 6, 9, 10};
   constexpr int kPrioOfWave[16] =           { 3,  3, 3, 3,  3, 3, 2, 2,  3, 2, 1, 1,  3, 1, 0,  0};
+  // (one walker per SIMD -- waves 0, 1, 2 -- measured the same: profiles/r03_scan_notes.md)
   const int walker = c == 0 ? 0 : (c == 4 ? 1 : (c == 1 ? 2 : -1));
   int g = -1, prio = 0;
 #pragma unroll
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   int* xy_done = b_done + 16;                       // [16] positions (position walk)
   int* ev_done = xy_done + 16;                      // [16] freeze / goal events of the group and of all before it (chunk wave)
   int* c_done = ev_done + 16;                       // [16] records (chunk wave): 1, or 3 = a penalty in the group
+  int* cc_done = c_done + 16;                       // [16] control-cost terms (chunk wave)
   const bool folded = pend.packets != nullptr;
   if (folded && c == 0) pending_apply_prepare(pend, lane, scale_sh);
   if (c == 4) {
@@ -182,9 +184,10 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
       fz_count[lane] = 0;
       if (lane == 0) flags[0] = 0u;
     }
-    for (int i = lane; i < 6 * 16; i += 64) a_done[i] = 0;
+    for (int i = lane; i < 7 * 16; i += 64) a_done[i] = 0;
   }
   lds_barrier();  // (every wave has only just started)
+  MPPI_STAMP(stamp_wg && c < 16, stamp_base + 9);
   // Everything a flag guards is in LDS, and the LDS executes one wave's instructions in the order they
   // were issued: a flag written after the data IS after the data for every other wave.  No s_waitcnt
   // before the flag store (a release would drain the wave's outstanding LDS stores first: ~100 cycles
@@ -295,6 +298,16 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     float cost = 0.0f;
     double2 sg[2][4];  // [set][chunk of the group * 2 + half]
     float4 fo[2][2], fu[2][2];
+    // terminal cost of a rollout that met no event: from the position after the last step.  Computed
+    // while this wave waits for the last group's records (the position walk is several groups ahead).
+    double term_plain = 0.0;
+    bool term_ready = false;
+    auto plain_terminal = [&]() {
+      const float2 pf = pos[(size_t)T * R + r];
+      const double dx = (double)(Q.xg - pf.x), dy = (double)(Q.yg - pf.y);
+      term_plain = sqrt(fma(dx, dx, dy * dy)) / Q.v_post_den;  // mppi.py:26-28, 1005
+      term_ready = true;
+    };
     walk_groups(
         c_done,
         [&](auto set, int gi) {
@@ -308,7 +321,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
             fu[S][hh] = reinterpret_cast<const float4*>(in + hh * 2048 + 32)[1];
           }
         },
-        [&](auto set, int, int flag_value) {
+        [&](auto set, int gi, int flag_value) {
           constexpr int S = decltype(set)::value;
           // (a group that met no obstacle or unknown cell adds +0.0f twice per step, which leaves a
           //  cost >= +0 as it is: its walk is the three instructions of the float64 add alone)
@@ -332,14 +345,21 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
               cost = (float)((double)cost + s23.y);
             }
           }
+          // (between two groups, as soon as the position walk is through: this wave mostly waits for records)
+          if (!term_ready && peek(&xy_done[W - 1])) plain_terminal();
         });
+    if (!term_ready) {
+      (void)wait_for(&xy_done[W - 1]);
+      plain_terminal();
+    }
     MPPI_STAMP(stamp_wg, stamp_base + 1);
     const bool failed = flags[0] != 0u;  // (every chunk wave has published its vote before its c_done)
     if (!failed) {
       const int cnt = fz_count[r];
       if (__any(cnt > 0)) cost = frozen_block_exact(cost, fz_k[r], fz_po[r], fz_pu[r], cnt);
       MPPI_STAMP(stamp_wg, stamp_base + 2);
-      cost = (float)((double)cost + term_sh[r]);
+      const bool had_event = (evw[2 * r] | evw[2 * r + 1]) != 0u;
+      cost = (float)((double)cost + (had_event ? term_sh[r] : term_plain));
     } else {
       // ---- the tile step by step, with the tractions of the visited cells: k_rollout_map's arithmetic
       if (lane == 0 && Q.spec_failures) {
@@ -356,6 +376,8 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     }
     // the control cost of all T steps, also after an early goal break (mppi.py:1007-1009); steps past
     // the horizon hold zero noise: their terms are +0.0
+    while (!__all(lane >= W || __hip_atomic_load(&cc_done[lane & 15], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0))
+      __builtin_amdgcn_s_sleep(2);
     {
       const double* at = ccr + (size_t)r * CHL;
       double2 ca[2][4];
@@ -431,11 +453,6 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
 #pragma unroll
       for (int j = 0; j < CHL; ++j) ut[j] = uq[min(t0 + j, T - 1)];
     }
-    const uint32_t ref = scan_lookup<POW2RES>(Q, cells16, Q.x0, Q.y0) & 0x3fffu;
-    if (lane < 8) {  // the control ratios of this wave's 8 steps (float64 quotients: mppi.py:709)
-      const float2 ul = folded ? u_sh[8 * g + lane] : uq[min(8 * g + lane, T - 1)];
-      uos[8 * g + lane] = make_double2((double)ul.x / Q.s0sq, (double)ul.y / Q.s1sq);
-    }
     float2 e[CHL];
     if constexpr (GEN) {
       const uint64_t epoch = gen.epoch + (gen.gen_counter ? *gen.gen_counter : 0ull);
@@ -451,6 +468,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
 #pragma unroll
       for (int j = 0; j < CHL; ++j) e[j] = col[(size_t)min(t0 + j, T - 1) * 64];
     }
+    MPPI_STAMP(stamp_wg && c < 16, stamp_base + 10);
     double qx[CHL];  // dt * clipped speed: exact products of float32 factors
 #pragma unroll
     for (int j = 0; j < CHL; ++j) {
@@ -467,10 +485,8 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     raise(&a_done[g], 1);
     if ((c & 3) == 0) __builtin_amdgcn_s_setprio(0);  // (beside the theta and x | y walks from here on)
     MPPI_STAMP(stamp_wg && c < 16, stamp_base + 1);
-    // meanwhile: lambda * (u0/s0^2 * e0 + u1/s1^2 * e1) in float64   (mppi.py:1007-1009)
-#pragma unroll
-    for (int j = 0; j < CHL; ++j) ccr[((size_t)k * R + r) * CHL + j] = control_cost(Q, uos[min(t0 + j, Tp - 1)], e[j]);
-    MPPI_STAMP(stamp_wg && c < 16, stamp_base + 2);
+    // (everything the walks do not wait for comes after their flags: the control-cost products last of all)
+    const uint32_t ref = scan_lookup<POW2RES>(Q, cells16, Q.x0, Q.y0) & 0x3fffu;
 
     // ---------------------------------------------------------------- B: sin / cos of this wave's headings
     (void)wait_for(&th_done[g]);
@@ -577,18 +593,10 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
       const bool dead = (word & ((1ull << (2 * k)) - 1ull)) != 0ull;
       n_act = dead ? 0 : n_act;
       const bool owner = !dead && ev != 0u;
-      const bool last = t0 < T && t0 + CHL >= T;
-      if (owner || (!dead && last)) {
-        double term = 0.0;  // (1 - reached) * sqrt(d2) / (v_post + 1e-6)   (mppi.py:26-28, 1005)
-        if (ev == 2u) {
-          term = f_hit ? 0.0 : sqrt(f_d2) / Q.v_post_den;
-        } else if (ev == 0u) {
-          double n2l = n2[0];
-#pragma unroll
-          for (int j = 1; j < CHL; ++j) n2l = (nvalid - 1 == j) ? n2[j] : n2l;
-          term = sqrt(n2l) / Q.v_post_den;
-        }
-        term_sh[r] = term;
+      if (owner) {
+        // (1 - reached) * sqrt(d2) / (v_post + 1e-6)   (mppi.py:26-28, 1005): zero after a goal hit, from the
+        // frozen position otherwise; a rollout without any event: the cost wave, from the final position
+        term_sh[r] = (ev == 2u && !f_hit) ? sqrt(f_d2) / Q.v_post_den : 0.0;
         if (ev == 2u) {
           fz_k[r] = f_k;
           fz_po[r] = f_po;
@@ -608,6 +616,16 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     }
     raise(&c_done[g], group_pen ? 3 : 1);
     MPPI_STAMP(stamp_wg && c < 16, stamp_base + 6);
+    // ---------------------------------------------------------------- the control-cost terms of this wave's steps:
+    // lambda * (u0/s0^2 * e0 + u1/s1^2 * e1) in float64 (mppi.py:1007-1009), needed after the terminal cost only
+    if (lane < 8) {  // the control ratios of the 8 steps (float64 quotients: mppi.py:709)
+      const float2 ul = folded ? u_sh[8 * g + lane] : uq[min(8 * g + lane, T - 1)];
+      uos[8 * g + lane] = make_double2((double)ul.x / Q.s0sq, (double)ul.y / Q.s1sq);
+    }
+#pragma unroll
+    for (int j = 0; j < CHL; ++j) ccr[((size_t)k * R + r) * CHL + j] = control_cost(Q, uos[min(t0 + j, Tp - 1)], e[j]);
+    raise(&cc_done[g], 1);
+    MPPI_STAMP(stamp_wg && c < 16, stamp_base + 2);
   }
   lds_barrier();
 

@@ -10,8 +10,9 @@ barrier 1 (2), barrier 2 (3), had its stage costs (4), reached barrier 3 (5), ba
 costs written (7); every wave: end (8); wave 0: stage additions done (9), frozen steps done (10), weights (11).
 k_rollout_scan_exact: wave 0 = heading walk, wave 1 = position walk: entered (0), walk done (1); wave 2 =
 cost walk: stage walk done (1), frozen steps (2), control-cost walk (3), weights written (4); waves 3.. =
-chunk waves: increments stored (1), control-cost products (2), sin / cos + position increments (3),
-positions arrived (4), events published (5), records stored (6); every wave: end (8)."""
+chunk waves: increments stored (1), sin / cos + position increments (3),
+positions arrived (4), events published (5), records stored (6); every wave: end (8), first barrier passed
+(9); chunk waves: noise generated (10), control-cost products (2: after the records)."""
 import argparse
 import contextlib
 import ctypes as C
