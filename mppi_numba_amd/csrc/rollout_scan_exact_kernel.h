@@ -200,9 +200,15 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   auto peek = [&](const int* flag) {  // wave-uniform
     return __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
   };
+  // (every flag is raised within some ten thousand cycles of the launch; a wave that has polled for ~50 ms
+  //  has found a bug, and says so instead of hanging the device)
+  constexpr int kMaxPolls = 1 << 19;
   auto wait_for = [&](const int* flag) {
-    int v;
-    while ((v = peek(flag)) == 0) __builtin_amdgcn_s_sleep(2);
+    int v, polls = 0;
+    while ((v = peek(flag)) == 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++polls > kMaxPolls) __builtin_trap();
+    }
     return v;
   };
   const double dt64 = (double)Q.dt;
@@ -376,8 +382,11 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     }
     // the control cost of all T steps, also after an early goal break (mppi.py:1007-1009); steps past
     // the horizon hold zero noise: their terms are +0.0
-    while (!__all(lane >= W || __hip_atomic_load(&cc_done[lane & 15], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0))
+    for (int polls = 0;
+         !__all(lane >= W || __hip_atomic_load(&cc_done[lane & 15], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0);) {
       __builtin_amdgcn_s_sleep(2);
+      if (++polls > kMaxPolls) __builtin_trap();
+    }
     {
       const double* at = ccr + (size_t)r * CHL;
       double2 ca[2][4];
