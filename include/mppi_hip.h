@@ -281,8 +281,10 @@ int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity)
 /* diagnostic: compares the library's single-block Philox4x32-10 with rocRAND's engine on
  * 65536 (seed, subsequence, offset) triples; *mismatches must come back 0 */
 /* developer switches for the parity tests, which pin every rollout kernel variant by name
- * (mppi_planner_describe_last_rollout).  With MPPI_MATH_EXACT the results never depend on them (every
- * variant has the reference's bits).  With MPPI_MATH_FAST they select between kernels that agree to
+ * (mppi_planner_describe_last_rollout).  With MPPI_MATH_EXACT the costs never depend on them (every
+ * variant has the reference's bits); u agrees to float32 resolution between kernel families (the
+ * update's float64 summation tree follows the rollout kernel's tiles of 32 or 64 rollouts: both sit
+ * far inside the 1e-5 the reference's own unordered float32 atomics allow).  With MPPI_MATH_FAST they select between kernels that agree to
  * float32 tolerance only -- and so does whatever else decides which kernel runs there: N, the map
  * (a failed traction vote re-runs a tile sequentially; a map that keeps failing switches the
  * speculative kernels off until it changes). */

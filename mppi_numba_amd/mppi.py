@@ -443,7 +443,8 @@ class MPPI_Numba(object):
 
     def set_debug_flags(self, flags):
         """Developer switches (_lib.DEBUG_*): which rollout kernel variant runs.  math="exact": never the
-        results; math="fast": variants agree to float32 tolerance (include/mppi_hip.h)."""
+        costs (u to float32 resolution: the update's float64 summation tree follows the rollout kernel's
+        tiles, 32 or 64 rollouts); math="fast": variants agree to float32 tolerance (include/mppi_hip.h)."""
         _lib.call("mppi_planner_set_debug_flags", self._handle, int(flags))
 
     def set_graph_replay(self, enabled=True, iterations_per_graph=2):
