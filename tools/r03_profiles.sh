@@ -14,14 +14,14 @@ for item in "$@"; do
   w=${item%%:*}; m=${item##*:}
   name=${TAG}_${w}; [ "$m" = fast ] && name=${name}_fast
   BENCH="python $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload $w --math $m"
-  timeout 600 $BENCH > $OUT/${name/_$w/_bench_$w}.json 2> $RAW/${name}_bench.err
+  timeout 150 $BENCH > $OUT/${name/_$w/_bench_$w}.json 2> $RAW/${name}_bench.err
   for pass in trace fetch write; do
     case $pass in
       trace) ARGS="--kernel-trace --stats";;
       fetch) ARGS="--kernel-trace --pmc FETCH_SIZE";;
       write) ARGS="--kernel-trace --pmc WRITE_SIZE";;
     esac
-    timeout 600 rocprofv3 $ARGS -d $RAW/${name}_$pass -o $pass -- $BENCH > $RAW/${name}_$pass.log 2>&1
+    timeout 150 rocprofv3 $ARGS -d $RAW/${name}_$pass -o $pass -- $BENCH > $RAW/${name}_$pass.log 2>&1
     db=$(find $RAW/${name}_$pass -name "*_results.db" | head -1)
     python $ROOT/tools/rocpd_summary.py "$db" | sed "s#$RAW/##" > $OUT/${name}_$pass.txt 2>&1
   done
