@@ -200,14 +200,22 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   auto peek = [&](const int* flag) {  // wave-uniform
     return __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
   };
-  // (every flag is raised within some ten thousand cycles of the launch; a wave that has polled for ~50 ms
-  //  has found a bug, and says so instead of hanging the device)
+  // Every wave raises every flag of its role unconditionally and in order -- no flag depends on data --
+  // and all waves of a workgroup are resident: the waits cannot deadlock.  A build with -DMPPI_POLL_BOUND
+  // (make -C csrc bounded) makes a wave that has polled for ~50 ms trap instead of hanging the device:
+  // for work on this file (a wrong group index in a wait cost 30 GPU-minutes once); measured at 0.35 us
+  // per launch (13.7 vs 13.4), so not the default.
+#ifdef MPPI_POLL_BOUND
   constexpr int kMaxPolls = 1 << 19;
+#endif
   auto wait_for = [&](const int* flag) {
-    int v, polls = 0;
+    int v;
+    [[maybe_unused]] int polls = 0;
     while ((v = peek(flag)) == 0) {
       __builtin_amdgcn_s_sleep(2);
+#ifdef MPPI_POLL_BOUND
       if (++polls > kMaxPolls) __builtin_trap();
+#endif
     }
     return v;
   };
@@ -382,10 +390,12 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     }
     // the control cost of all T steps, also after an early goal break (mppi.py:1007-1009); steps past
     // the horizon hold zero noise: their terms are +0.0
-    for (int polls = 0;
+    for ([[maybe_unused]] int polls = 0;
          !__all(lane >= W || __hip_atomic_load(&cc_done[lane & 15], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0);) {
       __builtin_amdgcn_s_sleep(2);
+#ifdef MPPI_POLL_BOUND
       if (++polls > kMaxPolls) __builtin_trap();
+#endif
     }
     {
       const double* at = ccr + (size_t)r * CHL;
