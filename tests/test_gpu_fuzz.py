@@ -111,7 +111,17 @@ def test_random_configuration_matches_oracle(seed):
     assert (np.abs(planner.u_cur_d.copy_to_host() - u_ref) / scale).max() <= 1e-5, kernel
 
 
-@pytest.mark.parametrize("seed", range(1000, 1048))
+def _patch_seeds():
+    """48 fixed cases; MPPI_FUZZ_PATCH_RANGE="a:b" swaps in other seeds for a soak run."""
+    import os
+    span = os.environ.get("MPPI_FUZZ_PATCH_RANGE")
+    if span:
+        lo, hi = (int(v) for v in span.split(":"))
+        return range(lo, hi)
+    return range(1000, 1048)
+
+
+@pytest.mark.parametrize("seed", _patch_seeds())
 def test_random_configuration_on_patchwise_constant_traction(seed):
     """The speculation of the time-parallel kernels HOLDS on these maps (one traction value, or two in
     large patches: tiles that stay inside a patch keep their assumption, tiles that cross fail their
