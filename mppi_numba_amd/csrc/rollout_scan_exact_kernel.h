@@ -37,7 +37,8 @@
 //   D' first event wins, per-step addends                              -> c_done[g]
 //      last of all: the control-cost products (mppi.py:1007-1009)      -> cc_done[g]
 //                                     cost walk over group g (stage, obstacle, unknown per step)
-//   ... then, by the cost wave: frozen steps, terminal cost, the T control-cost terms
+//   (a rollout stopped in a zero-traction cell keeps paying where it stands: ordinary records)
+//   ... then, by the cost wave: terminal cost, the T control-cost terms
 //   (mppi.py:1005-1009), cost, tile weights; barrier; F: per-tile update sums, lane = step.
 //
 // Workgroup = 3 walkers + ceil(T / 8) chunk waves: T <= 104.  Waves go to the four SIMDs of a CU
@@ -64,7 +65,8 @@ namespace mppi {
 //                         [R] {double stage[4]; float obstacle[4]; float unknown[4]}
 //   p2   [Tp + 1][R] float2 positions (row t = before step t); the float32 headings [Tp + 1][R]
 //                         live in its upper half until the positions overwrite them (see th_sh)
-//   small: control ratios, frozen / terminal data, event words, weights, flags
+//   small: control ratios, terminal data, event words, weights, flags; per (chunk, rollout) what a rollout
+//          that stops in that chunk goes on paying: {double stage cost; uint32 where / how}
 struct ScanExactLds {
   static constexpr int R = 32, CHL = 4, kMaxChunkWaves = 13;
   // the waves a workgroup needs for W groups (walkers: waves 0, 4, 1; chunk waves: kWaveOfGroup below)
@@ -78,26 +80,10 @@ struct ScanExactLds {
   __host__ __device__ static constexpr size_t grp(int W) { return 2 * plane(W); }
   __host__ __device__ static constexpr size_t p2(int W) { return (size_t)(W * 8 + 1) * R * 8; }
   __host__ __device__ static constexpr size_t small(int W) {
-    return (size_t)W * 8 * (16 + 8) + R * 64 + 64 + 8 * (kMaxFoldedRanks + 2) + 7 * 16 * 4;
+    return (size_t)W * 8 * (16 + 8) + R * 64 + 64 + 8 * (kMaxFoldedRanks + 2) + 7 * 16 * 4 + (size_t)2 * W * R * 16;
   }
   __host__ __device__ static constexpr size_t total(int W) { return e2(W) + ccr(W) + grp(W) + p2(W) + small(W); }
 };
-
-// the frozen steps of an exact walk: the closed form of frozen_block when there is no penalty
-// (a tie of the float64 addend exactly between two float32 neighbours would need the running sum's
-// parity: measure zero), step by step with both additions otherwise
-__device__ __forceinline__ float frozen_block_exact(float acc, double k, float pen_o, float pen_u, int count) {
-  if (pen_o != 0.0f || pen_u != 0.0f) {
-    for (; count > 0; --count) {
-      acc = (float)((double)acc + k);
-      acc = acc + pen_o;
-      acc = acc + pen_u;
-    }
-    return acc;
-  }
-  return frozen_block(acc, k, 0.0f, count);
-}
-
 
 template <bool POW2RES, bool GEN>
 __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const uint16_t* __restrict__ cells16,
@@ -156,13 +142,9 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   float* th_sh = reinterpret_cast<float*>(pos) + (size_t)Tp * R;                 // [Tp + 1][R]
   char* small = reinterpret_cast<char*>(pos) + L::p2(W);
   double2* uos = reinterpret_cast<double2*>(small);                              // [Tp] u / std^2
-  double* fz_k = reinterpret_cast<double*>(uos + Tp);                            // [R]
-  double* term_sh = fz_k + R;                                                    // [R]
+  double* term_sh = reinterpret_cast<double*>(uos + Tp);                         // [R]
   uint32_t* evw = reinterpret_cast<uint32_t*>(term_sh + R);                      // [R][2]
-  float* fz_po = reinterpret_cast<float*>(evw + 2 * R);                          // [R]
-  float* fz_pu = fz_po + R;                                                      // [R]
-  int* fz_count = reinterpret_cast<int*>(fz_pu + R);                             // [R]
-  float* wsh = reinterpret_cast<float*>(fz_count + R);                           // [R]
+  float* wsh = reinterpret_cast<float*>(evw + 2 * R);                            // [R]
   uint32_t* flags = reinterpret_cast<uint32_t*>(wsh + R);                        // [0] a failed vote
   // a sharded iteration's update applied here (update_kernels.h, PendingApply): the updated sequence
   double* scale_sh = reinterpret_cast<double*>(small + (size_t)Tp * 16 + R * 64 + 64);  // [kMaxFoldedRanks + 2]
@@ -175,13 +157,13 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   int* ev_done = xy_done + 16;                      // [16] freeze / goal events of the group and of all before it (chunk wave)
   int* c_done = ev_done + 16;                       // [16] records (chunk wave): 1, or 3 = a penalty in the group
   int* cc_done = c_done + 16;                       // [16] control-cost terms (chunk wave)
+  double2* stop_sh = reinterpret_cast<double2*>(cc_done + 16);  // [2W][R] {stage cost of a rollout stopped in this chunk; bits}
   const bool folded = pend.packets != nullptr;
   if (folded && c == 0) pending_apply_prepare(pend, lane, scale_sh);
   if (c == 4) {
     if (lane < R) {
       evw[2 * lane] = 0u;
       evw[2 * lane + 1] = 0u;
-      fz_count[lane] = 0;
       if (lane == 0) flags[0] = 0u;
     }
     for (int i = lane; i < 7 * 16; i += 64) a_done[i] = 0;
@@ -369,8 +351,6 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     MPPI_STAMP(stamp_wg, stamp_base + 1);
     const bool failed = flags[0] != 0u;  // (every chunk wave has published its vote before its c_done)
     if (!failed) {
-      const int cnt = fz_count[r];
-      if (__any(cnt > 0)) cost = frozen_block_exact(cost, fz_k[r], fz_po[r], fz_pu[r], cnt);
       MPPI_STAMP(stamp_wg, stamp_base + 2);
       const bool had_event = (evw[2 * r] | evw[2 * r + 1]) != 0u;
       cost = (float)((double)cost + (had_event ? term_sh[r] : term_plain));
@@ -600,18 +580,23 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
       f_k = fma(Q.dist_weight, sqrt_newton_nz_f64(f_d2), dt64);
       f_hit = f_d2 <= gt2;
     }
-    bool pen = false;
-#pragma unroll
-    for (int j = 0; j < CHL; ++j) pen = pen || (j < nvalid && (po[j] != 0.0f || pu[j] != 0.0f));
-    const bool group_pen = __any(pen);
+    // A rollout that stops in a zero-traction cell goes on paying the stage cost and the penalties of the
+    // place where it stands, step after step (once, if it stands inside the goal circle): what and from
+    // where, for whoever writes the records of the later steps (bits: 0-1 step of the chunk, 2 inside the
+    // goal circle, 3 obstacle, 4 unknown).  Written by every lane that sees a stop, owner of the event or not.
+    if (froze)
+      stop_sh[(size_t)k * R + r] = make_double2(
+          f_k, __longlong_as_double((long long)((uint32_t)s | (f_hit ? 4u : 0u) | (f_po != 0.0f ? 8u : 0u) | (f_pu != 0.0f ? 16u : 0u))));
     // the events of ALL earlier chunks must be in evw when this wave looks: then the first event wins
-    // (a short chain from wave to wave: publish, pass the baton, only then the records)
+    // (a chain from wave to wave that must stay short -- it is the last stage's critical path: publish and
+    //  pass the baton, only then look who owns what)
     if (g > 0) (void)wait_for(&ev_done[g - 1]);
     if (ev != 0u) atomicOr(&evw[2 * r + ((2 * k) >> 5)], ev << ((2 * k) & 31));
     raise(&ev_done[g], 1);
     MPPI_STAMP(stamp_wg && c < 16, stamp_base + 5);
 
-    // ---------------------------------------------------------------- D'
+    // ---------------------------------------------------------------- D': the records of this wave's steps
+    bool group_pen;
     {
       // (the lower half's event of this very wave is in evw: LDS operations of a wave complete in order)
       const uint32_t w0 = evw[2 * r], w1 = evw[2 * r + 1];
@@ -623,22 +608,41 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
         // (1 - reached) * sqrt(d2) / (v_post + 1e-6)   (mppi.py:26-28, 1005): zero after a goal hit, from the
         // frozen position otherwise; a rollout without any event: the cost wave, from the final position
         term_sh[r] = (ev == 2u && !f_hit) ? sqrt(f_d2) / Q.v_post_den : 0.0;
-        if (ev == 2u) {
-          fz_k[r] = f_k;
-          fz_po[r] = f_po;
-          fz_pu[r] = f_pu;
-          fz_count[r] = f_hit ? 1 : T - (t0 + s);
-        }
       }
       if (__any(!dead && bad) && lane == 0) atomicOr(&flags[0], 1u);
+      // the first event of the rollout, here or earlier: a stop?
+      const int first = word != 0ull ? (__builtin_ctzll(word) >> 1) : 0;
+      const bool stopped = word != 0ull && ((word >> (2 * first)) & 3ull) == 2ull;
+      double fk = 0.0;
+      float fo = 0.0f, fu = 0.0f;
+      int f_begin = 0, f_end = 0;
+      if (__any(stopped)) {
+        const double2 sl = stop_sh[(size_t)(stopped ? first : k) * R + r];  // (written before that chunk's event was published)
+        const uint32_t bits = (uint32_t)__double_as_longlong(sl.y);
+        fk = sl.x;
+        fo = (bits & 8u) ? Q.obs_cost : 0.0f;
+        fu = (bits & 16u) ? Q.unk_cost : 0.0f;
+        f_begin = stopped ? first * CHL + (int)(bits & 3u) : 0;
+        f_end = stopped ? ((bits & 4u) ? f_begin + 1 : T) : 0;
+      }
+      bool pen = false;
+#pragma unroll
+      for (int j = 0; j < CHL; ++j) {
+        const bool own = j < n_act, standing = t0 + j >= f_begin && t0 + j < f_end;
+        sg[j] = own ? sg[j] : (standing ? fk : 0.0);
+        po[j] = own ? po[j] : (standing ? fo : 0.0f);
+        pu[j] = own ? pu[j] : (standing ? fu : 0.0f);
+        pen = pen || po[j] != 0.0f || pu[j] != 0.0f;
+      }
+      group_pen = __any(pen);
       // the group's records over its (consumed) position increments
       char* out = grp + (size_t)g * 4096 + (size_t)h * 2048 + (size_t)r * 64;
       double2* o2 = reinterpret_cast<double2*>(out);
-      o2[0] = make_double2(0 < n_act ? sg[0] : 0.0, 1 < n_act ? sg[1] : 0.0);
-      o2[1] = make_double2(2 < n_act ? sg[2] : 0.0, 3 < n_act ? sg[3] : 0.0);
+      o2[0] = make_double2(sg[0], sg[1]);
+      o2[1] = make_double2(sg[2], sg[3]);
       float4* o4 = reinterpret_cast<float4*>(out + CHL * 8);
-      o4[0] = make_float4(0 < n_act ? po[0] : 0.0f, 1 < n_act ? po[1] : 0.0f, 2 < n_act ? po[2] : 0.0f, 3 < n_act ? po[3] : 0.0f);
-      o4[1] = make_float4(0 < n_act ? pu[0] : 0.0f, 1 < n_act ? pu[1] : 0.0f, 2 < n_act ? pu[2] : 0.0f, 3 < n_act ? pu[3] : 0.0f);
+      o4[0] = make_float4(po[0], po[1], po[2], po[3]);
+      o4[1] = make_float4(pu[0], pu[1], pu[2], pu[3]);
     }
     raise(&c_done[g], group_pen ? 3 : 1);
     MPPI_STAMP(stamp_wg && c < 16, stamp_base + 6);
