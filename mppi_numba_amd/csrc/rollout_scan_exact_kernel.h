@@ -25,14 +25,16 @@
 //
 // The walks follow each other down the horizon, one group of 8 steps apart, and the chunk waves work
 // between them -- no workgroup barrier between entry and the update sums, only flags in LDS
-// (release store by the producer, acquire poll by the consumer):
+// (a plain store by the producer after its data -- the LDS executes a wave's instructions in order --,
+// an acquire poll by the consumer):
 //
 //   chunk wave g                      walker
 //   A  noise (GEN: Philox; else read), clipped controls, dt*w          -> a_done[g]
 //                                     theta walk over group g          -> th_done[g]
 //   B  sin / cos of the 8 headings, (dt*v)*cos, (dt*v)*sin             -> b_done[g]
 //                                     x | y walk over group g          -> xy_done[g]
-//   C  lookups, goal distances, sqrt, stage costs; freeze / goal events, the vote
+//   C  lookups, goal distances, sqrt, stage costs; freeze / goal events, the vote; what a rollout that
+//      stops here goes on paying -> its (chunk, rollout) slot
 //      (after ev_done[g-1]: all earlier events are known)              -> ev_done[g]
 //   D' first event wins, per-step addends                              -> c_done[g]
 //      last of all: the control-cost products (mppi.py:1007-1009)      -> cc_done[g]
@@ -69,7 +71,7 @@ namespace mppi {
 //          that stops in that chunk goes on paying: {double stage cost; uint32 where / how}
 struct ScanExactLds {
   static constexpr int R = 32, CHL = 4, kMaxChunkWaves = 13;
-  // the waves a workgroup needs for W groups (walkers: waves 0, 4, 1; chunk waves: kWaveOfGroup below)
+  // the waves a workgroup needs for W groups (walkers: waves 0, 4, 1; chunk waves: kGroupOfWave in the kernel)
   __host__ __device__ static constexpr int waves(int W) {
     constexpr int need[kMaxChunkWaves] = {6, 6, 6, 10, 10, 10, 14, 14, 14, 15, 16, 16, 16};  // 1 + the highest wave among groups 0 .. W-1 and the walkers
     return need[W - 1];
