@@ -69,6 +69,10 @@ namespace mppi {
 //                         live in its upper half until the positions overwrite them (see th_sh)
 //   small: control ratios, terminal data, event words, weights, flags; per (chunk, rollout) what a rollout
 //          that stops in that chunk goes on paying: {double stage cost; uint32 where / how}
+// s_sleep argument of the flag polls (units of 64 cycles)
+#ifndef MPPI_SCAN_POLL_SLEEP
+#define MPPI_SCAN_POLL_SLEEP 2
+#endif
 struct ScanExactLds {
   static constexpr int R = 32, CHL = 4, kMaxChunkWaves = 13;
   // the waves a workgroup needs for W groups (walkers: waves 0, 4, 1; chunk waves: kGroupOfWave in the kernel)
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     int v;
     [[maybe_unused]] int polls = 0;
     while ((v = peek(flag)) == 0) {
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(MPPI_SCAN_POLL_SLEEP);
 #ifdef MPPI_POLL_BOUND
       if (++polls > kMaxPolls) __builtin_trap();
 #endif
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     // the horizon hold zero noise: their terms are +0.0
     for ([[maybe_unused]] int polls = 0;
          !__all(lane >= W || __hip_atomic_load(&cc_done[lane & 15], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0);) {
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(MPPI_SCAN_POLL_SLEEP);
 #ifdef MPPI_POLL_BOUND
       if (++polls > kMaxPolls) __builtin_trap();
 #endif
