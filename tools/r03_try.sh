@@ -1,5 +1,6 @@
 #!/bin/bash
 # a change to the time-parallel exact kernel, tried safely: the tests on the build whose waits trap, then the bench lines
+# (build both libraries BEFORE sending: make -C mppi_numba_amd/csrc all bounded -- built .so files travel with the snapshot)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 cd $ROOT
