@@ -88,12 +88,14 @@ struct mppi_planner {
   uint64_t bumps_launched = 0;            // host mirror of *gen_dev once the stream has drained
   bool primed = false;                    // noise_buf[noise_cur ^ 1] already holds the NEXT iteration's noise
   bool graph_warm = false;                // one direct iteration has run since graph mode was enabled
-  // one cached graph per parity of the noise double buffer (a call with an odd number of
-  // iterations leaves the other parity behind)
-  hipGraph_t graph[2] = {nullptr, nullptr};
-  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
-  std::vector<unsigned char> graph_sig[2];  // everything the captured launches took by value
-  uint64_t graph_spec_tiles[2] = {0, 0};    // speculative tiles one replay of the graph launches
+  // one cached graph per parity of the noise double buffer and of the two control buffers of a sharded
+  // handle (a call with an odd number of iterations leaves the other parity behind)
+  static constexpr int kGraphSlots = 4;
+  hipGraph_t graph[kGraphSlots] = {nullptr, nullptr, nullptr, nullptr};
+  hipGraphExec_t graph_exec[kGraphSlots] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<unsigned char> graph_sig[kGraphSlots];  // everything the captured launches took by value
+  uint64_t graph_spec_tiles[kGraphSlots] = {0, 0, 0, 0};  // speculative tiles one replay of the graph launches
+  int u_parity = 0;                         // flips whenever u and u_alt change places
   long graph_replays = 0, graph_captures = 0;
   std::string last_rollout;        // which rollout kernel variant the last launch used (diagnostic)
   int debug_flags = 0;             // mppi_planner_set_debug_flags (tests pin every kernel variant through it)
@@ -198,7 +200,7 @@ struct mppi_planner {
 };
 
 static void drop_graphs(mppi_planner* p) {
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < mppi_planner::kGraphSlots; ++i) {
     if (p->graph_exec[i]) (void)hipGraphExecDestroy(p->graph_exec[i]);
     if (p->graph[i]) (void)hipGraphDestroy(p->graph[i]);
     p->graph_exec[i] = nullptr;

@@ -498,6 +498,7 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
   const bool applied_here = p->apply_pending;
   if (applied_here) {  // the first tile's workgroup has written the updated sequence into the other buffer
     std::swap(p->u, p->u_alt);
+    p->u_parity ^= 1;
     p->apply_pending = false;
     ++p->folded_applies;
   }
@@ -1163,6 +1164,7 @@ static int launch_apply(mppi_planner* p) {
                      a.vrange[1], a.wrange[0], a.wrange[1], p->stats);
   HIP_TRY(hipGetLastError());
   std::swap(p->u, p->u_alt);
+  p->u_parity ^= 1;
   p->apply_pending = false;
   return MPPI_OK;
 }
@@ -1386,7 +1388,7 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
       std::vector<unsigned char> sig;
       graph_signature(p, d, lin, ang, sig);
       sig.push_back(have_noise ? 1 : 0);
-      const int slot = p->noise_cur & 1;
+      const int slot = (p->noise_cur & 1) | ((p->u_parity & 1) << 1);
       if (!p->graph_exec[slot] || sig != p->graph_sig[slot]) {
         if (p->graph_exec[slot]) { (void)hipGraphExecDestroy(p->graph_exec[slot]); p->graph_exec[slot] = nullptr; }
         if (p->graph[slot]) { (void)hipGraphDestroy(p->graph[slot]); p->graph[slot] = nullptr; }

@@ -343,3 +343,25 @@ def test_loop_with_a_communicator_leaves_the_update_to_the_next_rollout(math):
     print("\n%s: us per iteration -- unsharded %.2f, 1-rank communicator with the update left to the rollout %.2f, "
           "with k_apply %.2f" % (math, times["local"], times["folded"], times["k_apply"]))
     assert times["folded"] <= times["k_apply"] + 0.5
+
+
+def test_graphs_of_a_sharded_handle_survive_odd_call_lengths():
+    """Every sharded iteration flips the handle's two control buffers; a call with an odd number of
+    iterations leaves the other one current.  One cached graph per parity (of the noise double buffer
+    and of the control buffers): calls of odd length alternate between cached graphs, they do not
+    re-capture every time."""
+    from mppi_numba_amd.mppi import comm_unique_id
+    _, _, _, _, direct, _ = build("c2", 2048)
+    _, _, _, _, graph, _ = build("c2", 2048)
+    for planner in (direct, graph):
+        planner.comm_init(comm_unique_id())
+    graph.set_graph_replay(True, 2)
+    for planner in (direct, graph):
+        planner.solve()
+    for _ in range(8):
+        for planner in (direct, graph):
+            planner.iterate_async(3)
+            planner.synchronize()
+        assert np.array_equal(direct.u_cur_d.copy_to_host(), graph.u_cur_d.copy_to_host())
+    stats = graph.graph_stats()
+    assert stats["replays"] >= 7 and stats["captures"] <= 4, stats
