@@ -298,6 +298,7 @@ int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity)
 #define MPPI_DEBUG_SCAN_READ_NOISE 64    /* the iteration loop stores its noise and the kernel reads it (as the stage-level calls do) */
 #define MPPI_DEBUG_SCAN_FULL_TILES 128   /* workgroups of 64 rollouts (one lane per rollout) instead of 32 (two) */
 #define MPPI_DEBUG_NO_FOLDED_APPLY 256   /* sharded handle: every iteration's update by its own k_apply launch, never by the next rollout launch */
+#define MPPI_DEBUG_NO_REDUCE_FOLD 512    /* one GPU: every iteration's update by its own k_combine_tiles launch, never reduced and applied by the next rollout launch */
 int mppi_planner_set_debug_flags(mppi_planner* p, int flags);
 int mppi_selftest_philox(int device, int* mismatches);
 /* developer instrumentation: in-kernel clock stamps of a -DMPPI_STAMPS build

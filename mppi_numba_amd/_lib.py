@@ -23,6 +23,7 @@ DEBUG_KEEP_SPECULATING = 16
 # MPPI_MATH_FAST, the time-parallel rollout kernel (include/mppi_hip.h)
 DEBUG_NO_SCAN_KERNEL, DEBUG_SCAN_READ_NOISE, DEBUG_SCAN_FULL_TILES = 32, 64, 128
 DEBUG_NO_FOLDED_APPLY = 256
+DEBUG_NO_REDUCE_FOLD = 512
 ABI_VERSION = 1
 
 

@@ -90,11 +90,13 @@ struct mppi_planner {
   bool graph_warm = false;                // one direct iteration has run since graph mode was enabled
   // one cached graph per parity of the noise double buffer and of the two control buffers of a sharded
   // handle (a call with an odd number of iterations leaves the other parity behind)
-  static constexpr int kGraphSlots = 4;
-  hipGraph_t graph[kGraphSlots] = {nullptr, nullptr, nullptr, nullptr};
-  hipGraphExec_t graph_exec[kGraphSlots] = {nullptr, nullptr, nullptr, nullptr};
+  // (... and of the two tile packet buffers of the time-parallel kernels)
+  static constexpr int kGraphSlots = 8;
+  hipGraph_t graph[kGraphSlots] = {};
+  hipGraphExec_t graph_exec[kGraphSlots] = {};
   std::vector<unsigned char> graph_sig[kGraphSlots];  // everything the captured launches took by value
-  uint64_t graph_spec_tiles[kGraphSlots] = {0, 0, 0, 0};  // speculative tiles one replay of the graph launches
+  uint64_t graph_spec_tiles[kGraphSlots] = {};  // speculative tiles one replay of the graph launches
+  int graph_u_flip[kGraphSlots] = {}, graph_tpk_flip[kGraphSlots] = {};  // buffer parities one replay changes
   int u_parity = 0;                         // flips whenever u and u_alt change places
   long graph_replays = 0, graph_captures = 0;
   std::string last_rollout;        // which rollout kernel variant the last launch used (diagnostic)
@@ -115,12 +117,20 @@ struct mppi_planner {
   int n_tiles = 0;
   bool tile_packets_fresh = false;  // w_rel / tile_beta written by the rollout kernel for the current costs
   bool theta_bounded = false;  // |heading| < 5e4 rad over the horizon (decided per launch: launch_rollout)
-  // k_rollout_scan (MPPI_MATH_FAST): per-tile sums of w_rel * noise, consumed by k_combine_tiles
-  float2* tnum = nullptr;  // [T][tiles]
-  float* tden = nullptr;   // [tiles]
-  float* tbeta = nullptr;  // [tiles] minimum cost of each of the kernel's tiles (32 or 64 rollouts)
+  // The time-parallel kernels (rollout_scan*.h) leave one packet per tile of 32 (64) rollouts -- minimum cost,
+  // sum of w_rel, sum of w_rel * noise(t) -- consumed by k_combine_tiles or, inside an iteration loop on one GPU,
+  // by the class reduction of the NEXT rollout launch (update_kernels.h, PendingApply::reduce_tiles): two buffers,
+  // a launch reads its predecessor's while it writes its own.  Allocated with the handle (a lazy hipMalloc could
+  // fall inside a stream capture).
+  float* tile_packets[2] = {nullptr, nullptr};  // [ceil(n_local / 32)][tile_packet_floats(T)]
+  int tpk_cur = 0;         // the buffer the last such launch wrote
   int scan_tile = 32;      // rollouts per tile of the last such launch
   bool scan_packets_fresh = false;  // ... written by the last rollout launch for the current costs
+  unsigned long long* published = nullptr;  // [2][T][kPublishedStride] words {float u; uint32 flag}; all zero between loops (k_combine_tiles)
+  bool reduce_pending = false;  // the last launch's tile packets hold an update that the next rollout launch applies
+  int reduce_index = 0;         // such launches since the loop began: picks the flag set
+  uint64_t reduced_applies = 0;
+  uint64_t bumps_owed = 0;      // graph replay: iterations whose update kernel (and its epoch bump) did not run
   // the iteration loop of such a handle generates the noise INSIDE the rollout launch (Philox counter
   // blocks, never stored): noise_buf is then stale, and whoever wants the noise of the last iteration
   // (get_noise, get_state_rollout, a stage-level update) has it regenerated from the same counters
@@ -177,6 +187,7 @@ struct mppi_planner {
   // iterations it runs (4 events per iteration), picked up by MPPI_KLAUNCH
   hipEvent_t kev_start = nullptr, kev_stop = nullptr;
   std::vector<hipEvent_t> ktime_events;
+  std::vector<char> ktime_update_ran;  // per timed iteration: its update was a launch of its own
   int ktime_index = -1;
   // comm
   ncclComm_t comm = nullptr;

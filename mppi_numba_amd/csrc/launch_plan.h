@@ -410,20 +410,17 @@ static int materialize_noise(mppi_planner* p) {
   return MPPI_OK;
 }
 
+// One GPU: whether a rollout launch over `tiles` workgroups can combine its predecessor's tile packets itself
+// (update_kernels.h, PendingApply::reduce_tiles): step t in workgroup t, at most two steps per idle walker wave.
+static bool tiles_can_reduce(int tiles, int n_steps) { return 4 * tiles >= n_steps; }
+
 static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan) {
   const int N = p->n_local, T = p->cfg.num_steps;
   const int tiles = ceil_div(N, plan.tile);
-  if (!p->tnum) {  // (sized for the smaller tile)
-    const size_t cap = (size_t)ceil_div(N, 32);
-    TRY(dev_alloc(&p->tnum, (size_t)T * cap));
-    TRY(dev_alloc(&p->tden, cap));
-    TRY(dev_alloc(&p->tbeta, cap));
-  }
+  REQUIRE(p->tile_packets[0] && p->tile_packets[1], MPPI_ERR_STATE, "internal: no tile packet buffers on this handle");
   const bool gen = p->scan_gen_now;
   ScanPackets pk;
-  pk.tnum = p->tnum;
-  pk.tden = p->tden;
-  pk.tbeta = p->tbeta;
+  pk.tiles = p->tile_packets[p->tpk_cur ^ 1];  // (the other one may be read by this very launch: reduce_pending)
   pk.n_tiles = tiles;
   NoiseJob gen_job, next_job;
   memset(&gen_job, 0, sizeof(gen_job));
@@ -446,7 +443,7 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
   // a sharded iteration whose update has not been applied yet: this launch does it (PendingApply)
   PendingApply pend;
   memset(&pend, 0, sizeof(pend));
-  if (p->apply_pending) {
+  if (p->apply_pending || p->reduce_pending) {
     const mppi_params& a = p->params;
     pend.packets = p->packets;
     pend.u_out = p->u_alt;
@@ -457,6 +454,17 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
     pend.lambda = a.lambda_weight;
     pend.v_lo = a.vrange[0]; pend.v_hi = a.vrange[1];
     pend.w_lo = a.wrange[0]; pend.w_hi = a.wrange[1];
+  }
+  if (p->reduce_pending) {
+    // one GPU: the previous launch's tile packets, reduced and applied by this launch (no update kernel ran)
+    REQUIRE(plan.exact && !p->apply_pending, MPPI_ERR_STATE, "internal: tile packets left to a launch that cannot reduce them");
+    REQUIRE(tiles_can_reduce(tiles, T) && plan.tile == p->scan_tile, MPPI_ERR_STATE, "internal: %d workgroups cannot combine the tile packets of %d steps", tiles, T);
+    pend.packets = p->packets;  // (not read in this mode; non-null: "an update is pending")
+    pend.world = 1;
+    pend.reduce_tiles = p->tile_packets[p->tpk_cur];
+    pend.reduce_n_tiles = ceil_div(N, p->scan_tile);
+    pend.published = p->published;
+    pend.flag_set = p->reduce_index & 1;
   }
   p->spec_tiles_launched += (uint64_t)tiles;
 #define MPPI_LAUNCH_SCAN_EXACT(P2, GEN)                                                                    \
@@ -495,18 +503,24 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
 #undef MPPI_LAUNCH_SCAN
 #undef MPPI_LAUNCH_SCAN_EXACT
   HIP_TRY(hipGetLastError());
-  const bool applied_here = p->apply_pending;
+  const bool applied_here = p->apply_pending || p->reduce_pending;
   if (applied_here) {  // the first tile's workgroup has written the updated sequence into the other buffer
     std::swap(p->u, p->u_alt);
     p->u_parity ^= 1;
-    p->apply_pending = false;
-    ++p->folded_applies;
+    if (p->reduce_pending) {
+      ++p->reduce_index;
+      ++p->reduced_applies;
+    } else {
+      ++p->folded_applies;
+    }
+    p->apply_pending = p->reduce_pending = false;
   }
+  p->tpk_cur ^= 1;
   char buf[256];
   snprintf(buf, sizeof(buf),
            "k_rollout_scan%s tile=%d waves=%d pow2res=%d noise=%s lds=%zu noise_blocks=%d problems=%d%s",
            plan.exact ? "_exact" : "", plan.tile, plan.waves, (int)plan.pow2res, gen ? "in-kernel" : "read", plan.lds, extra,
-           p->inst_set ? p->B : 0, applied_here ? " applies_update=1" : "");
+           p->inst_set ? p->B : 0, applied_here ? (pend.reduce_tiles ? " applies_update=1 reduces_tiles=1" : " applies_update=1") : "");
   p->last_rollout = buf;
   p->tile_packets_fresh = false;  // (w_rel is relative to this kernel's own tiles: tbeta, not tile_beta)
   p->scan_packets_fresh = true;
@@ -1034,6 +1048,8 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
 
 
 static int launch_apply(mppi_planner* p);
+static bool next_rollout_reduces_tiles(const mppi_planner* p);
+static int settle_reduce_pending(mppi_planner* p);
 
 static int launch_rollout(mppi_planner* p, const DevParams& d) {
   REQUIRE(p->B == 1 || p->inst_set, MPPI_ERR_STATE,
@@ -1042,6 +1058,7 @@ static int launch_rollout(mppi_planner* p, const DevParams& d) {
           p->cfg.num_steps);
   // an update left to its consumer (launch_update) and a rollout kernel that will not take it
   if (p->apply_pending && !(p->cfg.mode == MPPI_MODE_DET && scan_plan(p, nullptr))) TRY(launch_apply(p));
+  if (p->reduce_pending && !next_rollout_reduces_tiles(p)) TRY(settle_reduce_pending(p));
   // |theta| can never exceed |theta0| + T*dt*max|w|*max(traction): when that is far
   // inside the range of the two-term pi/2 reduction, the kernels drop the libm branch
   const mppi_params& a = p->params;
@@ -1107,16 +1124,21 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
     p->tile_packets_fresh = false;
     const dim3 grid(T, p->B);
     unsigned long long* gen = p->graph_on ? p->gen_dev : (unsigned long long*)nullptr;
-    const int per_problem = ceil_div(p->n_inst, p->scan_tile), total = ceil_div(p->n_local, p->scan_tile);
+    const int per_problem = ceil_div(p->n_inst, p->scan_tile);
+    // (graph replay: this launch also accounts for the iterations whose update ran inside a rollout launch)
+    const unsigned long long bump = 1ull + (unsigned long long)p->bumps_owed;
+    const float* tiles = p->tile_packets[p->tpk_cur];
     if (apply_here)
-      MPPI_KLAUNCH((k_combine_tiles<true>), grid, dim3(64), 0, p->stream, p->tbeta, p->tden, p->tnum, per_problem, total,
+      MPPI_KLAUNCH((k_combine_tiles<true>), grid, dim3(64), 0, p->stream, tiles, per_problem,
                    T, a.lambda_weight, my_packet, p->u, p->u_prev, (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0], a.vrange[1],
-                   a.wrange[0], a.wrange[1], p->stats, gen);
+                   a.wrange[0], a.wrange[1], p->stats, gen, bump, p->published);
     else
-      MPPI_KLAUNCH((k_combine_tiles<false>), grid, dim3(64), 0, p->stream, p->tbeta, p->tden, p->tnum, per_problem, total,
+      MPPI_KLAUNCH((k_combine_tiles<false>), grid, dim3(64), 0, p->stream, tiles, per_problem,
                    T, a.lambda_weight, my_packet, p->u, p->u_prev, (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0], a.vrange[1],
-                   a.wrange[0], a.wrange[1], p->stats, gen);
-    if (p->graph_on) ++p->bumps_launched;
+                   a.wrange[0], a.wrange[1], p->stats, gen, bump, p->published);
+    if (p->graph_on) p->bumps_launched += bump;
+    p->bumps_owed = 0;
+    p->reduce_index = 0;  // (the flags are all clear again)
     HIP_TRY(hipGetLastError());
     return MPPI_OK;
   }
@@ -1176,6 +1198,24 @@ static bool next_rollout_applies_updates(const mppi_planner* p) {
          p->cfg.world_size <= kMaxFoldedRanks && p->cfg.mode == MPPI_MODE_DET && !p->mirror_now && scan_plan(p, nullptr);
 }
 
+// One GPU: whether the NEXT rollout launch can reduce and apply the tile packets of this one (no update kernel).
+static bool next_rollout_reduces_tiles(const mppi_planner* p) {
+  static const bool disabled = getenv("MPPI_NO_REDUCE_FOLD") != nullptr;  // developer switch (ablation)
+  ScanPlan plan;
+  return !disabled && !(p->debug_flags & (MPPI_DEBUG_NO_FOLDED_APPLY | MPPI_DEBUG_NO_REDUCE_FOLD)) && p->B == 1 && !p->inst_set &&
+         p->m_count == 1 && p->cfg.world_size == 1 && !p->comm && p->cfg.mode == MPPI_MODE_DET && !p->mirror_now &&
+         scan_plan(p, &plan) && plan.exact && plan.tile == p->scan_tile &&
+         tiles_can_reduce(ceil_div(p->n_local, plan.tile), p->cfg.num_steps);
+}
+
+// tile packets left to a rollout launch that will not come (another kernel family, a stage-level call): the
+// ordinary combination
+static int settle_reduce_pending(mppi_planner* p) {
+  p->reduce_pending = false;
+  p->scan_packets_fresh = true;
+  return launch_update_local(p, true);
+}
+
 // `defer_exchange` (mppi_group_iterate_async): stop after this rank's packet; the caller issues the
 // all-gathers of all its devices inside one RCCL group and then launches k_apply on each
 // `may_leave_apply`: another iteration follows on this stream: the update may be left to its rollout launch
@@ -1185,6 +1225,13 @@ static int launch_update(mppi_planner* p, bool prof, bool defer_exchange = false
   // (a communicator on a single rank is honoured too: it exercises the same path as N ranks)
   // (samples sharded: every rank holds all N costs and all the noise -- the update is local)
   if ((p->cfg.world_size == 1 && !p->comm) || p->m_count > 1) {
+    if (may_leave_apply && !prof && p->scan_packets_fresh && next_rollout_reduces_tiles(p)) {
+      // the next rollout launch reduces this one's tile packets and applies the update itself: no launch here
+      p->scan_packets_fresh = false;
+      p->reduce_pending = true;
+      if (p->graph_on) ++p->bumps_owed;
+      return MPPI_OK;
+    }
     TRY(launch_update_local(p, true));
     if (prof) {
       HIP_TRY(hipEventRecord(p->ev_stage[3], p->stream));
@@ -1278,6 +1325,7 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
   p->scan_gen_now = false;
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[2], p->stream));
   TraceRange tr_update("mppi:update");
+  const int ktime_slot = p->ktime_index;
   if (p->ktime_index >= 0) {
     p->kev_start = p->ktime_events[4 * (size_t)p->ktime_index + 2];
     p->kev_stop = p->ktime_events[4 * (size_t)p->ktime_index + 3];
@@ -1287,6 +1335,8 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
     const int rc = launch_update(p, prof, defer_exchange, may_leave_apply);
     p->kev_start = p->kev_stop = nullptr;
     TRY(rc);
+    // (an update left to the next rollout launch has no launch of its own to time)
+    if (ktime_slot >= 0 && (size_t)ktime_slot < p->ktime_update_ran.size()) p->ktime_update_ran[(size_t)ktime_slot] = !p->reduce_pending;
   }
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[5], p->stream));
   return MPPI_OK;
@@ -1388,13 +1438,14 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
       std::vector<unsigned char> sig;
       graph_signature(p, d, lin, ang, sig);
       sig.push_back(have_noise ? 1 : 0);
-      const int slot = (p->noise_cur & 1) | ((p->u_parity & 1) << 1);
+      const int slot = (p->noise_cur & 1) | ((p->u_parity & 1) << 1) | ((p->tpk_cur & 1) << 2);
       if (!p->graph_exec[slot] || sig != p->graph_sig[slot]) {
         if (p->graph_exec[slot]) { (void)hipGraphExecDestroy(p->graph_exec[slot]); p->graph_exec[slot] = nullptr; }
         if (p->graph[slot]) { (void)hipGraphDestroy(p->graph[slot]); p->graph[slot] = nullptr; }
         p->graph_sig[slot].clear();
         const bool primed_before = have_noise;
         const uint64_t spec_before = p->spec_tiles_launched;
+        const int u_parity_before = p->u_parity, tpk_before = p->tpk_cur;
         HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
         int rc = MPPI_OK;
         // (the last iteration of a graph applies its update itself: a graph starts and ends with nothing pending)
@@ -1407,6 +1458,10 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
         HIP_TRY(hipGraphInstantiate(&p->graph_exec[slot], p->graph[slot], nullptr, nullptr, 0));
         p->graph_sig[slot] = sig;
         p->graph_spec_tiles[slot] = p->spec_tiles_launched - spec_before;
+        // (one GPU, updates applied inside rollout launches: all but the last iteration of the graph change control
+        //  buffers -- an odd number when the graph holds an even number of iterations)
+        p->graph_u_flip[slot] = (p->u_parity ^ u_parity_before) & 1;
+        p->graph_tpk_flip[slot] = (p->tpk_cur ^ tpk_before) & 1;
         ++p->graph_captures;
         // (capturing ran the host side of two iterations; the launch below runs their device side)
       } else {
@@ -1415,6 +1470,11 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
         p->bumps_launched += (uint64_t)chunk;
         // (the replayed kernels count their failed tiles like the captured ones did)
         p->spec_tiles_launched += p->graph_spec_tiles[slot];
+        if (p->graph_u_flip[slot]) {
+          std::swap(p->u, p->u_alt);
+          p->u_parity ^= 1;
+        }
+        p->tpk_cur ^= p->graph_tpk_flip[slot];
       }
       HIP_TRY(hipGraphLaunch(p->graph_exec[slot], p->stream));
       ++p->graph_replays;

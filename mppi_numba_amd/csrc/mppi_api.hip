@@ -475,9 +475,9 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   dev_free(p->weights_out);
   dev_free(p->w_rel);
   dev_free(p->tile_beta);
-  dev_free(p->tnum);
-  dev_free(p->tden);
-  dev_free(p->tbeta);
+  dev_free(p->tile_packets[0]);
+  dev_free(p->tile_packets[1]);
+  dev_free(p->published);
   dev_free(p->packets);
   dev_free(p->stats);
   dev_free(p->cells);
@@ -556,6 +556,15 @@ static int planner_alloc(mppi_planner* p) {
   TRY(dev_alloc(&p->w_rel, N));
   TRY(dev_alloc(&p->tile_beta, (size_t)p->n_tiles));
   TRY(dev_alloc(&p->packets, (size_t)c.world_size * B * packet_len((int)T)));
+  if (c.mode == MPPI_MODE_DET) {  // the time-parallel kernels' tile packets (handles.h)
+    const size_t tiles = (size_t)ceil_div((long)N, 32);
+    for (int b = 0; b < 2; ++b) {
+      TRY(dev_alloc(&p->tile_packets[b], tiles * (size_t)tile_packet_floats((int)T)));
+      HIP_TRY(hipMemsetAsync(p->tile_packets[b], 0, tiles * (size_t)tile_packet_floats((int)T) * sizeof(float), p->stream));
+    }
+    TRY(dev_alloc(&p->published, published_words((int)T)));
+    HIP_TRY(hipMemsetAsync(p->published, 0, sizeof(unsigned long long) * published_words((int)T), p->stream));
+  }
   TRY(dev_alloc(&p->stats, 2 * B));
   TRY(dev_alloc(&p->state_rollout, (size_t)c.num_vis_state_rollouts * (T + 1) * 3));
   HIP_TRY(hipMemsetAsync(p->u, 0, B * T * sizeof(float2), p->stream));  // u_seq0 = zeros (mppi.py:93)
@@ -1334,6 +1343,7 @@ extern "C" int mppi_planner_time_kernels(mppi_planner* p, mppi_tdm* lin, mppi_td
     p->ktime_events.push_back(e);
   }
   TRY(run_iterations(p, lin, ang, 2, /*timed=*/false));  // steady state first
+  p->ktime_update_ran.assign((size_t)reps, 1);
   p->ktime_index = 0;
   const int rc = run_iterations(p, lin, ang, reps, /*timed=*/false);
   p->ktime_index = -1;
@@ -1344,6 +1354,7 @@ extern "C" int mppi_planner_time_kernels(mppi_planner* p, mppi_tdm* lin, mppi_td
   for (int r = 0; r < reps; ++r)
     for (int k = 0; k < 2; ++k) {
       float ms = 0.f;
+      if (k == 1 && !p->ktime_update_ran[(size_t)r]) continue;  // (applied inside the next rollout launch: counted there)
       HIP_TRY(hipEventElapsedTime(&ms, p->ktime_events[4 * (size_t)r + 2 * k], p->ktime_events[4 * (size_t)r + 2 * k + 1]));
       sum[k] += (double)ms;
     }
@@ -1449,6 +1460,7 @@ extern "C" int mppi_planner_set_debug_flags(mppi_planner* p, int flags) {
   REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
   p->debug_flags = flags;
   drop_graphs(p);  // (a captured graph holds the kernels chosen under the old flags)
+  p->graph_warm = false;  // (another kernel family may run next: its host-side effects happen in a direct iteration)
   return MPPI_OK;
 }
 

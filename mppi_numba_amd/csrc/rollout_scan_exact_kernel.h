@@ -86,7 +86,7 @@ struct ScanExactLds {
   __host__ __device__ static constexpr size_t grp(int W) { return 2 * plane(W); }
   __host__ __device__ static constexpr size_t p2(int W) { return (size_t)(W * 8 + 1) * R * 8; }
   __host__ __device__ static constexpr size_t small(int W) {
-    return (size_t)W * 8 * (16 + 8) + R * 64 + 64 + 8 * (kMaxFoldedRanks + 2) + 7 * 16 * 4 + (size_t)2 * W * R * 16;
+    return (size_t)W * 8 * (16 + 8) + R * 64 + 64 + 8 * (kMaxFoldedRanks + 2) + 8 * 16 * 4 + (size_t)2 * W * R * 16;
   }
   __host__ __device__ static constexpr size_t total(int W) { return e2(W) + ccr(W) + grp(W) + p2(W) + small(W); }
 };
@@ -123,8 +123,8 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   }
   g = g < W ? g : -1;
   const int k = 2 * g + h;  // this lane's chunk of 4 steps
-  [[maybe_unused]] const bool stamp_wg = blockIdx.x == 5;
-  [[maybe_unused]] const int stamp_base = 64 + 16 * c;
+  [[maybe_unused]] const bool stamp_wg = blockIdx.x == 5 || blockIdx.x == 200;  // (a workgroup that combines a step of a folded update, one that does not)
+  [[maybe_unused]] const int stamp_base = (blockIdx.x == 200 ? 1024 : 64) + 16 * c;
   MPPI_STAMP(stamp_wg && c < 16, stamp_base + 0);
   DevParams Q = P;
   const int tile = blockIdx.x;
@@ -135,6 +135,20 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   const bool live = n < N;
   const int t0 = k * CHL;
   const int nvalid = min(max(T - t0, 0), CHL);
+  // One GPU, an update left to this launch (update_kernels.h, PendingApply::reduce_tiles): step tt of it is combined
+  // by workgroup tt -- by its theta walker; with fewer workgroups than steps the x | y walkers take the next
+  // gridDim.x steps, and so on round.  The tile packets of this wave's first step are requested before anything
+  // else: they come from the other XCDs' writes of the previous launch, a trip of ~1.5 us.
+  const bool folded = pend.packets != nullptr;
+  const bool reducing = folded && pend.reduce_tiles != nullptr;
+  const int red_t = tile + max(walker, 0) * (int)gridDim.x;
+  const bool reduce_here = reducing && (walker == 0 || walker == 1) && red_t < T;
+  StepLoads red_loads;
+  float2 red_u = make_float2(0.0f, 0.0f);
+  if (reduce_here) {
+    red_loads = combine_step_issue(pend.reduce_tiles, pend.reduce_n_tiles, tile_packet_floats(T), red_t, lane);
+    red_u = uq[red_t];
+  }
 
   char* base = reinterpret_cast<char*>(scan_lds);
   float2* e2 = reinterpret_cast<float2*>(base);                                  // [Tp][R] (swizzled)
@@ -163,16 +177,15 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   int* ev_done = xy_done + 16;                      // [16] freeze / goal events of the group and of all before it (chunk wave)
   int* c_done = ev_done + 16;                       // [16] records (chunk wave): 1, or 3 = a penalty in the group
   int* cc_done = c_done + 16;                       // [16] control-cost terms (chunk wave)
-  double2* stop_sh = reinterpret_cast<double2*>(cc_done + 16);  // [2W][R] {stage cost of a rollout stopped in this chunk; bits}
-  const bool folded = pend.packets != nullptr;
-  if (folded && c == 0) pending_apply_prepare(pend, lane, scale_sh);
+  int* u_ready = cc_done + 16;                      // [0] the updated control sequence is in u_sh (wave 0; folded launches)
+  double2* stop_sh = reinterpret_cast<double2*>(u_ready + 16);  // [2W][R] {stage cost of a rollout stopped in this chunk; bits}
   if (c == 4) {
     if (lane < R) {
       evw[2 * lane] = 0u;
       evw[2 * lane + 1] = 0u;
       if (lane == 0) flags[0] = 0u;
     }
-    for (int i = lane; i < 7 * 16; i += 64) a_done[i] = 0;
+    for (int i = lane; i < 8 * 16; i += 64) a_done[i] = 0;
   }
   lds_barrier();  // (every wave has only just started)
   MPPI_STAMP(stamp_wg && c < 16, stamp_base + 9);
@@ -208,6 +221,46 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     return v;
   };
   const double dt64 = (double)Q.dt;
+
+  if (folded && (walker == 0 || walker == 1)) {
+    __builtin_amdgcn_s_setprio(3);
+    // The update this launch owes (update_kernels.h, PendingApply), while the chunk waves draw their Philox
+    // blocks; the chunk waves pick the new sequence up from LDS behind u_ready.  (Here, next to the entry code, not
+    // inside the walkers' branch: a cold instruction fetch is ~1k cycles for a lone wave.)
+    if (reducing) {
+      // One GPU: this wave's step(s) of the update, exactly as block t of k_combine_tiles forms them, published to
+      // all workgroups; every workgroup's theta walker then collects the whole sequence.
+      MPPI_STAMP(stamp_wg, stamp_base + 5);
+      if (reduce_here) {
+        const int stride = tile_packet_floats(T);
+        publish_step(pend, combine_step_finish(red_loads, pend.reduce_tiles, pend.reduce_n_tiles, stride, red_t, pend.lambda, lane),
+                     red_u, red_t, T, lane);
+        for (int tt = red_t + 2 * (int)gridDim.x; tt < T; tt += 2 * (int)gridDim.x)
+          publish_step(pend, combine_step(pend.reduce_tiles, pend.reduce_n_tiles, stride, tt, pend.lambda, lane), uq[tt], tt, T, lane);
+      }
+      MPPI_STAMP(stamp_wg, stamp_base + 6);
+      if (walker == 0) collect_published(pend, T, Tp, lane, u_sh);
+      MPPI_STAMP(stamp_wg, stamp_base + 7);
+    } else if (walker == 0) {
+      // Several GPUs: the packets were all-gathered before the launch.  k_apply's expressions in k_apply's
+      // order: the same bits in every workgroup and on every rank.
+      pending_apply_prepare(pend, lane, scale_sh);
+      pin_memory_order();
+      for (int tt = lane; tt < Tp; tt += 64) {
+        const float2 v = tt < T ? pending_apply_control(pend, scale_sh, uq, tt) : make_float2(0.0f, 0.0f);
+        u_sh[tt] = v;
+        if (tile == 0 && tt < T) {
+          pend.u_out[tt] = v;
+          pend.u_prev[tt] = v;
+        }
+      }
+      if (tile == 0 && lane == 0) {
+        pend.stats[0] = scale_sh[kMaxFoldedRanks + 1];
+        pend.stats[1] = scale_sh[kMaxFoldedRanks];
+      }
+    }
+    if (walker == 0) raise(&u_ready[0], 1);
+  }
 
   // Groups handed to a walker.  Two register sets: while one group is walked the next one's operands
   // are already on their way, and the flag of the one after is read WITHOUT waiting (the answer is
@@ -428,8 +481,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     if (lane < R) wsh[lane] = wr;
     const float den = wave_sum_to_lane63_f32(wr);
     if (lane == 63) {
-      pk.tbeta[tile] = beta;
-      pk.tden[tile] = den;
+      *reinterpret_cast<float2*>(pk.tiles + (size_t)tile * tile_packet_floats(T)) = make_float2(beta, den);
     }
     __builtin_amdgcn_s_setprio(0);
     MPPI_STAMP(stamp_wg, stamp_base + 4);
@@ -445,23 +497,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     double* const inc_y = inc_x + 8 * R;                                      // [8][R]: (dt*v)*sin
     // ---------------------------------------------------------------- A
     float2 ut[CHL];
-    if (folded) {  // (wave-uniform) the 8 controls of this wave's steps from the ranks' packets
-      if (lane < 8) {
-        const int t = 8 * g + lane;
-        const float2 v = t < T ? pending_apply_control(pend, scale_sh, uq, t) : make_float2(0.0f, 0.0f);
-        u_sh[t] = v;
-        if (tile == 0 && t < T) {
-          pend.u_out[t] = v;
-          pend.u_prev[t] = v;
-        }
-      }
-      if (tile == 0 && g == 0 && lane == 0) {
-        pend.stats[0] = scale_sh[kMaxFoldedRanks + 1];
-        pend.stats[1] = scale_sh[kMaxFoldedRanks];
-      }
-#pragma unroll
-      for (int j = 0; j < CHL; ++j) ut[j] = u_sh[t0 + j];
-    } else {
+    if (!folded) {  // (requested before the Philox blocks: their first touch is a trip to memory)
 #pragma unroll
       for (int j = 0; j < CHL; ++j) ut[j] = uq[min(t0 + j, T - 1)];
     }
@@ -481,6 +517,11 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
       for (int j = 0; j < CHL; ++j) e[j] = col[(size_t)min(t0 + j, T - 1) * 64];
     }
     MPPI_STAMP(stamp_wg && c < 16, stamp_base + 10);
+    if (folded) {  // (wave-uniform) the sequence this launch's update leaves: formed by wave 0 meanwhile
+      (void)wait_for(&u_ready[0]);
+#pragma unroll
+      for (int j = 0; j < CHL; ++j) ut[j] = u_sh[t0 + j];
+    }
     double qx[CHL];  // dt * clipped speed: exact products of float32 factors
 #pragma unroll
     for (int j = 0; j < CHL; ++j) {
@@ -681,7 +722,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
         ax = fmaf(wm, en.x, ax);
         ay = fmaf(wm, en.y, ay);
       }
-      pk.tnum[(size_t)t * pk.n_tiles + tile] = make_float2(ax, ay);
+      *reinterpret_cast<float2*>(pk.tiles + (size_t)tile * tile_packet_floats(T) + 2 + 2 * t) = make_float2(ax, ay);
     }
   }
   MPPI_STAMP(stamp_wg && c < 16, stamp_base + 8);

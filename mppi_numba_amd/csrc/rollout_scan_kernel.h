@@ -42,8 +42,8 @@
 //      (frozen_block), the terminal cost, the T control-cost additions (mppi.py:1005-1009); cost,
 //      weights relative to the tile's minimum (update_kernels.h)
 //   F  two waves, lane = step: sum over the tile's rollouts of w_rel * noise(t, n) from LDS -- the
-//      tile's contribution to the update, [T][tiles] float2: k_combine_tiles needs no pass over the
-//      noise.
+//      tile's contribution to the update (tile packets: update_kernels.h): no pass over the noise
+//      is left.
 // A failed vote (a rollout still moving meets a cell whose traction differs): phase E is replaced
 // by a sequential float32 rollout of the tile by one wave.  The host stops launching this kernel on
 // maps where most tiles fail (review_speculation).
@@ -53,11 +53,10 @@
 
 namespace mppi {
 
-// tile contributions to the control update, written by phase F / read by k_combine_tiles
+// tile contributions to the control update, written by the weight epilogue and phase F; read by
+// k_combine_tiles or by the class reduction of the next rollout launch (update_kernels.h)
 struct ScanPackets {
-  float2* tnum;  // [T][n_tiles]: sum over the tile's rollouts of w_rel * noise(t)
-  float* tden;   // [n_tiles]:    sum of w_rel
-  float* tbeta;  // [n_tiles]:    minimum cost
+  float* tiles;  // [n_tiles][tile_packet_floats(T)]: {minimum cost, sum of w_rel, sum of w_rel * noise(t) for every t}
   int n_tiles;
 };
 
@@ -583,8 +582,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
     if (lane < R) wsh[lane] = wr;
     const float den = wave_sum_to_lane63_f32(wr);
     if (lane == 63) {
-      pk.tbeta[tile] = beta;
-      pk.tden[tile] = den;
+      *reinterpret_cast<float2*>(pk.tiles + (size_t)tile * tile_packet_floats(T)) = make_float2(beta, den);
     }
     MPPI_STAMP(stamp_wg, stamp_base + 11);
   }
@@ -604,7 +602,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
         ax = fmaf(wm, en.x, ax);
         ay = fmaf(wm, en.y, ay);
       }
-      pk.tnum[(size_t)t * pk.n_tiles + tile] = make_float2(ax, ay);
+      *reinterpret_cast<float2*>(pk.tiles + (size_t)tile * tile_packet_floats(T) + 2 + 2 * t) = make_float2(ax, ay);
     }
   }
   MPPI_STAMP(stamp_wg && c < 16, stamp_base + 8);

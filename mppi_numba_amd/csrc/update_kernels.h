@@ -54,16 +54,31 @@ __device__ __forceinline__ void apply_update(float2* u, float2* u_prev, float2* 
 // reading the old one).  packets == nullptr: nothing pending, u is read as it is.
 constexpr int kMaxFoldedRanks = 16;
 struct PendingApply {
-  const double* packets;  // [world][stride] as all-gathered; nullptr: none
+  const double* packets;  // [world][stride] as all-gathered; nullptr: none (or: see reduce_tiles)
   float2* u_out;          // the other control buffer
   float2* u_prev;
   double* stats;          // {beta, den} of the update
   int world, stride;      // stride: doubles per rank (= packet_len(T) for the single-problem handle)
   float lambda, v_lo, v_hi, w_lo, w_hi;
+  // One GPU, iteration loop of the time-parallel exact kernel (round 4): the previous launch left one packet per
+  // TILE and no update kernel ran.  Workgroup t of this launch (t < T; its otherwise idle theta walker) combines the
+  // tile packets for step t exactly as block t of k_combine_tiles would -- the same function, the same bits -- and
+  // publishes u[t] to every other workgroup through `published`: two 8-byte words {float value; uint32 1} per step,
+  // written and polled at agent scope (the word carries its own flag: no fence, no second round trip).  Set
+  // `flag_set` is used by this launch and the other one is cleared for the launch after next; k_combine_tiles, which
+  // closes every loop, clears both.
+  const float* reduce_tiles;        // [reduce_n_tiles][tile_packet_floats(T)]; nullptr: not this mode
+  int reduce_n_tiles;
+  unsigned long long* published;    // [2][T][kPublishedStride] words, two used per step
+  int flag_set;
 };
 
-// wave 0 of a workgroup, before the workgroup's first barrier: the scale of every rank's packet and
-// the common denominator (k_apply's lines) -> scale_sh[0 .. world), scale_sh[kMaxFoldedRanks] = den
+// ---- tile packets of the time-parallel kernels (rollout_scan*.h), tile-major ------------------------------
+// per tile of 32 (64) rollouts: [0] beta_tile (minimum cost)  [1] sum of w_rel  [2 + 2t + c] sum of w_rel * noise(t)[c]
+__host__ __device__ inline int tile_packet_floats(int n_steps) { return 2 + 2 * n_steps; }
+
+// one wave of a workgroup: the scale of every rank's packet and the common denominator (k_apply's
+// lines) -> scale_sh[0 .. world), scale_sh[kMaxFoldedRanks] = den, [kMaxFoldedRanks + 1] = beta
 __device__ __forceinline__ void pending_apply_prepare(const PendingApply& A, int lane, double* scale_sh) {
   const double mine = A.packets[(size_t)min(lane, A.world - 1) * A.stride];
   double beta = A.packets[0];
@@ -78,7 +93,7 @@ __device__ __forceinline__ void pending_apply_prepare(const PendingApply& A, int
   }
 }
 
-// one control of the updated sequence (any lane, after the barrier that follows pending_apply_prepare)
+// one control of the updated sequence (any lane, after pending_apply_prepare)
 __device__ __forceinline__ float2 pending_apply_control(const PendingApply& A, const double* scale_sh,
                                                         const float2* __restrict__ u_old, int t) {
   double nx = 0.0, ny = 0.0;
@@ -89,6 +104,135 @@ __device__ __forceinline__ float2 pending_apply_control(const PendingApply& A, c
     ny = fma(sg, num.y, ny);
   }
   return updated_control(u_old[t], nx, ny, scale_sh[kMaxFoldedRanks], A.v_lo, A.v_hi, A.w_lo, A.w_hi);
+}
+
+// ---- the combination of the tile packets for ONE step, by one wave (k_combine_tiles; PendingApply::reduce_tiles)
+// beta = min over the tiles' minima, scale_tile = exp(-(beta_tile - beta)/lambda) through v_exp_f32 (the argument is
+// an exact float32 difference), den and num[t] in float64: each lane its tiles lane, lane + 64, ... in order, then a
+// fixed butterfly -- the same bits wherever it runs.  Four tiles per lane cover N = 8192 (256 tiles of 32 rollouts)
+// in one batch of loads; everything is requested before anything is waited for.
+struct StepSums {
+  float beta;
+  double den, nx, ny;
+};
+// (issued apart from their use: a rollout launch requests them before its first barrier)
+struct StepLoads {
+  static constexpr int U = 4;
+  float2 bd[U], m[U];
+};
+__device__ __forceinline__ StepLoads combine_step_issue(const float* __restrict__ tile_packets, int n_tiles, int stride,
+                                                        int t, int lane) {
+  StepLoads L;
+#pragma unroll
+  for (int q = 0; q < StepLoads::U; ++q) {
+    const int g = min(lane + 64 * q, n_tiles - 1);
+    const float* at = tile_packets + (size_t)g * stride;
+    L.bd[q] = *reinterpret_cast<const float2*>(at);
+    L.m[q] = *reinterpret_cast<const float2*>(at + 2 + 2 * t);
+  }
+  return L;
+}
+__device__ __forceinline__ StepSums combine_step_finish(StepLoads L, const float* __restrict__ tile_packets, int n_tiles,
+                                                        int stride, int t, float lambda, int lane) {
+  constexpr int U = StepLoads::U;
+#pragma unroll
+  for (int q = 0; q < U; ++q)
+    if (lane + 64 * q >= n_tiles) {
+      L.bd[q] = make_float2(__builtin_inff(), 0.0f);
+      L.m[q] = make_float2(0.0f, 0.0f);
+    }
+  float bm = fminf(fminf(L.bd[0].x, L.bd[1].x), fminf(L.bd[2].x, L.bd[3].x));
+  for (int g = lane + 64 * U; g < n_tiles; g += 64) bm = fminf(bm, tile_packets[(size_t)g * stride]);
+  StepSums S;
+  S.beta = wave_min_f32(bm);
+  const float beta = S.beta;
+  const float scale = -1.4426950408889634f / lambda;
+  double den = 0.0, nx = 0.0, ny = 0.0;
+  auto take = [&](float tb, float td, float2 tn) {
+    const double s = (double)__builtin_amdgcn_exp2f((tb - beta) * scale);
+    den = fma(s, (double)td, den);
+    nx = fma(s, (double)tn.x, nx);
+    ny = fma(s, (double)tn.y, ny);
+  };
+#pragma unroll
+  for (int q = 0; q < U; ++q) take(L.bd[q].x == __builtin_inff() ? beta : L.bd[q].x, L.bd[q].y, L.m[q]);
+  for (int g = lane + 64 * U; g < n_tiles; g += 64) {
+    const float* at = tile_packets + (size_t)g * stride;
+    take(at[0], at[1], *reinterpret_cast<const float2*>(at + 2 + 2 * t));
+  }
+  S.den = wave_sum_f64(den);
+  S.nx = wave_sum_f64(nx);
+  S.ny = wave_sum_f64(ny);
+  return S;
+}
+__device__ __forceinline__ StepSums combine_step(const float* __restrict__ tile_packets, int n_tiles, int stride, int t,
+                                                 float lambda, int lane) {
+  return combine_step_finish(combine_step_issue(tile_packets, n_tiles, stride, t, lane), tile_packets, n_tiles, stride, t,
+                             lambda, lane);
+}
+
+// The published sequence: the two words of step t, {float u.x; uint32 1} {float u.y; uint32 1}, sit 4 KiB apart
+// from the next step's -- 256 workgroups poll them while ~100 publish: next to each other they are one hot spot of
+// a dozen cache lines behind one memory channel.
+constexpr int kPublishedStride = 512;  // words per step
+__host__ __device__ inline size_t published_words(int n_steps) { return (size_t)2 * n_steps * kPublishedStride; }
+__device__ __forceinline__ unsigned long long published_word(float v) {
+  return (1ull << 32) | (unsigned long long)__float_as_uint(v);
+}
+
+// PendingApply::reduce_tiles, one wave of workgroup `tile`: step t of the update -> both published words (and the
+// handle's other control buffer, u_prev, the update's {beta, den}); the words of the other set are cleared
+__device__ __forceinline__ void publish_step(const PendingApply& A, const StepSums& S, float2 u_old, int t, int n_steps,
+                                             int lane) {
+  if (lane == 0) {
+    const float2 ut = updated_control(u_old, S.nx, S.ny, S.den, A.v_lo, A.v_hi, A.w_lo, A.w_hi);
+    unsigned long long* mine = A.published + ((size_t)A.flag_set * n_steps + t) * kPublishedStride;
+    unsigned long long* other = A.published + ((size_t)(A.flag_set ^ 1) * n_steps + t) * kPublishedStride;
+    __hip_atomic_store(mine, published_word(ut.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(mine + 1, published_word(ut.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    other[0] = 0ull;  // (polled again two launches from now at the earliest)
+    other[1] = 0ull;
+    A.u_out[t] = ut;
+    A.u_prev[t] = ut;
+    if (t == 0) {
+      A.stats[0] = (double)S.beta;
+      A.stats[1] = S.den;
+    }
+  }
+}
+
+// every workgroup, one wave: the published sequence -> u_sh[0 .. Tp) (LDS); steps past the horizon are zero.
+// A lane polls the steps lane, lane + 64, ... and stops asking for a step once it has it.
+// Bounded: the publishers are the first workgroups of the grid, dispatched before any workgroup that waits for them,
+// so this cannot deadlock; should it ever poll for about a second, something else is broken: trap rather than hang.
+__device__ __forceinline__ void collect_published(const PendingApply& A, int n_steps, int padded_steps, int lane,
+                                                  float2* u_sh) {
+  unsigned long long* words = A.published + (size_t)A.flag_set * n_steps * kPublishedStride;
+  for (int base = 0; base < padded_steps; base += 128) {  // (one round for T <= 128)
+    unsigned long long wx[2] = {0ull, 0ull}, wy[2] = {0ull, 0ull};
+    for (int polls = 0;; ++polls) {
+      bool all_there = true;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int t = base + lane + 64 * q;
+        if (t < n_steps && ((wx[q] & wy[q]) >> 32) == 0ull) {
+          wx[q] = __hip_atomic_load(words + (size_t)t * kPublishedStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          wy[q] = __hip_atomic_load(words + (size_t)t * kPublishedStride + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          all_there = all_there && ((wx[q] & wy[q]) >> 32) != 0ull;
+        }
+      }
+      if (__all(all_there)) break;
+      if (polls > (1 << 20)) __builtin_trap();
+      __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int t = base + lane + 64 * q;
+      if (t < padded_steps)
+        u_sh[t] = t < n_steps ? make_float2(__uint_as_float((unsigned int)wx[q]), __uint_as_float((unsigned int)wy[q]))
+                              : make_float2(0.0f, 0.0f);
+    }
+  }
 }
 
 // ---- stage 1: weights relative to the minimum of each tile of 64 rollouts ----------
@@ -298,86 +442,57 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
   MPPI_STAMP(stamp_wg, 517);
 }
 
-// ---- stage 2 after k_rollout_scan (rollout_scan_kernel.h): the rollout launch has already reduced
-// w_rel * noise over each tile of 64 rollouts (tnum [T][tiles] float2, tden [tiles]); what is left
-// of update_useq_numba (mppi.py:1147-1191) is the combination of the tiles -- T x tiles x 8 bytes
+// ---- stage 2 after the time-parallel kernels (rollout_scan*.h): the rollout launch has already reduced
+// w_rel * noise over each of its tiles (tile packets, tile-major: tile_packet_floats); what is left
+// of update_useq_numba (mppi.py:1147-1191) is the combination of the tiles -- tiles x (2T + 2) floats
 // instead of a pass over the noise.  Grid (T, problems), one wave per step: beta = min over
 // tile_beta, scale_tile = exp(-(beta_tile - beta)/lambda), den / num in float64 in a fixed order
 // (identical den in every workgroup), then as k_update_rows: apply, or this rank's packet.
+// Inside an iteration loop on one GPU this launch does not run at all: the next rollout launch combines the
+// tile packets itself, step t in workgroup t (PendingApply::reduce_tiles, the same combine_step: the same bits);
+// it closes a loop (and serves batched handles, several GPUs, the tolerance kernel).  gen_bump: the iterations
+// whose noise generation this launch accounts for (graph replay: itself plus those whose update ran inside a
+// rollout launch).  published: the words of both flag sets, cleared for the next loop.
 template <bool APPLY>
-__global__ __launch_bounds__(64) void k_combine_tiles(const float* __restrict__ tile_beta,
-                                                      const float* __restrict__ tden,
-                                                      const float2* __restrict__ tnum, int n_tiles, int total_tiles,
+__global__ __launch_bounds__(64) void k_combine_tiles(const float* __restrict__ tile_packets, int n_tiles,
                                                       int n_steps, float lambda, double* __restrict__ rank_packet,
                                                       float2* __restrict__ u, float2* __restrict__ u_prev,
                                                       float2* __restrict__ u_mirror, float v_lo, float v_hi,
                                                       float w_lo, float w_hi, double* __restrict__ stats,
-                                                      unsigned long long* __restrict__ gen_counter) {
-  if (gen_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *gen_counter += 1ull;
+                                                      unsigned long long* __restrict__ gen_counter,
+                                                      unsigned long long gen_bump,
+                                                      unsigned long long* __restrict__ published) {
+  if (gen_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *gen_counter += gen_bump;
   const int t = blockIdx.x, inst = blockIdx.y, lane = threadIdx.x;
+  if (published && inst == 0 && lane < 4) published[((size_t)(lane >> 1) * n_steps + t) * kPublishedStride + (lane & 1)] = 0ull;
   [[maybe_unused]] const bool stamp_wg = (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && blockIdx.y == 0;
   [[maybe_unused]] const int stamp_base = blockIdx.x == 0 ? 520 : 528;
   MPPI_STAMP(stamp_wg, stamp_base + 0);
-  tile_beta += (size_t)inst * n_tiles;
-  tden += (size_t)inst * n_tiles;
-  tnum += (size_t)t * total_tiles + (size_t)inst * n_tiles;
+  const int stride = tile_packet_floats(n_steps);
+  tile_packets += (size_t)inst * n_tiles * stride;  // problem `inst` owns tiles [inst * n_tiles, (inst + 1) * n_tiles)
   rank_packet += (size_t)inst * packet_len(n_steps);
   u += (size_t)inst * n_steps;
   u_prev += (size_t)inst * n_steps;
   if (u_mirror) u_mirror += (size_t)inst * n_steps;
   stats += 2 * inst;
-  // four tiles per lane cover N = 8192 (256 tiles of 32 rollouts) in one batch of loads; more go
-  // round the loop.  Everything is requested before anything is waited for.
-  constexpr int U = 4;
-  float b[U], d[U];
-  float2 m[U];
-#pragma unroll
-  for (int q = 0; q < U; ++q) {
-    const int g = lane + 64 * q;
-    const bool in = g < n_tiles;
-    b[q] = in ? tile_beta[g] : __builtin_inff();
-    d[q] = in ? tden[g] : 0.0f;
-    m[q] = in ? tnum[g] : make_float2(0.0f, 0.0f);
-  }
   const float2 u_old = APPLY ? u[t] : make_float2(0.0f, 0.0f);
-  float bm = fminf(fminf(b[0], b[1]), fminf(b[2], b[3]));
-  for (int g = lane + 64 * U; g < n_tiles; g += 64) bm = fminf(bm, tile_beta[g]);
-  MPPI_STAMP(stamp_wg, stamp_base + 1);
-  const float beta = wave_min_f32(bm);
-  MPPI_STAMP(stamp_wg, stamp_base + 2);
-  // exp(-(beta_tile - beta)/lambda) through v_exp_f32: the argument is an exact float32 difference
-  const float scale = -1.4426950408889634f / lambda;
-  double den = 0.0, nx = 0.0, ny = 0.0;
-  auto take = [&](float tb, float td, float2 tn) {
-    const double s = (double)__builtin_amdgcn_exp2f((tb - beta) * scale);
-    den = fma(s, (double)td, den);
-    nx = fma(s, (double)tn.x, nx);
-    ny = fma(s, (double)tn.y, ny);
-  };
-#pragma unroll
-  for (int q = 0; q < U; ++q) take(b[q] == __builtin_inff() ? beta : b[q], d[q], m[q]);
-  for (int g = lane + 64 * U; g < n_tiles; g += 64) take(tile_beta[g], tden[g], tnum[g]);
-  den = wave_sum_f64(den);
-  nx = wave_sum_f64(nx);
-  ny = wave_sum_f64(ny);
+  const StepSums S = combine_step(tile_packets, n_tiles, stride, t, lambda, lane);
   MPPI_STAMP(stamp_wg, stamp_base + 3);
   if (lane == 0) {
     if (APPLY) {
-      float2 ut = u_old;
-      ut.x = clip_f32(ut.x + (float)(nx / den), v_lo, v_hi);
-      ut.y = clip_f32(ut.y + (float)(ny / den), w_lo, w_hi);
+      const float2 ut = updated_control(u_old, S.nx, S.ny, S.den, v_lo, v_hi, w_lo, w_hi);
       u[t] = ut;
       u_prev[t] = ut;
       if (u_mirror) u_mirror[t] = ut;
     } else {
-      rank_packet[2 + 2 * t] = nx;
-      rank_packet[3 + 2 * t] = ny;
+      rank_packet[2 + 2 * t] = S.nx;
+      rank_packet[3 + 2 * t] = S.ny;
     }
     if (t == 0) {
-      rank_packet[0] = (double)beta;
-      rank_packet[1] = den;
-      stats[0] = (double)beta;
-      stats[1] = den;
+      rank_packet[0] = (double)S.beta;
+      rank_packet[1] = S.den;
+      stats[0] = (double)S.beta;
+      stats[1] = S.den;
     }
   }
   MPPI_STAMP(stamp_wg, stamp_base + 4);

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--math", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--iterations", type=int, default=1, help="iterations per call (>1: the last launch folds the previous update)")
     args = ap.parse_args()
     from mppi_numba_amd import _lib
     with contextlib.redirect_stdout(io.StringIO()):
@@ -43,17 +44,25 @@ def main():
     buf = (C.c_ulonglong * 4096)()
     _lib.call("mppi_debug_read_stamps", buf, 4096, 1)
     for rep in range(3):
-        planner.iterate_async(1)
+        planner.iterate_async(args.iterations)  # (the stamps of the last launch survive)
         planner.synchronize()
         _lib.call("mppi_debug_read_stamps", buf, 4096, 1)
         st = np.array(buf[:], dtype=np.uint64).astype(np.int64)
     print(planner.last_rollout_kernel())
+    # workgroup 5 and (exact kernel) workgroup 200; walkers of a launch that applies the previous update itself:
+    # 5 combine begins, 6 published, 7 sequence collected
+    for title, first in (("workgroup 5", 64), ("workgroup 200", 1024)):
+        rows = [st[first + 16 * c: first + 16 * c + 12] for c in range(16)]
+        if not any(r[0] for r in rows):
+            continue
+        t0 = min(int(r[0]) for r in rows if r[0])
+        print(title)
+        print(" wave  " + "".join("%8d" % k for k in range(12)))
+        for c, r in enumerate(rows):
+            if r[0]:
+                print("%5d  " % c + "".join("%8s" % (int(v - t0) if v else "-") for v in r))
     rows = [st[64 + 16 * c: 64 + 16 * c + 12] for c in range(16)]
     t0 = min(int(r[0]) for r in rows if r[0])
-    print(" wave  " + "".join("%8d" % k for k in range(12)))
-    for c, r in enumerate(rows):
-        if r[0]:
-            print("%5d  " % c + "".join("%8s" % (int(v - t0) if v else "-") for v in r))
     # every workgroup's entry / exit (slots 2048 + 2 b, 2049 + 2 b) when the kernel records them
     ent, ext = st[2048:2048 + 1024:2], st[2049:2049 + 1024:2]
     if ent.any():
