@@ -270,6 +270,9 @@ def main():
     ap.add_argument("--problems", type=int, default=None, help="c5: problems per GPU (default 64)")
     ap.add_argument("--math", default="exact", choices=["exact", "fast"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--regions", type=int, default=15,
+                    help="repeat the K-step timed region this many more times (ms_per_step stays the FIRST region; "
+                         "median / min over all regions are reported beside it)")
     ap.add_argument("--debug-flags", type=int, default=0,
                     help="developer switches (include/mppi_hip.h MPPI_DEBUG_*): which kernel variant runs (experiments)")
     ap.add_argument("--graph", type=int, default=0, metavar="ITERATIONS",
@@ -446,6 +449,17 @@ def main():
     per_rank = hub.all_gather(own_elapsed) if world > 1 else [own_elapsed]
     elapsed = max(per_rank)
     ms_per_step = 1e3 * elapsed / args.steps
+    # The contract's number is the region above, one shot (K x ~17 us at C2: a fraction of a millisecond).  The
+    # same region again, `--regions` times, each bracketed the same way: the spread IS the measurement's noise.
+    region_ms = [ms_per_step]
+    for _ in range(max(0, args.regions)):
+        barrier()
+        t1 = time.perf_counter()
+        runner.iterate_async(args.steps)
+        runner.synchronize()
+        own = time.perf_counter() - t1
+        barrier()
+        region_ms.append(1e3 * (max(hub.all_gather(own)) if world > 1 else own) / args.steps)
     rollouts_per_step = (problems * n_local * world) if problems else n_global
     if by_samples:
         # weak scaling in M: N control samples x (M * world) traction samples per step, counted in
@@ -519,6 +533,8 @@ def main():
                                ("one process per GPU, %s" % ("external launcher (RANK/WORLD_SIZE)"
                                                              if "MPPI_RDZV_FILE" not in os.environ else
                                                              "started by bench.py itself")) if world > 1 else "single process"},
+        "ms_per_step_median": float(np.median(region_ms)), "ms_per_step_min": float(np.min(region_ms)),
+        "ms_per_step_regions": region_ms,
         "gpu_ms_per_step_events": gpu_ms / args.steps,
         "ms_per_step_per_rank": [1e3 * e / args.steps for e in per_rank],
         "closing_barrier_ms": 1e3 * closing_barrier_s,
@@ -530,9 +546,11 @@ def main():
                           "no events inside the loop); kernel_us_in_loop has no such overhead",
         "kernel_us_in_loop": None if not kernel_us else
             {"rollout": kernel_us[0], "update": kernel_us[1],
-             "how": "200 ordinary iterations; every rollout / update launch carries its own start / stop HIP events "
-                    "(hipExtLaunchKernelGGL: the dispatch's begin / end timestamps, as rocprofv3 --kernel-trace "
-                    "reports them; averages agree with profiles/)"},
+             "how": "200 ordinary iterations of one call; every rollout / update launch carries its own start / stop HIP "
+                    "events (hipExtLaunchKernelGGL: the dispatch's begin / end timestamps, as rocprofv3 --kernel-trace "
+                    "reports them; averages agree with profiles/).  `update` is the update launches' time per ITERATION: "
+                    "when the next rollout launch applies the update itself (rollout_kernel says applies_update=1) only "
+                    "the last iteration of a call has an update launch and its time is spread over all of them"},
         "roofline": {"bound": "hbm",
                      "kernel": kernel_name + (" (rollout + next iteration's noise)" if kernel_name in ("k_rollout_pipe", "k_rollout_spec", "k_rollout_deep") else
                                               " (noise + rollout + per-tile update sums)" if fused else ""),
@@ -543,6 +561,9 @@ def main():
                                     "sums, not by HBM (priced against the reference's dataflow as SURVEY.md 8d prescribes)") if fused else None,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": None if achieved is None else achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     # (for a fused launch `achieved` is a speed-of-job index, not bus utilisation)
+                     "algorithmic_equivalent_GBps": achieved,
+                     "hbm_GBps_measured": None if (traffic is None or roll_s <= 0) else traffic / roll_s / 1e9,
                      "traffic_source": "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                        "kernel on this workload (committed; not re-measured in this run)",
                      "algorithmic_bytes_per_launch": bytes_roll,

@@ -69,7 +69,7 @@ def test_longer_graphs():
         graphed.synchronize()
         assert np.array_equal(direct.u_cur_d.copy_to_host(), graphed.u_cur_d.copy_to_host()), chunk
     stats = graphed.graph_stats()
-    assert stats["replays"] >= 4 and stats["captures"] <= 2, stats
+    assert stats["replays"] >= 4 and stats["captures"] <= 4, stats  # (one graph per parity of the control and tile-packet buffers)
     from mppi_numba_amd import _lib
     with pytest.raises(_lib.MppiError, match="even"):
         graphed.set_graph_replay(True, iterations_per_graph=3)
