@@ -65,6 +65,26 @@ def synthetic_world(workload, rng):
         pmf[-1] = 100  # nominal traction (README.md:136-151 recipe)
         bin_values = np.array([0.0, 1.0])
         alpha = 1.0
+    elif workload == "c2s":
+        # A semantic map as the reference builds it in deterministic-dynamics mode (terrain.py:183-342): every
+        # cell's PMF is one-hot at the bin of its terrain type's (CVaR-)expected traction, i.e. the traction is
+        # piecewise constant over patches of terrain.  Four terrain types in rectangles of 4-16 m (16-64 cells).
+        bins = 16
+        bin_values = np.linspace(0.0, 1.0, bins)
+        type_bin = np.array([15, 12, 9, 7])  # traction 1.0, 0.8, 0.6, 0.47
+        kinds = np.zeros((rows, cols), dtype=np.int64)
+        r0 = 0
+        while r0 < rows:
+            h = int(rng.integers(16, 65))
+            c0 = 0
+            while c0 < cols:
+                wd = int(rng.integers(16, 65))
+                kinds[r0:r0 + h, c0:c0 + wd] = int(rng.integers(0, len(type_bin)))
+                c0 += wd
+            r0 += h
+        pmf = np.zeros((bins, rows, cols), dtype=np.int8)
+        pmf[type_bin[kinds], np.arange(rows)[:, None], np.arange(cols)[None, :]] = 100
+        alpha = 1.0
     else:
         bins = 16
         raw = rng.dirichlet(np.ones(bins), size=(rows, cols))
@@ -91,6 +111,11 @@ def make_params(workload):
 WORKLOADS = {
     "c2": dict(n=8192, t=100, m=1, mode=dict(use_det_dynamics=True),
                label="Unicycle MPPI det-dyn, N=8192/GPU, T=100, 256x256 nominal traction grid"),
+    # the C2 shape on maps the time-parallel kernel's assumption does not hold on
+    "c2s": dict(n=8192, t=100, m=1, mode=dict(use_det_dynamics=True),
+                label="Unicycle MPPI det-dyn, N=8192/GPU, T=100, 256x256 SEMANTIC map: 4 terrain types in patches of 4-16 m"),
+    "c2c": dict(n=8192, t=100, m=1, mode=dict(use_det_dynamics=True),
+                label="Unicycle MPPI det-dyn, N=8192/GPU, T=100, 256x256 CVaR-bin traction (changes from cell to cell, as C4)"),
     "c3": dict(n=4096, t=100, m=128, mode=dict(use_tdm=True),
                label="CVaR MPPI, N=4096/GPU x M=128 traction samples, 16-bin PMF, 256x256"),
     "c4": dict(n=65536, t=200, m=1, mode=dict(use_det_dynamics=True),

@@ -95,7 +95,7 @@ struct mppi_planner {
   hipGraph_t graph[kGraphSlots] = {};
   hipGraphExec_t graph_exec[kGraphSlots] = {};
   std::vector<unsigned char> graph_sig[kGraphSlots];  // everything the captured launches took by value
-  uint64_t graph_spec_tiles[kGraphSlots] = {};  // speculative tiles one replay of the graph launches
+  uint64_t graph_spec_launches[kGraphSlots] = {};  // speculative launches in one replay of the graph
   int graph_u_flip[kGraphSlots] = {}, graph_tpk_flip[kGraphSlots] = {};  // buffer parities one replay changes
   int u_parity = 0;                         // flips whenever u and u_alt change places
   long graph_replays = 0, graph_captures = 0;
@@ -177,11 +177,12 @@ struct mppi_planner {
   // changes from cell to cell: every tile fails its vote and re-runs on the exact schedule, slower
   // than launching k_rollout_pipe in the first place (N = 8192, T = 200 over a CVaR-bin map: 85 vs
   // 49 us).  The kernels count failed tiles in a host-mapped word; whenever the host has
-  // synchronised anyway it compares that with the tiles launched and, past one half, stops
-  // speculating until the packed map changes.
+  // synchronised anyway it compares that with the LAUNCHES it made (a launch lasts as long as its slowest
+  // tile: one failing tile stalls it) and, from one failed tile per two launches on, stops speculating
+  // until the packed map changes.
   unsigned int* spec_fail_host = nullptr;  // pinned, device-mapped
   unsigned int* spec_fail_dev = nullptr;   // device view of the same word
-  uint64_t spec_tiles_launched = 0;
+  uint64_t spec_launches = 0;
   bool speculation_off = false;
   // mppi_planner_time_kernels: dispatch begin / end of the rollout and update launches of the
   // iterations it runs (4 events per iteration), picked up by MPPI_KLAUNCH

@@ -414,7 +414,8 @@ static int materialize_noise(mppi_planner* p) {
 // (update_kernels.h, PendingApply::reduce_tiles): step t in workgroup t, at most two steps per idle walker wave.
 static bool tiles_can_reduce(int tiles, int n_steps) { return 4 * tiles >= n_steps; }
 
-static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan) {
+static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan_in, bool have_window) {
+  ScanPlan plan = plan_in;
   const int N = p->n_local, T = p->cfg.num_steps;
   const int tiles = ceil_div(N, plan.tile);
   REQUIRE(p->tile_packets[0] && p->tile_packets[1], MPPI_ERR_STATE, "internal: no tile packet buffers on this handle");
@@ -466,7 +467,27 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
     pend.published = p->published;
     pend.flag_set = p->reduce_index & 1;
   }
-  p->spec_tiles_launched += (uint64_t)tiles;
+  p->spec_launches += 1;
+  // Exact kernel: where a tile whose vote fails is re-executed (rollout_scan_exact_kernel.h, scan_exact_reexecute):
+  // controls, 16-bit map window and one chunk ring in the LDS of the walks' groups and positions, dead by then --
+  // or behind everything when the horizon is too short for that region to hold them.
+  ScanFallback fallback = {-1, 0};
+  static const bool no_fast_fallback = getenv("MPPI_SCAN_SLOW_FALLBACK") != nullptr;  // developer switch (ablation)
+  if (plan.exact && have_window && !no_fast_fallback) {
+    const int W = plan.chunk_waves;
+    const size_t map_bytes = (size_t)d.win_rows * (size_t)d.win_cols * sizeof(uint16_t);
+    const size_t need = ScanFallback::bytes(8 * W, (int)map_bytes);
+    const size_t budget = (size_t)p->lds_per_cu - 1024;
+    const size_t total = (ScanExactLds::total(W) + 15) & ~(size_t)15;
+    if (need <= ScanExactLds::grp(W) + ScanExactLds::p2(W)) {
+      fallback.offset = (int)(ScanExactLds::e2(W) + ScanExactLds::ccr(W));
+      fallback.map_bytes = (int)map_bytes;
+    } else if (total + need <= budget) {
+      fallback.offset = (int)total;
+      fallback.map_bytes = (int)map_bytes;
+      plan.lds = std::max(plan.lds, total + need);
+    }
+  }
 #define MPPI_LAUNCH_SCAN_EXACT(P2, GEN)                                                                    \
   do {                                                                                                    \
     auto kern = k_rollout_scan_exact<P2, GEN>;                                                            \
@@ -474,7 +495,7 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));            \
     MPPI_KLAUNCH(kern, dim3(tiles), dim3(64 * plan.waves), plan.lds, p->stream, d, p->cells16, p->cells,  \
-                 p->noise, gen_job, p->u, p->costs, p->w_rel, pk, pend);                                   \
+                 p->noise, gen_job, p->u, p->costs, p->w_rel, pk, pend, fallback);                         \
   } while (0)
 #define MPPI_LAUNCH_SCAN(RR, P2, GEN)                                                                      \
   do {                                                                                                    \
@@ -518,9 +539,9 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
   p->tpk_cur ^= 1;
   char buf[256];
   snprintf(buf, sizeof(buf),
-           "k_rollout_scan%s tile=%d waves=%d pow2res=%d noise=%s lds=%zu noise_blocks=%d problems=%d%s",
+           "k_rollout_scan%s tile=%d waves=%d pow2res=%d noise=%s lds=%zu noise_blocks=%d problems=%d%s%s",
            plan.exact ? "_exact" : "", plan.tile, plan.waves, (int)plan.pow2res, gen ? "in-kernel" : "read", plan.lds, extra,
-           p->inst_set ? p->B : 0, applied_here ? (pend.reduce_tiles ? " applies_update=1 reduces_tiles=1" : " applies_update=1") : "");
+           p->inst_set ? p->B : 0, !plan.exact ? "" : (fallback.offset >= 0 ? " failed_tiles=pipelined" : " failed_tiles=one_wave"), applied_here ? (pend.reduce_tiles ? " applies_update=1 reduces_tiles=1" : " applies_update=1") : "");
   p->last_rollout = buf;
   p->tile_packets_fresh = false;  // (w_rel is relative to this kernel's own tiles: tbeta, not tile_beta)
   p->scan_packets_fresh = true;
@@ -599,7 +620,7 @@ static int try_launch_deep(mppi_planner* p, DevParams& d, const DetRegime& r, bo
       }
       if (!cc_lds && !p->cc_scratch) TRY(dev_alloc(&p->cc_scratch, (size_t)ceil_div(N, 64) * 64 * T));
       const int speculate = (p->debug_flags & MPPI_DEBUG_NO_SPECULATION) ? 0 : 1;
-      if (speculate) p->spec_tiles_launched += (uint64_t)ceil_div(N, 64);
+      if (speculate) p->spec_launches += 1;
 #define MPPI_LAUNCH_DEEP(CH, P2, CL)                                                                   \
   do {                                                                                                \
 auto kern = k_rollout_deep<CH, P2, CL, !EXACT>;                                                   \
@@ -690,7 +711,7 @@ static int try_launch_spec(mppi_planner* p, DevParams& d, const DetRegime& r, bo
       }
       if (!cc_lds && !p->cc_scratch) TRY(dev_alloc(&p->cc_scratch, (size_t)ceil_div(N, 64) * 64 * T));
       const int speculate = (p->debug_flags & MPPI_DEBUG_NO_SPECULATION) ? 0 : 1;
-      if (speculate) p->spec_tiles_launched += (uint64_t)ceil_div(N, 64);
+      if (speculate) p->spec_launches += 1;
 #define MPPI_LAUNCH_SPEC(CH, P2, CL)                                                                   \
   do {                                                                                                \
 auto kern = tiles_wg == 1 ? k_rollout_spec<CH, P2, CL, 1> : k_rollout_spec<CH, P2, CL, 2>;        \
@@ -879,7 +900,7 @@ static int launch_rollout_det(mppi_planner* p, DevParams d) {
   TRY(upload_instances(p));
   {
     ScanPlan plan;
-    if (scan_plan(p, &plan)) return launch_scan(p, d, plan);
+    if (scan_plan(p, &plan)) return launch_scan(p, d, plan, have_window);
   }
   // incremental trig: needs a heading increment |dt*w*traction| <= 0.36 rad and T <= 2000
   bool rot_ok = false, rot_ok_fast = false, pow2res = false;
@@ -1375,14 +1396,18 @@ static void graph_signature(const mppi_planner* p, const DevParams& d, const mpp
 // called where the host has just waited for the stream: did speculation pay on this map?
 static void review_speculation(mppi_planner* p) {
   if (!p->spec_fail_host) return;
-  if (p->spec_tiles_launched == 0) {  // (nothing speculative ran: whatever the word holds is stale)
+  if (p->spec_launches == 0) {  // (nothing speculative ran: whatever the word holds is stale)
     *p->spec_fail_host = 0u;
     return;
   }
   const uint64_t failed = *p->spec_fail_host;
-  if (2 * failed >= p->spec_tiles_launched) p->speculation_off = true;
+  // A launch lasts as long as its slowest tile, and a tile whose vote fails is rolled out twice: ONE failing tile
+  // makes its launch slower than the exact kernel would have been (C2 shape, round 4: 40 us against 29 us with
+  // k_rollout_pipe; 16 us when every vote holds), so speculation pays while fewer than about half of the LAUNCHES
+  // contain one.  The kernels count failed tiles: at least one per two launches -> stop.
+  if (2 * failed >= p->spec_launches) p->speculation_off = true;
   *p->spec_fail_host = 0u;
-  p->spec_tiles_launched = 0;
+  p->spec_launches = 0;
 }
 
 static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int iterations, bool timed = true,
@@ -1444,7 +1469,7 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
         if (p->graph[slot]) { (void)hipGraphDestroy(p->graph[slot]); p->graph[slot] = nullptr; }
         p->graph_sig[slot].clear();
         const bool primed_before = have_noise;
-        const uint64_t spec_before = p->spec_tiles_launched;
+        const uint64_t spec_before = p->spec_launches;
         const int u_parity_before = p->u_parity, tpk_before = p->tpk_cur;
         HIP_TRY(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
         int rc = MPPI_OK;
@@ -1457,7 +1482,7 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
         REQUIRE(have_noise == primed_before, MPPI_ERR_STATE, "graph capture: the iterations are not alike");
         HIP_TRY(hipGraphInstantiate(&p->graph_exec[slot], p->graph[slot], nullptr, nullptr, 0));
         p->graph_sig[slot] = sig;
-        p->graph_spec_tiles[slot] = p->spec_tiles_launched - spec_before;
+        p->graph_spec_launches[slot] = p->spec_launches - spec_before;
         // (one GPU, updates applied inside rollout launches: all but the last iteration of the graph change control
         //  buffers -- an odd number when the graph holds an even number of iterations)
         p->graph_u_flip[slot] = (p->u_parity ^ u_parity_before) & 1;
@@ -1469,7 +1494,7 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
         if (p->cfg.rng == MPPI_RNG_PHILOX) p->noise_epoch += (uint64_t)chunk;
         p->bumps_launched += (uint64_t)chunk;
         // (the replayed kernels count their failed tiles like the captured ones did)
-        p->spec_tiles_launched += p->graph_spec_tiles[slot];
+        p->spec_launches += p->graph_spec_launches[slot];
         if (p->graph_u_flip[slot]) {
           std::swap(p->u, p->u_alt);
           p->u_parity ^= 1;

@@ -91,13 +91,150 @@ struct ScanExactLds {
   __host__ __device__ static constexpr size_t total(int W) { return e2(W) + ccr(W) + grp(W) + p2(W) + small(W); }
 };
 
+// ---- a tile whose vote failed, re-executed on the exact three-wave schedule of k_rollout_pipe ---------------
+// (rollout_kernels.h, pipe_tile_body: the same operations on the same operands, i.e. the bits of k_rollout_map and
+// of the oracle; mppi.py:916-1009).  Round 3 rolled such a tile out with ONE wave, global cell lookups and a full
+// sincos per step: ~300 us per launch on a map where tiles fail, against ~29 us for k_rollout_pipe -- a cliff the
+// planner only left when half of its tiles failed.  Now: the 16-bit map window goes into the LDS the walks no
+// longer need (all waves copy), then producer (wave 2: clipped controls from the noise in LDS) -> state (wave 0)
+// -> cost (wave 1) one chunk of 8 steps apart, one workgroup barrier per chunk; the waves without a role only
+// keep the barrier count.  Lanes 32..63 mirror lanes 0..31 (a tile is 32 rollouts).  Returns the cost after the
+// last step and the terminal cost in the lanes of wave 1; the control-cost terms follow in the caller as for any
+// other tile.
+struct ScanFallback {
+  int offset;     // bytes from the start of the dynamic LDS: [Tp] float2 controls | window | ring; < 0: no room,
+  int map_bytes;  // ... the tile is rolled out step by step by one wave (global cells)
+  static constexpr int kRingBytes = PipeRing<8>::kBytesPerPair;
+  __host__ __device__ static constexpr size_t bytes(int Tp, int map_bytes) { return (size_t)Tp * 8 + (size_t)map_bytes + kRingBytes; }
+};
+
+template <bool POW2RES>
+__device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const uint16_t* __restrict__ cells16, char* fb,
+                                                      int map_bytes, const float2* e2, const float2* u_src, int T,
+                                                      int c, int lane) {
+  constexpr int C = 8, R = ScanExactLds::R;
+  using Ring = PipeRing<C>;
+  const int Tp = (T + 7) & ~7;
+  float2* us = reinterpret_cast<float2*>(fb);
+  uint16_t* lds_map = reinterpret_cast<uint16_t*>(fb + (size_t)Tp * 8);
+  char* ring_base = reinterpret_cast<char*>(lds_map) + map_bytes;
+  float2* ring_xy = reinterpret_cast<float2*>(ring_base);
+  double2* ring_qd = reinterpret_cast<double2*>(ring_xy + 2 * Ring::kHalf);
+  uint8_t* ring_flags = reinterpret_cast<uint8_t*>(ring_qd + 2 * Ring::kHalf);
+  const int r = lane & (R - 1);
+  const int K = (T + C - 1) / C;
+  // the window and the controls: everybody; the walks' data under them is dead
+  copy_window_to_lds(P, cells16, lds_map, 0, (int)blockDim.x);
+  for (int t = threadIdx.x; t < Tp; t += blockDim.x) us[t] = t < T ? u_src[t] : make_float2(0.0f, 0.0f);
+  __syncthreads();
+  float cost = 0.0f;
+  if (c == 2) {  // ---- producer: {dt * v, dt * w} of chunk k + 1 while the state wave integrates chunk k
+    const double dt64 = (double)P.dt;
+    auto produce = [&](int chunk) {
+      double2* out_qd = ring_qd + (size_t)(chunk & 1) * Ring::kHalf;
+#pragma unroll
+      for (int j = 0; j < C; ++j) {
+        const int t = chunk * C + j;  // (< Tp: the noise rows past the horizon hold zeros)
+        const float2 ut = us[t], e = e2[t * R + (r ^ (t & (R - 1)))];
+        out_qd[j * 64 + lane] = make_double2(dt64 * (double)clip_f32(ut.x + e.x, P.v_lo, P.v_hi),
+                                             dt64 * (double)clip_f32(ut.y + e.y, P.w_lo, P.w_hi));
+      }
+    };
+    produce(0);
+    __syncthreads();
+    for (int k = 0; k <= K; ++k) {
+      if (k + 1 < K) produce(k + 1);
+      __syncthreads();
+    }
+  } else if (c == 0) {  // ---- state: pipe_tile_body's role 0
+    float x = P.x0, y = P.y0, th = P.th0;
+    double x64 = (double)x, y64 = (double)y, th64 = (double)th;
+    double sn, cs;
+    sincos_f64<false>(th64, sn, cs);
+    const float win_c0f = (float)P.win_c0, win_r0f = (float)P.win_r0;
+    const float win_last_col = (float)(P.win_cols - 1), win_last_row = (float)(P.win_rows - 1);
+    const int win_pitch_bytes = 2 * P.win_cols;
+    const char* lds_bytes = reinterpret_cast<const char*>(lds_map);
+    __syncthreads();
+    for (int k = 0; k <= K; ++k) {
+      if (k < K) {
+        const double2* in_qd = ring_qd + (size_t)(k & 1) * Ring::kHalf;
+        float2* out_xy = ring_xy + (size_t)(k & 1) * Ring::kHalf;
+        uint8_t* out_flags = ring_flags + (size_t)(k & 1) * Ring::kHalf;
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+          const double2 qd = in_qd[j * 64 + lane];
+          int xi, yi;
+          if (POW2RES) {
+            xi = cell_coord_pow2(x, P.xlo, P.inv_res, win_c0f, win_last_col);
+            yi = cell_coord_pow2(y, P.ylo, P.inv_res, win_r0f, win_last_row);
+          } else {
+            xi = clamp_index(floordiv_to_int(x - P.xlo, P.res, P.inv_res) - P.win_c0, P.win_cols);
+            yi = clamp_index(floordiv_to_int(y - P.ylo, P.res, P.inv_res) - P.win_r0, P.win_rows);
+          }
+          const uint32_t c16 = *reinterpret_cast<const uint16_t*>(lds_bytes + (__mul24(yi, win_pitch_bytes) + (xi << 1)));
+          const double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), P.lin_lo);
+          const double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), P.ang_lo);
+          x = (float)fma(vtr, qd.x * cs, x64);
+          y = (float)fma(vtr, qd.x * sn, y64);
+          th = (float)fma(wtr, qd.y, th64);
+          x64 = (double)x;
+          y64 = (double)y;
+          const double th_new = (double)th;
+          // exact increment of the ROUNDED heading; beyond the rotation's range (never with the reference's
+          // parameters) the full evaluation
+          if (__all(fabs(th_new - th64) <= 0.36)) rotate_sincos_f64(th_new - th64, sn, cs);
+          else sincos_f64<false>(th_new, sn, cs);
+          th64 = th_new;
+          out_xy[j * 64 + lane] = make_float2(x, y);
+          out_flags[j * 64 + lane] = (uint8_t)(c16 >> 14);  // obstacle | unknown << 1 of the cell just left
+        }
+      }
+      __syncthreads();
+    }
+  } else if (c == 1) {  // ---- cost: pipe_tile_body's role 1
+    const double dt64 = (double)P.dt, gt2 = (double)P.gt2;
+    double d2 = 1e9;
+    bool done = false, reached = false;
+    __syncthreads();
+    for (int k = 0; k <= K; ++k) {
+      if (k >= 1) {
+        const int t0 = (k - 1) * C;
+        const float2* in_xy = ring_xy + (size_t)((k - 1) & 1) * Ring::kHalf;
+        const uint8_t* in_flags = ring_flags + (size_t)((k - 1) & 1) * Ring::kHalf;
+        const int count = min(C, T - t0);
+        for (int j = 0; j < count; ++j) {
+          const float2 xy = in_xy[j * 64 + lane];
+          const uint32_t fl = in_flags[j * 64 + lane];
+          const double dx = (double)(P.xg - xy.x), dy = (double)(P.yg - xy.y);
+          const double nd2 = fma(dx, dx, dy * dy);
+          float c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(nd2), dt64));
+          c1 = c1 + ((fl & 1u) ? P.obs_cost : 0.0f);
+          c1 = c1 + ((fl & 2u) ? P.unk_cost : 0.0f);
+          const bool hit = nd2 <= gt2, act = !done;
+          cost = act ? c1 : cost;
+          d2 = act ? nd2 : d2;
+          reached = reached || (act && hit);
+          done = done || hit;
+        }
+      }
+      __syncthreads();
+    }
+    cost = (float)((double)cost + (reached ? 0.0 : 1.0) * sqrt(d2) / P.v_post_den);
+  } else {
+    __syncthreads();
+    for (int k = 0; k <= K; ++k) __syncthreads();
+  }
+  return cost;
+}
+
 template <bool POW2RES, bool GEN>
 __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const uint16_t* __restrict__ cells16,
                                                              const uint32_t* __restrict__ cells,
                                                              const float2* __restrict__ noise, NoiseJob gen,
                                                              const float2* __restrict__ u, float* __restrict__ costs,
                                                              float* __restrict__ w_rel, ScanPackets pk,
-                                                             PendingApply pend) {
+                                                             PendingApply pend, ScanFallback fallback) {
   extern __shared__ double2 scan_lds[];
   using L = ScanExactLds;
   constexpr int R = L::R, CHL = L::CHL;
@@ -305,6 +442,69 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     }
   };
 
+  // what every tile ends with, by its cost wave (wave 1): the control cost of all T steps after the terminal cost, the
+  // cost, the weights relative to the tile's minimum and the header of the tile's packet
+  auto finish_tile = [&](float cost) {
+    // the control cost of all T steps, also after an early goal break (mppi.py:1007-1009); steps past
+    // the horizon hold zero noise: their terms are +0.0
+    for ([[maybe_unused]] int polls = 0;
+         !__all(lane >= W || __hip_atomic_load(&cc_done[lane & 15], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0);) {
+      __builtin_amdgcn_s_sleep(MPPI_SCAN_POLL_SLEEP);
+#ifdef MPPI_POLL_BOUND
+      if (++polls > kMaxPolls) __builtin_trap();
+#endif
+    }
+    {
+      const double* at = ccr + (size_t)r * CHL;
+      double2 ca[2][4];
+      auto load = [&](auto set, int gi) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const double* in = at + (size_t)(2 * gi + hh) * R * CHL;
+          ca[decltype(set)::value][2 * hh] = reinterpret_cast<const double2*>(in)[0];
+          ca[decltype(set)::value][2 * hh + 1] = reinterpret_cast<const double2*>(in)[1];
+        }
+      };
+      auto add = [&](auto set) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          cost = (float)((double)cost + ca[decltype(set)::value][i].x);
+          cost = (float)((double)cost + ca[decltype(set)::value][i].y);
+        }
+      };
+      load(PhaseTag<0>(), 0);
+      for (int gi = 0; gi < W; gi += 2) {
+        if (gi + 1 < W) load(PhaseTag<1>(), gi + 1);
+        add(PhaseTag<0>());
+        if (gi + 1 >= W) break;
+        if (gi + 2 < W) load(PhaseTag<0>(), gi + 2);
+        add(PhaseTag<1>());
+      }
+    }
+    MPPI_STAMP(stamp_wg, stamp_base + 3);
+    const bool mine = live && lane < R;
+    if (mine) costs[n] = cost;
+    // first half of the control update (update_kernels.h): weights relative to the tile's minimum.
+    // exp(-(c - beta)/lambda) = 2^(n + f): the fraction through v_exp_f32 (relative error ~1e-7 whatever
+    // the argument), the integer through the exponent (as k_rollout_scan; a float64 exp is ~1k cycles of
+    // this wave's serial tail, and u is held to 1e-5 of the range, not to bits)
+    const float beta = wave_min_f32(live ? cost : __builtin_inff());
+    float wr = 0.0f;
+    if (mine) {
+      const double a2 = (double)(cost - beta) * Q.neg_log2e_over_lambda;  // <= 0
+      const double nf = floor(a2);
+      wr = ldexpf(__builtin_amdgcn_exp2f((float)(a2 - nf)), (int)fmax(nf, -200.0));
+    }
+    if (mine) w_rel[n] = wr;
+    if (lane < R) wsh[lane] = wr;
+    const float den = wave_sum_to_lane63_f32(wr);
+    if (lane == 63) {
+      *reinterpret_cast<float2*>(pk.tiles + (size_t)tile * tile_packet_floats(T)) = make_float2(beta, den);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    MPPI_STAMP(stamp_wg, stamp_base + 4);
+  };
+
   if (walker == 0 || walker == 1) {
     // ================================================================ the theta walk (wave 0), the x | y walk (wave 4)
     // one running sum rounded to float32 after every fma; a lone wave issues an instruction per ~5
@@ -413,8 +613,11 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
       MPPI_STAMP(stamp_wg, stamp_base + 2);
       const bool had_event = (evw[2 * r] | evw[2 * r + 1]) != 0u;
       cost = (float)((double)cost + (had_event ? term_sh[r] : term_plain));
-    } else {
-      // ---- the tile step by step, with the tractions of the visited cells: k_rollout_map's arithmetic
+      finish_tile(cost);
+    } else if (fallback.offset < 0) {
+      // ---- no room for the map window: the tile step by step, with the tractions of the visited cells, by this
+      //      wave alone (k_rollout_map's arithmetic; slow, and counted: the host stops launching this kernel on a
+      //      map where that happens -- review_speculation)
       if (lane == 0 && Q.spec_failures) {
         atomicAdd_system(Q.spec_failures, 1u);
         __threadfence_system();
@@ -426,65 +629,9 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
         if (__all(st.done)) break;
       }
       cost = (float)((double)st.cost + (st.reached ? 0.0 : 1.0) * sqrt(st.d2) / Q.v_post_den);
+      finish_tile(cost);
     }
-    // the control cost of all T steps, also after an early goal break (mppi.py:1007-1009); steps past
-    // the horizon hold zero noise: their terms are +0.0
-    for ([[maybe_unused]] int polls = 0;
-         !__all(lane >= W || __hip_atomic_load(&cc_done[lane & 15], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0);) {
-      __builtin_amdgcn_s_sleep(MPPI_SCAN_POLL_SLEEP);
-#ifdef MPPI_POLL_BOUND
-      if (++polls > kMaxPolls) __builtin_trap();
-#endif
-    }
-    {
-      const double* at = ccr + (size_t)r * CHL;
-      double2 ca[2][4];
-      auto load = [&](auto set, int gi) {
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const double* in = at + (size_t)(2 * gi + hh) * R * CHL;
-          ca[decltype(set)::value][2 * hh] = reinterpret_cast<const double2*>(in)[0];
-          ca[decltype(set)::value][2 * hh + 1] = reinterpret_cast<const double2*>(in)[1];
-        }
-      };
-      auto add = [&](auto set) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          cost = (float)((double)cost + ca[decltype(set)::value][i].x);
-          cost = (float)((double)cost + ca[decltype(set)::value][i].y);
-        }
-      };
-      load(PhaseTag<0>(), 0);
-      for (int gi = 0; gi < W; gi += 2) {
-        if (gi + 1 < W) load(PhaseTag<1>(), gi + 1);
-        add(PhaseTag<0>());
-        if (gi + 1 >= W) break;
-        if (gi + 2 < W) load(PhaseTag<0>(), gi + 2);
-        add(PhaseTag<1>());
-      }
-    }
-    MPPI_STAMP(stamp_wg, stamp_base + 3);
-    const bool mine = live && lane < R;
-    if (mine) costs[n] = cost;
-    // first half of the control update (update_kernels.h): weights relative to the tile's minimum.
-    // exp(-(c - beta)/lambda) = 2^(n + f): the fraction through v_exp_f32 (relative error ~1e-7 whatever
-    // the argument), the integer through the exponent (as k_rollout_scan; a float64 exp is ~1k cycles of
-    // this wave's serial tail, and u is held to 1e-5 of the range, not to bits)
-    const float beta = wave_min_f32(live ? cost : __builtin_inff());
-    float wr = 0.0f;
-    if (mine) {
-      const double a2 = (double)(cost - beta) * Q.neg_log2e_over_lambda;  // <= 0
-      const double nf = floor(a2);
-      wr = ldexpf(__builtin_amdgcn_exp2f((float)(a2 - nf)), (int)fmax(nf, -200.0));
-    }
-    if (mine) w_rel[n] = wr;
-    if (lane < R) wsh[lane] = wr;
-    const float den = wave_sum_to_lane63_f32(wr);
-    if (lane == 63) {
-      *reinterpret_cast<float2*>(pk.tiles + (size_t)tile * tile_packet_floats(T)) = make_float2(beta, den);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    MPPI_STAMP(stamp_wg, stamp_base + 4);
+    // (a failed vote with room for the window: all waves re-execute the tile behind the barrier below)
   } else if (g >= 0) {
     // ================================================================ chunk wave g: steps 8 g .. 8 g + 7
     switch (prio) {  // (earlier groups first on their SIMD)
@@ -705,6 +852,17 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     MPPI_STAMP(stamp_wg && c < 16, stamp_base + 2);
   }
   lds_barrier();
+  if (fallback.offset >= 0 && flags[0] != 0u) {  // (workgroup-uniform: every vote is in)
+    // ---- a failed vote: the tile again, on the exact pipelined schedule (scan_exact_reexecute above)
+    if (c == 1 && lane == 0 && Q.spec_failures) atomicAdd_system(Q.spec_failures, 1u);  // (the host decides whether this map pays)
+    const float cost = scan_exact_reexecute<POW2RES>(Q, cells16, base + fallback.offset, fallback.map_bytes, e2,
+                                                     folded ? u_sh : uq, T, c, lane);
+    if (c == 1) {
+      __builtin_amdgcn_s_setprio(3);
+      finish_tile(cost);
+    }
+    lds_barrier();
+  }
 
   // ---------------------------------------------------------------- F: the tile's share of the update
   // (lane = step, two waves.  Every chunk wave its own 8 steps with a DPP tree over the rollouts was
