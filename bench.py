@@ -303,9 +303,12 @@ def main():
     ap.add_argument("--graph", type=int, default=0, metavar="ITERATIONS",
                     help="hipGraph replay of the iteration loop, that many (even) iterations per graph; "
                          "0 = direct launches (single GPU; same results)")
-    ap.add_argument("--exchange", default="rccl", choices=["rccl", "host"],
-                    help="multi-GPU packet exchange: RCCL all-gather on the stream (default) or, for debugging "
-                         "on a box where several ranks must share one GPU, host-staged over the rendezvous hub")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "p2p", "rccl", "host"],
+                    help="multi-GPU packet exchange.  p2p: every rank writes its numbers straight into its peers' "
+                         "inboxes from inside the rollout launch (IPC-mapped fine-grained memory; no collective, an "
+                         "iteration is one launch); rccl: one RCCL all-gather per iteration on the stream; auto "
+                         "(default): connect both, time both, report both, the faster one is the line's value; host: "
+                         "packets staged over the rendezvous hub (debugging)")
     ap.add_argument("--shard", default="controls", choices=["controls", "samples"],
                     help="multi-GPU c3: what the ranks split -- the N control samples (default; every rank holds all "
                          "M traction maps) or the M traction samples (every rank rolls all N controls over its own "
@@ -393,7 +396,31 @@ def main():
     rp, cp = lin.pmf_grid_d.shape[1:]
 
     exchange_note = None
-    if world > 1 and args.exchange == "rccl" and not problems:
+    p2p_ok = False
+    if world > 1 and args.exchange in ("auto", "p2p") and not problems and not by_samples:
+        err = ""
+        try:
+            handle = planner.p2p_export()
+        except Exception as e:
+            handle, err = b"", str(e)
+        handles = hub.all_gather(handle)
+        if not err and all(len(h) == _lib.P2P_HANDLE_BYTES for h in handles):
+            try:
+                planner.p2p_connect(handles)
+            except Exception as e:
+                err = str(e)
+        else:
+            err = err or "another rank could not export its inbox"
+        p2p_ok = not hub.all_max(1 if err else 0)
+        if not p2p_ok:
+            if not err:
+                planner.p2p_enable(False)  # (connected here, not everywhere: never use it)
+            print("bench.py rank %d: peer exchange unavailable (%s)" % (rank, err or "on another rank"), file=sys.stderr)
+            if args.exchange == "p2p":
+                args.exchange = "rccl"
+    want_rccl = args.exchange == "rccl" or (args.exchange == "auto" and not by_samples) or (args.exchange in ("auto", "p2p") and by_samples)
+    rccl_ok = False
+    if world > 1 and want_rccl and not problems:
         err = ""
         try:
             uid = comm_unique_id() if rank == 0 else None
@@ -406,7 +433,12 @@ def main():
             except Exception as e:
                 err = str(e)
         failed = hub.all_max(1 if (err or uid is None) else 0)
-        if failed:
+        rccl_ok = not failed
+        if failed and p2p_ok:
+            print("bench.py rank %d: RCCL communicator unavailable (%s): the peer exchange alone" % (rank, err or "on another rank"), file=sys.stderr)
+            if err == "" and uid is not None:
+                sys.exit("bench.py: this rank has a communicator the others lack")  # (cannot happen on one node)
+        elif failed:
             # keep the run alive and say so: same kernels, packets staged through the host
             args.exchange = "host"
             exchange_note = "RCCL communicator unavailable (%s): packets exchanged through the host" % (err or "on another rank")
@@ -457,22 +489,46 @@ def main():
     runner.synchronize()
 
     # ---- timed region ------------------------------------------------------------
-    runner.iterate_async(args.warmup)
-    runner.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    runner.iterate_async(args.steps)
-    runner.synchronize()
-    # every rank stops its own clock when ITS stream has drained; the slowest rank's time is the
-    # job's.  (The closing barrier -- a star of TCP messages through rank 0 -- is NOT inside the
-    # timed region: at 8 ranks it would be a visible share of a 0.5 ms run.  The ranks are already
-    # coupled by the all-gather of every iteration.)
-    own_elapsed = time.perf_counter() - t0
-    barrier()
-    closing_barrier_s = time.perf_counter() - t0 - own_elapsed
-    gpu_ms = planner.last_elapsed_ms()
-    per_rank = hub.all_gather(own_elapsed) if world > 1 else [own_elapsed]
-    elapsed = max(per_rank)
+    def timed_region():
+        """W untimed + exactly K timed iterations, barrier + drained stream on both sides (the contract)."""
+        runner.iterate_async(args.warmup)
+        runner.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        runner.iterate_async(args.steps)
+        runner.synchronize()
+        # every rank stops its own clock when ITS stream has drained; the slowest rank's time is the
+        # job's.  (The closing barrier -- a star of TCP messages through rank 0 -- is NOT inside the
+        # timed region: at 8 ranks it would be a visible share of a 0.5 ms run.  The ranks are already
+        # coupled by the exchange of every iteration.)
+        own_elapsed = time.perf_counter() - t0
+        barrier()
+        closing = time.perf_counter() - t0 - own_elapsed
+        per_rank = hub.all_gather(own_elapsed) if world > 1 else [own_elapsed]
+        return dict(per_rank=per_rank, elapsed=max(per_rank), closing=closing, gpu_ms=planner.last_elapsed_ms())
+
+    # several GPUs, both exchanges connected: the same region with each, the faster one is the line's value
+    modes = (["p2p"] if p2p_ok else []) + (["rccl"] if rccl_ok else [])
+    exchange_us = {}
+    region = None
+    if world > 1 and modes and not problems:
+        best = None
+        for mode in modes:
+            if p2p_ok:
+                planner.p2p_enable(mode == "p2p")
+            r = timed_region()
+            exchange_us[mode] = 1e6 * r["elapsed"] / args.steps
+            if best is None or r["elapsed"] < best[1]["elapsed"]:
+                best = (mode, r)
+        args.exchange = best[0]
+        if p2p_ok:
+            planner.p2p_enable(args.exchange == "p2p")
+        region = best[1]
+    else:
+        region = timed_region()
+    own_elapsed, closing_barrier_s, gpu_ms = region["per_rank"][rank] if world > 1 else region["elapsed"], region["closing"], region["gpu_ms"]
+    per_rank = region["per_rank"]
+    elapsed = region["elapsed"]
     ms_per_step = 1e3 * elapsed / args.steps
     # The contract's number is the region above, one shot (K x ~17 us at C2: a fraction of a millisecond).  The
     # same region again, `--regions` times, each bracketed the same way: the spread IS the measurement's noise.
@@ -551,8 +607,12 @@ def main():
                                 "N x (M_global / M) control samples" if by_samples else
                                 "control samples over ranks, 1 all-gather of (2T+2) f64 per step"),
                    "exchange": "none" if ((world == 1 and group_size == 1) or problems) else
-                               ("RCCL all-gather on the planner's stream" if args.exchange == "rccl" else
+                               ("peer exchange: every rank writes its numbers for step t into its peers' inboxes from inside "
+                                "the rollout launch (IPC-mapped fine-grained memory), no collective, one launch per step"
+                                if args.exchange == "p2p" else
+                                "RCCL all-gather on the planner's stream" if args.exchange == "rccl" else
                                 (exchange_note or "host-staged through the rendezvous hub (--exchange host)")),
+                   "exchange_us_per_step": exchange_us or None,
                    "n_ranks_seen_by_rccl": rccl_ranks,
                    "launcher": ("one process, %d devices (mppi_group_*)" % group_size) if group_size > 1 else
                                ("one process per GPU, %s" % ("external launcher (RANK/WORLD_SIZE)"

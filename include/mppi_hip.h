@@ -367,6 +367,26 @@ int mppi_comm_unique_id(char id[MPPI_COMM_ID_BYTES]);
 int mppi_planner_comm_init(mppi_planner* p, const char id[MPPI_COMM_ID_BYTES]);
 /* ranks RCCL itself reports for the handle's communicator (ncclCommCount); 0 without one */
 int mppi_planner_comm_count(mppi_planner* p, int* ranks);
+/* The peer exchange: the same sharding without a collective on the iteration's path.  Every rank owns an inbox
+ * in fine-grained device memory; the workgroup that has combined the local tiles for step t of an update writes the
+ * rank's four numbers for that step straight into every rank's inbox (peer access inside one process, IPC-mapped
+ * memory across processes: xGMI on a multi-GPU node) and waits for the others' in its own -- inside the next
+ * rollout launch, or inside the update launch that closes a loop.  A sharded iteration of the time-parallel exact
+ * kernel (deterministic dynamics, one round of tiles: BASELINE configs[1] per GPU) is then ONE launch; u has the bits
+ * of the all-gather + k_apply path.  Handles the kernels cannot serve keep using the communicator.
+ *   p2p_export   this rank's inbox as an opaque handle (hipIpcMemHandle_t) for the other processes
+ *   p2p_connect  the handles of all `count` = world_size ranks, in rank order (the own one is ignored)
+ *   group_p2p_connect  one process driving `count` devices: planners[g] is rank g
+ *   p2p_stats    connected?, exchanges performed so far, how the inbox was allocated
+ * A rank whose peers never send (a dead process) traps its kernel after about two seconds of polling: the call that
+ * synchronises next returns MPPI_ERR_HIP instead of hanging the device. */
+#define MPPI_P2P_HANDLE_BYTES 64
+int mppi_planner_p2p_export(mppi_planner* p, char handle[MPPI_P2P_HANDLE_BYTES]);
+int mppi_planner_p2p_connect(mppi_planner* p, const char* handles, int count);
+int mppi_group_p2p_connect(mppi_planner** planners, int count);
+int mppi_planner_p2p_stats(mppi_planner* p, int* connected, long* exchanges, char* kind, int capacity);
+/* a connected exchange switched off and on again (all ranks alike; off: the handle's communicator is used) */
+int mppi_planner_p2p_set_enabled(mppi_planner* p, int enabled);
 /* One process driving `count` devices: planners[g] is rank g of `count` on its own device.
  * comm_init creates all communicators inside one RCCL group; iterate_async runs `iterations` x
  * {per device: noise, rollout, shard packet | one group of all-gathers | per device: apply} and

@@ -25,6 +25,7 @@ DEBUG_NO_SCAN_KERNEL, DEBUG_SCAN_READ_NOISE, DEBUG_SCAN_FULL_TILES = 32, 64, 128
 DEBUG_NO_FOLDED_APPLY = 256
 DEBUG_NO_REDUCE_FOLD = 512
 ABI_VERSION = 1
+P2P_HANDLE_BYTES = 64
 
 
 class MppiError(RuntimeError):
@@ -131,6 +132,11 @@ SIGNATURES = {
     "mppi_planner_graph_probe": [_vp, _vp, _vp, C.c_int, C.c_int, _f32p, _f32p],
     "mppi_planner_set_graph_replay": [_vp, C.c_int],
     "mppi_planner_graph_stats": [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long)],
+    "mppi_planner_p2p_export": [_vp, C.c_char_p],
+    "mppi_planner_p2p_connect": [_vp, C.c_char_p, C.c_int],
+    "mppi_group_p2p_connect": [C.POINTER(_vp), C.c_int],
+    "mppi_planner_p2p_stats": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_long), C.c_char_p, C.c_int],
+    "mppi_planner_p2p_set_enabled": [_vp, C.c_int],
     "mppi_world_create": [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _f64p, _f64p, C.POINTER(_vp)],
     "mppi_world_destroy": [_vp],
     "mppi_world_get": [_vp, _f64p, C.c_int, _f64p, _f64p],

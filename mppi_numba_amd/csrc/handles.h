@@ -192,6 +192,17 @@ struct mppi_planner {
   int ktime_index = -1;
   // comm
   ncclComm_t comm = nullptr;
+  // The peer exchange (mppi_planner_p2p_*; update_kernels.h, PeerExchange): this rank's inbox -- fine-grained device
+  // memory the other ranks write into -- and the other ranks' inboxes as this device addresses them (peer access within
+  // one process, IPC handles across processes).  With it a sharded iteration of the time-parallel exact kernel is ONE
+  // launch and no collective; the last iteration of a call exchanges inside k_combine_tiles.
+  unsigned long long* inbox = nullptr;
+  unsigned long long* peer_inbox[kMaxFoldedRanks] = {};
+  bool peer_mapped[kMaxFoldedRanks] = {};  // opened with hipIpcOpenMemHandle: to be closed
+  const char* inbox_kind = "";  // how the inbox was allocated (diagnostic)
+  bool p2p_on = false;
+  int p2p_index = 0;  // exchanges so far: its parity picks the inbox set (the same on every rank)
+  uint64_t p2p_exchanges = 0;
   // CVaR mode with the M traction samples sharded over GPUs (mppi_planner_set_sample_sharding):
   // this handle rolls ALL N control samples over its cfg.num_grid_samples grids; the per-(n, m)
   // costs of all shards are all-gathered and every rank forms the CVaR of every control sample

@@ -410,6 +410,19 @@ static int materialize_noise(mppi_planner* p) {
   return MPPI_OK;
 }
 
+// this exchange's view of the inboxes; every exchange uses the other set
+static PeerExchange make_peer_exchange(mppi_planner* p) {
+  PeerExchange X;
+  memset(&X, 0, sizeof(X));
+  for (int g = 0; g < p->cfg.world_size; ++g) X.inbox[g] = p->peer_inbox[g];
+  X.world = p->cfg.world_size;
+  X.rank = p->cfg.rank;
+  X.set = p->p2p_index & 1;
+  ++p->p2p_index;
+  ++p->p2p_exchanges;
+  return X;
+}
+
 // One GPU: whether a rollout launch over `tiles` workgroups can combine its predecessor's tile packets itself
 // (update_kernels.h, PendingApply::reduce_tiles): step t in workgroup t, at most two steps per idle walker wave.
 static bool tiles_can_reduce(int tiles, int n_steps) { return 4 * tiles >= n_steps; }
@@ -457,7 +470,8 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
     pend.w_lo = a.wrange[0]; pend.w_hi = a.wrange[1];
   }
   if (p->reduce_pending) {
-    // one GPU: the previous launch's tile packets, reduced and applied by this launch (no update kernel ran)
+    // the previous launch's tile packets, combined and applied by this launch (no update kernel ran); several GPUs:
+    // with the peer exchange in between
     REQUIRE(plan.exact && !p->apply_pending, MPPI_ERR_STATE, "internal: tile packets left to a launch that cannot reduce them");
     REQUIRE(tiles_can_reduce(tiles, T) && plan.tile == p->scan_tile, MPPI_ERR_STATE, "internal: %d workgroups cannot combine the tile packets of %d steps", tiles, T);
     pend.packets = p->packets;  // (not read in this mode; non-null: "an update is pending")
@@ -466,6 +480,7 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
     pend.reduce_n_tiles = ceil_div(N, p->scan_tile);
     pend.published = p->published;
     pend.flag_set = p->reduce_index & 1;
+    if (p->p2p_on) pend.peers = make_peer_exchange(p);  // (advances the inbox set)
   }
   p->spec_launches += 1;
   // Exact kernel: where a tile whose vote fails is re-executed (rollout_scan_exact_kernel.h, scan_exact_reexecute):
@@ -1149,14 +1164,17 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
     // (graph replay: this launch also accounts for the iterations whose update ran inside a rollout launch)
     const unsigned long long bump = 1ull + (unsigned long long)p->bumps_owed;
     const float* tiles = p->tile_packets[p->tpk_cur];
+    PeerExchange peers;
+    memset(&peers, 0, sizeof(peers));
+    if (apply_here && p->p2p_on && p->cfg.world_size > 1) peers = make_peer_exchange(p);  // (exchanged inside the launch)
     if (apply_here)
       MPPI_KLAUNCH((k_combine_tiles<true>), grid, dim3(64), 0, p->stream, tiles, per_problem,
                    T, a.lambda_weight, my_packet, p->u, p->u_prev, (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0], a.vrange[1],
-                   a.wrange[0], a.wrange[1], p->stats, gen, bump, p->published);
+                   a.wrange[0], a.wrange[1], p->stats, gen, bump, p->published, peers);
     else
       MPPI_KLAUNCH((k_combine_tiles<false>), grid, dim3(64), 0, p->stream, tiles, per_problem,
                    T, a.lambda_weight, my_packet, p->u, p->u_prev, (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0], a.vrange[1],
-                   a.wrange[0], a.wrange[1], p->stats, gen, bump, p->published);
+                   a.wrange[0], a.wrange[1], p->stats, gen, bump, p->published, peers);
     if (p->graph_on) p->bumps_launched += bump;
     p->bumps_owed = 0;
     p->reduce_index = 0;  // (the flags are all clear again)
@@ -1219,12 +1237,20 @@ static bool next_rollout_applies_updates(const mppi_planner* p) {
          p->cfg.world_size <= kMaxFoldedRanks && p->cfg.mode == MPPI_MODE_DET && !p->mirror_now && scan_plan(p, nullptr);
 }
 
-// One GPU: whether the NEXT rollout launch can reduce and apply the tile packets of this one (no update kernel).
+// Several GPUs without a collective: the peer exchange is connected and the kernels that carry it will run (the
+// time-parallel exact kernel leaves tile packets; one problem per handle).  Decided from things every rank has alike.
+static bool p2p_usable(const mppi_planner* p) {
+  ScanPlan plan;
+  return p->p2p_on && p->cfg.world_size > 1 && p->cfg.world_size <= kMaxFoldedRanks && p->B == 1 && !p->inst_set &&
+         p->m_count == 1 && p->cfg.mode == MPPI_MODE_DET && scan_plan(p, &plan) && plan.exact;
+}
+
+// Whether the NEXT rollout launch can combine and apply the tile packets of this one (no update kernel).
 static bool next_rollout_reduces_tiles(const mppi_planner* p) {
   static const bool disabled = getenv("MPPI_NO_REDUCE_FOLD") != nullptr;  // developer switch (ablation)
   ScanPlan plan;
   return !disabled && !(p->debug_flags & (MPPI_DEBUG_NO_FOLDED_APPLY | MPPI_DEBUG_NO_REDUCE_FOLD)) && p->B == 1 && !p->inst_set &&
-         p->m_count == 1 && p->cfg.world_size == 1 && !p->comm && p->cfg.mode == MPPI_MODE_DET && !p->mirror_now &&
+         p->m_count == 1 && ((p->cfg.world_size == 1 && !p->comm) || p2p_usable(p)) && p->cfg.mode == MPPI_MODE_DET && !p->mirror_now &&
          scan_plan(p, &plan) && plan.exact && plan.tile == p->scan_tile &&
          tiles_can_reduce(ceil_div(p->n_local, plan.tile), p->cfg.num_steps);
 }
@@ -1245,7 +1271,7 @@ static int launch_update(mppi_planner* p, bool prof, bool defer_exchange = false
   if (defer_exchange) return launch_update_local(p, false);
   // (a communicator on a single rank is honoured too: it exercises the same path as N ranks)
   // (samples sharded: every rank holds all N costs and all the noise -- the update is local)
-  if ((p->cfg.world_size == 1 && !p->comm) || p->m_count > 1) {
+  if ((p->cfg.world_size == 1 && !p->comm) || p->m_count > 1 || (p2p_usable(p) && p->scan_packets_fresh)) {
     if (may_leave_apply && !prof && p->scan_packets_fresh && next_rollout_reduces_tiles(p)) {
       // the next rollout launch reduces this one's tile packets and applies the update itself: no launch here
       p->scan_packets_fresh = false;
@@ -1388,6 +1414,7 @@ static void graph_signature(const mppi_planner* p, const DevParams& d, const mpp
   sig.epoch_bias = p->noise_epoch - p->bumps_launched;
   sig.noise_cur = p->noise_cur; sig.inst_set = p->inst_set; sig.want_sample_costs = p->want_sample_costs;
   sig.speculation_off = p->speculation_off ? 1 : 0; sig.debug_flags = p->debug_flags;
+  sig.pad = (p->p2p_on ? 2 : 0) | (p->p2p_index & 1);  // (the inbox set of the peer exchange is a by-value argument)
   out.assign(reinterpret_cast<unsigned char*>(&sig), reinterpret_cast<unsigned char*>(&sig) + sizeof(sig));
 }
 

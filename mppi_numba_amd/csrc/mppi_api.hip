@@ -461,6 +461,9 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   (void)hipSetDevice(p->cfg.device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   if (p->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(p->comm);
+  for (int g = 0; g < kMaxFoldedRanks; ++g)
+    if (p->peer_mapped[g] && p->peer_inbox[g]) (void)hipIpcCloseMemHandle(p->peer_inbox[g]);
+  if (p->inbox) (void)hipFree(p->inbox);
   dev_free(p->inst_dev);
   if (p->u_host) (void)hipHostFree(p->u_host);
   if (p->u_stage) (void)hipHostFree(p->u_stage);
@@ -1595,6 +1598,139 @@ extern "C" int mppi_group_iterate_async(mppi_planner** ps, mppi_tdm** lins, mppi
     p->elapsed_pending = true;
     p->last_iterations = iterations;
   }
+  return MPPI_OK;
+}
+
+// ---- the peer exchange (include/mppi_hip.h; update_kernels.h: PeerExchange) -----------------------------------
+static int p2p_alloc_inbox(mppi_planner* p, hipIpcMemHandle_t* handle) {
+  if (p->inbox) {
+    if (handle) HIP_TRY(hipIpcGetMemHandle(handle, p->inbox));
+    return MPPI_OK;
+  }
+  REQUIRE(p->cfg.world_size <= kMaxFoldedRanks, MPPI_ERR_INVALID, "the peer exchange serves up to %d ranks", kMaxFoldedRanks);
+  const size_t bytes = sizeof(unsigned long long) * inbox_words(p->cfg.world_size, p->cfg.num_steps);
+  // fine-grained memory: the peers' stores must be seen by kernels that are already running here.  (Uncached, then
+  // ordinary memory as fall-backs where the runtime will not export the former between processes: on ONE device --
+  // several ranks sharing a GPU, the test set-up -- device-scope coherence is enough.)
+  struct Kind { unsigned flags; const char* name; bool ext; };
+  const Kind kinds[] = {{hipDeviceMallocFinegrained, "fine-grained", true}, {hipDeviceMallocUncached, "uncached", true}, {0u, "coarse-grained", false}};
+  for (const Kind& k : kinds) {
+    void* ptr = nullptr;
+    hipError_t e = k.ext ? hipExtMallocWithFlags(&ptr, bytes, k.flags) : hipMalloc(&ptr, bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); continue; }
+    hipIpcMemHandle_t h;
+    if (handle && hipIpcGetMemHandle(&h, ptr) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipFree(ptr);
+      continue;
+    }
+    if (handle) *handle = h;
+    p->inbox = static_cast<unsigned long long*>(ptr);
+    p->inbox_kind = k.name;
+    HIP_TRY(hipMemset(p->inbox, 0, bytes));
+    return MPPI_OK;
+  }
+  return fail(MPPI_ERR_HIP, "could not allocate an exportable inbox for the peer exchange");
+}
+
+extern "C" int mppi_planner_p2p_export(mppi_planner* p, char handle[MPPI_P2P_HANDLE_BYTES]) {
+  static_assert(sizeof(hipIpcMemHandle_t) <= MPPI_P2P_HANDLE_BYTES, "hipIpcMemHandle_t larger than expected");
+  REQUIRE(p && handle, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(p->cfg.mode == MPPI_MODE_DET && p->B == 1, MPPI_ERR_INVALID, "the peer exchange serves single-problem deterministic-dynamics handles");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  hipIpcMemHandle_t h;
+  TRY(p2p_alloc_inbox(p, &h));
+  memset(handle, 0, MPPI_P2P_HANDLE_BYTES);
+  memcpy(handle, &h, sizeof(h));
+  return MPPI_OK;
+}
+
+static void p2p_disconnect(mppi_planner* p) {
+  for (int g = 0; g < kMaxFoldedRanks; ++g) {
+    if (p->peer_mapped[g] && p->peer_inbox[g]) (void)hipIpcCloseMemHandle(p->peer_inbox[g]);
+    p->peer_inbox[g] = nullptr;
+    p->peer_mapped[g] = false;
+  }
+  p->p2p_on = false;
+}
+
+extern "C" int mppi_planner_p2p_connect(mppi_planner* p, const char* handles, int count) {
+  REQUIRE(p && handles, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(count == p->cfg.world_size, MPPI_ERR_INVALID, "expected the inbox handles of %d ranks, got %d", p->cfg.world_size, count);
+  REQUIRE(p->inbox, MPPI_ERR_STATE, "call mppi_planner_p2p_export first");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p2p_disconnect(p);
+  drop_graphs(p);
+  for (int g = 0; g < count; ++g) {
+    if (g == p->cfg.rank) {
+      p->peer_inbox[g] = p->inbox;
+      continue;
+    }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handles + (size_t)g * MPPI_P2P_HANDLE_BYTES, sizeof(h));
+    void* ptr = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      p2p_disconnect(p);
+      return fail(MPPI_ERR_HIP, "hipIpcOpenMemHandle(rank %d's inbox) failed: %s", g, hipGetErrorString(e));
+    }
+    p->peer_inbox[g] = static_cast<unsigned long long*>(ptr);
+    p->peer_mapped[g] = true;
+  }
+  p->p2p_on = true;
+  p->p2p_index = 0;
+  return MPPI_OK;
+}
+
+// one process, several devices: the handles' inboxes addressed directly (peer access)
+extern "C" int mppi_group_p2p_connect(mppi_planner** ps, int count) {
+  REQUIRE(ps && count >= 1 && count <= kMaxFoldedRanks, MPPI_ERR_INVALID, "bad group of %d", count);
+  for (int g = 0; g < count; ++g) {
+    REQUIRE(ps[g] && ps[g]->cfg.world_size == count && ps[g]->cfg.rank == g, MPPI_ERR_INVALID, "planner %d is not rank %d of %d", g, g, count);
+    HIP_TRY(hipSetDevice(ps[g]->cfg.device));
+    TRY(p2p_alloc_inbox(ps[g], nullptr));
+  }
+  for (int g = 0; g < count; ++g) {
+    mppi_planner* p = ps[g];
+    HIP_TRY(hipSetDevice(p->cfg.device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p2p_disconnect(p);
+    drop_graphs(p);
+    for (int q = 0; q < count; ++q) {
+      if (ps[q]->cfg.device != p->cfg.device) {
+        int can = 0;
+        HIP_TRY(hipDeviceCanAccessPeer(&can, p->cfg.device, ps[q]->cfg.device));
+        REQUIRE(can, MPPI_ERR_HIP, "device %d cannot access device %d", p->cfg.device, ps[q]->cfg.device);
+        hipError_t e = hipDeviceEnablePeerAccess(ps[q]->cfg.device, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e);
+        (void)hipGetLastError();
+      }
+      p->peer_inbox[q] = ps[q]->inbox;
+    }
+    p->p2p_on = true;
+    p->p2p_index = 0;
+  }
+  return MPPI_OK;
+}
+
+// (measurements: the same handle with the exchange switched off falls back to its communicator; all ranks alike)
+extern "C" int mppi_planner_p2p_set_enabled(mppi_planner* p, int enabled) {
+  REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
+  REQUIRE(!enabled || (p->inbox && p->peer_inbox[p->cfg.rank]), MPPI_ERR_STATE, "the peer exchange is not connected");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  drop_graphs(p);
+  p->p2p_on = enabled != 0;
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_p2p_stats(mppi_planner* p, int* connected, long* exchanges, char* kind, int capacity) {
+  REQUIRE(p && connected && exchanges, MPPI_ERR_INVALID, "NULL argument");
+  *connected = p->p2p_on ? 1 : 0;
+  *exchanges = (long)p->p2p_exchanges;
+  if (kind && capacity > 0) snprintf(kind, (size_t)capacity, "%s", p->inbox_kind);
   return MPPI_OK;
 }
 

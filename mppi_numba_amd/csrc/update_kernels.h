@@ -53,6 +53,19 @@ __device__ __forceinline__ void apply_update(float2* u, float2* u_prev, float2* 
 // workgroup also stores the sequence, into the OTHER control buffer (the rest of the grid is still
 // reading the old one).  packets == nullptr: nothing pending, u is read as it is.
 constexpr int kMaxFoldedRanks = 16;
+
+// The peer exchange (no RCCL on the iteration's path).  Every rank owns an INBOX in fine-grained device memory:
+// [2 sets][world][T steps][8 words]; rank g's numbers for step t -- the doubles beta_g, den_g, num_g[t].x, num_g[t].y of
+// its packet (packet_len) -- arrive as eight 8-byte words {uint32 half of a double; uint32 1}: each word carries its
+// own flag, so nothing orders them and nobody fences.  Set `set` is used by this exchange; the reader clears the
+// words of the OTHER set for its step before it sends (the peers write that set only after they have received what
+// is sent after the clearing).  world <= kMaxFoldedRanks.
+struct PeerExchange {
+  unsigned long long* inbox[kMaxFoldedRanks];  // every rank's inbox as THIS device addresses it; [rank] is the own one
+  int world, rank, set;                        // world == 0: no exchange
+};
+__host__ __device__ inline size_t inbox_words(int world, int n_steps) { return (size_t)2 * world * n_steps * 8; }
+
 struct PendingApply {
   const double* packets;  // [world][stride] as all-gathered; nullptr: none (or: see reduce_tiles)
   float2* u_out;          // the other control buffer
@@ -71,6 +84,11 @@ struct PendingApply {
   int reduce_n_tiles;
   unsigned long long* published;    // [2][T][kPublishedStride] words, two used per step
   int flag_set;
+  // Several GPUs in that mode (round 4, the peer exchange): the workgroup that has combined the LOCAL tiles for
+  // step t writes this rank's four numbers for that step -- beta_g, den_g, num_g[t] -- straight into every rank's
+  // inbox (peer access / IPC-mapped fine-grained memory: xGMI on a multi-GPU node) and waits for the other ranks'
+  // numbers for the same step in its own, before it forms and publishes u[t]: no collective, no extra launch.
+  PeerExchange peers;
 };
 
 // ---- tile packets of the time-parallel kernels (rollout_scan*.h), tile-major ------------------------------
@@ -171,6 +189,76 @@ __device__ __forceinline__ StepSums combine_step(const float* __restrict__ tile_
                              lambda, lane);
 }
 
+// One wave, after it has combined the local tiles for step t: send, receive, and combine over the ranks with
+// k_apply's expressions in k_apply's order (the bits of the all-gather + k_apply path).  Returns the sums of the whole
+// job in S (beta as double in *beta_out).  Bounded polls: a rank that never sends (a dead peer) traps this kernel after
+// about two seconds instead of hanging the device.
+__device__ __forceinline__ StepSums exchange_step(const PeerExchange& X, const StepSums& mine, int t, int n_steps, float lambda,
+                                                  int lane, double* beta_out) {
+  const size_t set_words = (size_t)X.world * n_steps * 8;
+  unsigned long long* own = X.inbox[X.rank];
+  // clear the other set's words for this step (all ranks' slots), then make sure that is done before anything is sent
+  {
+    unsigned long long* other = own + (size_t)(X.set ^ 1) * set_words;
+    for (int i = lane; i < 8 * X.world; i += 64)
+      __hip_atomic_store(other + ((size_t)(i >> 3) * n_steps + t) * 8 + (i & 7), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  // this rank's eight words: lane i < 8 holds word i
+  const double vals[4] = {(double)mine.beta, mine.den, mine.nx, mine.ny};
+  unsigned long long word = 0ull;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[k]);
+    if (lane == 2 * k) word = (1ull << 32) | (bits >> 32);
+    if (lane == 2 * k + 1) word = (1ull << 32) | (bits & 0xffffffffull);
+  }
+  const size_t slot = ((size_t)X.set * X.world + X.rank) * n_steps + t;  // (the same place in every inbox)
+  for (int q = 0; q < X.world; ++q)
+    if (lane < 8) __hip_atomic_store(X.inbox[q] + slot * 8 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // receive: lane i polls word i & 7 of rank i >> 3 (and of rank 8 + (i >> 3) when there are more than 8)
+  unsigned long long got[2] = {0ull, 0ull};
+  const unsigned long long* in = own + (size_t)X.set * set_words;
+  for (int polls = 0;; ++polls) {
+    bool all_there = true;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = 8 * h + (lane >> 3);
+      if (q < X.world && (got[h] >> 32) == 0ull) {
+        got[h] = __hip_atomic_load(const_cast<unsigned long long*>(in) + ((size_t)q * n_steps + t) * 8 + (lane & 7), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_SYSTEM);
+        all_there = all_there && (got[h] >> 32) != 0ull;
+      }
+    }
+    if (__all(all_there)) break;
+    if (polls > (1 << 21)) __builtin_trap();
+    __builtin_amdgcn_s_sleep(2);
+  }
+  // k_apply's lines over the ranks' numbers (wave-uniform: every lane computes the same)
+  auto number = [&](int q, int k) {  // double k of rank q
+    const unsigned int src = (q >= 8 ? got[1] : got[0]) & 0xffffffffu;
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)src, 8 * (q & 7) + 2 * k);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)src, 8 * (q & 7) + 2 * k + 1);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  };
+  double beta = number(0, 0);
+  for (int q = 1; q < X.world; ++q) beta = fmin(beta, number(q, 0));
+  const double neg_inv_lambda = -1.0 / (double)lambda;
+  StepSums S;
+  S.den = 0.0;
+  S.nx = 0.0;
+  S.ny = 0.0;
+  for (int q = 0; q < X.world; ++q) S.den += exp(neg_inv_lambda * (number(q, 0) - beta)) * number(q, 1);
+  for (int q = 0; q < X.world; ++q) {
+    const double sg = exp(neg_inv_lambda * (number(q, 0) - beta));
+    S.nx = fma(sg, number(q, 2), S.nx);
+    S.ny = fma(sg, number(q, 3), S.ny);
+  }
+  S.beta = (float)beta;
+  *beta_out = beta;
+  return S;
+}
+
 // The published sequence: the two words of step t, {float u.x; uint32 1} {float u.y; uint32 1}, sit 4 KiB apart
 // from the next step's -- 256 workgroups poll them while ~100 publish: next to each other they are one hot spot of
 // a dozen cache lines behind one memory channel.
@@ -182,8 +270,10 @@ __device__ __forceinline__ unsigned long long published_word(float v) {
 
 // PendingApply::reduce_tiles, one wave of workgroup `tile`: step t of the update -> both published words (and the
 // handle's other control buffer, u_prev, the update's {beta, den}); the words of the other set are cleared
-__device__ __forceinline__ void publish_step(const PendingApply& A, const StepSums& S, float2 u_old, int t, int n_steps,
+__device__ __forceinline__ void publish_step(const PendingApply& A, StepSums S, float2 u_old, int t, int n_steps,
                                              int lane) {
+  double beta = (double)S.beta;
+  if (A.peers.world > 0) S = exchange_step(A.peers, S, t, n_steps, A.lambda, lane, &beta);
   if (lane == 0) {
     const float2 ut = updated_control(u_old, S.nx, S.ny, S.den, A.v_lo, A.v_hi, A.w_lo, A.w_hi);
     unsigned long long* mine = A.published + ((size_t)A.flag_set * n_steps + t) * kPublishedStride;
@@ -195,7 +285,7 @@ __device__ __forceinline__ void publish_step(const PendingApply& A, const StepSu
     A.u_out[t] = ut;
     A.u_prev[t] = ut;
     if (t == 0) {
-      A.stats[0] = (double)S.beta;
+      A.stats[0] = beta;
       A.stats[1] = S.den;
     }
   }
@@ -461,7 +551,7 @@ __global__ __launch_bounds__(64) void k_combine_tiles(const float* __restrict__ 
                                                       float w_lo, float w_hi, double* __restrict__ stats,
                                                       unsigned long long* __restrict__ gen_counter,
                                                       unsigned long long gen_bump,
-                                                      unsigned long long* __restrict__ published) {
+                                                      unsigned long long* __restrict__ published, PeerExchange peers) {
   if (gen_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *gen_counter += gen_bump;
   const int t = blockIdx.x, inst = blockIdx.y, lane = threadIdx.x;
   if (published && inst == 0 && lane < 4) published[((size_t)(lane >> 1) * n_steps + t) * kPublishedStride + (lane & 1)] = 0ull;
@@ -476,7 +566,10 @@ __global__ __launch_bounds__(64) void k_combine_tiles(const float* __restrict__ 
   if (u_mirror) u_mirror += (size_t)inst * n_steps;
   stats += 2 * inst;
   const float2 u_old = APPLY ? u[t] : make_float2(0.0f, 0.0f);
-  const StepSums S = combine_step(tile_packets, n_tiles, stride, t, lambda, lane);
+  StepSums S = combine_step(tile_packets, n_tiles, stride, t, lambda, lane);
+  double beta64 = (double)S.beta;
+  // (several GPUs, peer exchange: the last iteration of a loop exchanges here and applies: no collective)
+  if (APPLY && peers.world > 0) S = exchange_step(peers, S, t, n_steps, lambda, lane, &beta64);
   MPPI_STAMP(stamp_wg, stamp_base + 3);
   if (lane == 0) {
     if (APPLY) {
@@ -489,9 +582,9 @@ __global__ __launch_bounds__(64) void k_combine_tiles(const float* __restrict__ 
       rank_packet[3 + 2 * t] = S.ny;
     }
     if (t == 0) {
-      rank_packet[0] = (double)S.beta;
+      rank_packet[0] = beta64;
       rank_packet[1] = S.den;
-      stats[0] = (double)S.beta;
+      stats[0] = beta64;
       stats[1] = S.den;
     }
   }

@@ -480,6 +480,28 @@ class MPPI_Numba(object):
         _lib.call("mppi_planner_comm_count", self._handle, C.byref(n))
         return int(n.value)
 
+    # multi-GPU without a collective: the peer exchange (include/mppi_hip.h)
+    def p2p_export(self):
+        """This rank's inbox as an opaque handle (bytes) for the other ranks' p2p_connect."""
+        buf = C.create_string_buffer(_lib.P2P_HANDLE_BYTES)
+        _lib.call("mppi_planner_p2p_export", self._handle, buf)
+        return bytes(buf.raw)
+
+    def p2p_connect(self, handles):
+        """The inbox handles of ALL ranks in rank order (p2p_export of each; the own one is ignored)."""
+        raw = b"".join(bytes(h) for h in handles)
+        assert len(raw) == _lib.P2P_HANDLE_BYTES * len(handles)
+        _lib.call("mppi_planner_p2p_connect", self._handle, C.c_char_p(raw), len(handles))
+
+    def p2p_enable(self, enabled=True):
+        """Switch a connected peer exchange off / on (off: the communicator's all-gather); all ranks alike."""
+        _lib.call("mppi_planner_p2p_set_enabled", self._handle, int(bool(enabled)))
+
+    def p2p_stats(self):
+        on, count, kind = C.c_int(0), C.c_long(0), C.create_string_buffer(32)
+        _lib.call("mppi_planner_p2p_stats", self._handle, C.byref(on), C.byref(count), kind, 32)
+        return dict(connected=bool(on.value), exchanges=int(count.value), inbox=kind.value.decode())
+
     def update_local(self):
         n = C.c_int(0)
         _lib.call("mppi_planner_packet_len", self._handle, C.byref(n))

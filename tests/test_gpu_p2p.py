@@ -1,0 +1,51 @@
+"""The peer exchange (include/mppi_hip.h: mppi_planner_p2p_*; update_kernels.h: PeerExchange): control samples
+sharded over ranks WITHOUT a collective -- every rank writes its numbers for step t of an update straight into its
+peers' inboxes (IPC-mapped fine-grained device memory) from inside the rollout launch that applies the update, so a
+sharded iteration is one launch.  On this box the ranks are processes that share the one GPU and reach each other
+through IPC handles: the one-process-per-GPU set-up minus xGMI.  The control sequence must have the BITS of the
+all-gather + k_apply path (here: packets staged through the host hub), on every rank and between the ranks
+(update_useq_numba mppi.py:1113-1191)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_ranks(*args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MPPI_RDZV_FILE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "p2p_ranks.py")] + list(args), capture_output=True,
+                         text=True, timeout=timeout, env=env, cwd=ROOT)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("P2P_")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-1500:], out.stderr[-1500:])
+    return lines[0]
+
+
+@pytest.mark.parametrize("ranks,n,t,iterations", [(2, 1024, 100, 6), (2, 4096, 100, 5), (3, 2048, 64, 4), (8, 512, 60, 7)])
+def test_ranks_sharing_the_device_through_ipc_have_the_bits_of_the_k_apply_loop(ranks, n, t, iterations):
+    line = run_ranks("--ranks", str(ranks), "--n", str(n), "--t", str(t), "--iterations", str(iterations))
+    print("\n" + line)
+    assert line.startswith("P2P_OK") and "world=%d" % ranks in line, line
+    assert "k_rollout_scan_exact+reduces_tiles" in line, line   # (the exchange ran inside the rollout launches)
+    assert "max|du|=0.000e+00" in line, line
+
+
+def test_bench_line_with_the_peer_exchange():
+    """bench.py --gpus 2: both exchanges are tried; two ranks on one device cannot have an RCCL communicator, so the
+    line is the peer exchange's and says so."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MPPI_RDZV_FILE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "2048", "--steps", "20",
+                          "--warmup", "5", "--regions", "2", "--no-cpu-baseline"], capture_output=True, text=True,
+                         timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    cfg = res["config"]
+    assert res["n_gpus"] == 2 and cfg["global_rollouts"] == 4096
+    assert cfg["exchange"].startswith("peer exchange"), cfg["exchange"]
+    assert set(cfg["exchange_us_per_step"]) == {"p2p"} and cfg["exchange_us_per_step"]["p2p"] > 0
+    assert "reduces_tiles=1" in cfg["rollout_kernel"] and res["roofline"]["frac"] > 0
+    assert res["ms_per_step"] < 0.2   # (the host-staged exchange is ~0.2 ms per step, the peer exchange ~0.02)
