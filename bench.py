@@ -387,6 +387,13 @@ def main():
             group = MPPI_Group(cfgs)
             group.setup(params, lins, angs)
             planner = group.planners[0]
+            if args.exchange in ("auto", "p2p"):
+                try:  # the peer exchange between the devices of this process (peer access)
+                    group.connect_peers()
+                    args.exchange = "p2p"
+                except Exception as e:
+                    print("bench.py: peer exchange unavailable in the device group (%s): RCCL" % e, file=sys.stderr)
+                    args.exchange = "rccl"
         elif by_samples:
             planner = MPPI_Numba(cfg, sample_shard=shard)
             planner.setup(params, lin, ang)

@@ -1552,6 +1552,20 @@ extern "C" int mppi_group_comm_init(mppi_planner** ps, int count) {
 extern "C" int mppi_group_iterate_async(mppi_planner** ps, mppi_tdm** lins, mppi_tdm** angs, int count,
                                         int iterations) {
   REQUIRE(ps && lins && angs && count >= 1 && iterations >= 0, MPPI_ERR_INVALID, "bad arguments");
+  {
+    // The peer exchange connected on every handle (mppi_group_p2p_connect) and usable by the kernels that will run:
+    // nothing to coordinate on the host -- each device's loop is enqueued as if it were alone, the launches wait for
+    // each other's numbers on the devices.  (Decided alike for all: they share sizes, mode and maps.)
+    bool all_p2p = count > 1;
+    for (int g = 0; g < count && all_p2p; ++g) all_p2p = ps[g] && ps[g]->params_set && p2p_usable(ps[g]);
+    if (all_p2p) {
+      for (int g = 0; g < count; ++g) {
+        HIP_TRY(hipSetDevice(ps[g]->cfg.device));
+        TRY(run_iterations(ps[g], lins[g], angs[g], iterations));
+      }
+      return MPPI_OK;
+    }
+  }
   std::vector<DevParams> d((size_t)count);
   std::vector<char> have((size_t)count);
   for (int g = 0; g < count; ++g) {

@@ -573,6 +573,12 @@ class MPPI_Group(object):
             _lib.call("mppi_group_comm_init", handles, self.world_size)
             self._comm = True
 
+    def connect_peers(self):
+        """The peer exchange between the group's devices (peer access; include/mppi_hip.h): iterations of the
+        time-parallel exact kernel then need neither RCCL nor a launch of their own for the update."""
+        handles = (C.c_void_p * self.world_size)(*[p._handle for p in self.planners])
+        _lib.call("mppi_group_p2p_connect", handles, self.world_size)
+
     def _arrays(self):
         mk = lambda hs: (C.c_void_p * self.world_size)(*hs)
         return (mk([p._handle for p in self.planners]), mk([p.lin_tdm._handle for p in self.planners]),

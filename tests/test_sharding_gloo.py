@@ -175,3 +175,98 @@ def test_shard_ranges_cover_all_rollouts():
         for r in range(world):
             seen[r * (n // world):(r + 1) * (n // world)] += 1
         assert (seen == 1).all()
+
+
+# ---- the peer exchange (update_kernels.h: PeerExchange / exchange_step), restated ------------------------------
+def words_of(values):
+    """Four doubles -> eight 8-byte words {uint32 half; uint32 1}: every word carries its own flag."""
+    bits = np.asarray(values, dtype=np.float64).view(np.uint64)
+    out = np.empty(8, dtype=np.uint64)
+    out[0::2] = (np.uint64(1) << np.uint64(32)) | (bits >> np.uint64(32))
+    out[1::2] = (np.uint64(1) << np.uint64(32)) | (bits & np.uint64(0xffffffff))
+    return out
+
+
+def doubles_of(words):
+    assert ((words >> np.uint64(32)) == 1).all(), "a word that has not arrived"
+    half = words & np.uint64(0xffffffff)
+    return ((half[0::2] << np.uint64(32)) | half[1::2]).view(np.float64)
+
+
+def _peer_worker(rank, world, port, q):
+    """Two ranks, every step of every iteration exchanged separately through per-rank inboxes [2 sets][world][T][8]
+    (gloo send / recv stand in for the stores into the peer's memory): the reader clears the other set's slots of
+    the step before it sends, the numbers are combined with k_apply's expressions.  Must equal the all-gather of
+    whole packets + apply_packets, bit for bit, over several iterations (both sets in use)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from helpers import golden, iterations, params_from_golden
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        checked = 0
+        g = golden("det_cvar")
+        P = params_from_golden(g)
+        its = iterations(g)
+        t_steps = its[0]["u_in"].shape[0]
+        inbox = np.zeros((2, world, t_steps, 8), dtype=np.uint64)
+        exchange = 0
+        for rep in range(3):
+            for it in its:
+                n = it["costs"].shape[0]
+                lo, hi = rank * n // world, (rank + 1) * n // world
+                packet = local_packet(it["costs"][lo:hi], it["noise"][lo:hi], P["lambda_weight"])
+                s = exchange & 1
+                exchange += 1
+                u = np.empty_like(it["u_in"], dtype=np.float32)
+                for t in range(t_steps):
+                    inbox[s ^ 1, :, t, :] = 0  # (cleared before anything is sent for this step)
+                    mine = words_of([packet[0], packet[1], packet[2 + 2 * t], packet[3 + 2 * t]])
+                    inbox[s, rank, t] = mine
+                    for peer in range(world):
+                        if peer == rank:
+                            continue
+                        got = torch.zeros(8, dtype=torch.int64)
+                        reqs = [dist.isend(torch.from_numpy(mine.view(np.int64).copy()), peer), dist.irecv(got, peer)]
+                        for r in reqs:
+                            r.wait()
+                        assert (inbox[s, peer, t] == 0).all(), "slot not cleared"
+                        inbox[s, peer, t] = got.numpy().view(np.uint64)
+                    rows = np.stack([doubles_of(inbox[s, g_, t]) for g_ in range(world)])  # beta, den, nx, ny per rank
+                    step_packets = np.concatenate([rows[:, :2], rows[:, 2:]], axis=1)
+                    u[t] = apply_packets(step_packets, P["lambda_weight"], it["u_in"][t:t + 1], P["vrange"], P["wrange"])[0]
+                gathered = [torch.zeros(packet.size, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(gathered, torch.from_numpy(packet))
+                want = apply_packets(np.stack([x.numpy() for x in gathered]), P["lambda_weight"], it["u_in"], P["vrange"], P["wrange"])
+                np.testing.assert_array_equal(u, want)
+                checked += 1
+        q.put((rank, checked))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_exchange_words_and_inbox_sets_over_gloo_world2():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_peer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(checked >= 3 for _, checked in results), results
+
+
+def test_words_round_trip_every_bit_pattern_class():
+    vals = np.array([0.0, -0.0, 1.0, -1.5e-300, 3.141592653589793e200, np.float64(np.float32(13000.25)), 5e-324, -7.25])
+    for i in range(0, len(vals), 4):
+        four = vals[i:i + 4]
+        np.testing.assert_array_equal(doubles_of(words_of(four)).view(np.uint64), four.view(np.uint64))
