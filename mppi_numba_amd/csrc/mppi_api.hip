@@ -1233,6 +1233,9 @@ extern "C" int mppi_planner_update_apply_and_rollout(mppi_planner* p, const doub
   REQUIRE(p && packets, MPPI_ERR_INVALID, "NULL argument");
   REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
   REQUIRE(count == p->cfg.world_size, MPPI_ERR_INVALID, "expected %d packets, got %d", p->cfg.world_size, count);
+  // (control samples sharded; a handle whose traction SAMPLES are sharded exchanges cost slabs, not packets:
+  //  mppi_planner_rollout / sample_costs_local / sample_costs_apply / update)
+  REQUIRE(p->m_count == 1, MPPI_ERR_STATE, "update_apply_and_rollout serves handles that shard their control samples");
   HIP_TRY(hipSetDevice(p->cfg.device));
   TRY(check_tdms(p, lin, ang));
   TRY(ensure_packed(p, lin, ang));
@@ -1243,8 +1246,12 @@ extern "C" int mppi_planner_update_apply_and_rollout(mppi_planner* p, const doub
   // the rollout launch applies the update when it is one that can (launch_rollout settles it otherwise)
   if (next_rollout_applies_updates(p)) p->apply_pending = true;
   else TRY(launch_apply(p));
-  TRY(launch_rollout(p, d));
-  REQUIRE(!p->apply_pending, MPPI_ERR_STATE, "internal: the update was left unapplied");
+  const int rc = launch_rollout(p, d);
+  if (p->apply_pending) {  // (the rollout launch failed before it could take the packets: the update must not be lost)
+    const int ra = launch_apply(p);
+    if (rc == MPPI_OK) TRY(ra);
+  }
+  TRY(rc);
   HIP_TRY(hipStreamSynchronize(p->stream));
   return MPPI_OK;
 }

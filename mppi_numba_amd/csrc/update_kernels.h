@@ -8,9 +8,14 @@
 //                   den and num[t] in float64; applies the update (one GPU) or writes the
 //                   rank packet {beta, den, num[T][2]} for the all-gather (several)
 //   k_apply         grid 1: combine the packets of all GPUs, u += num/den, clip
-// Everything is a deterministic tree (no atomics): the same inputs give the
-// same bits on every run, and the result does not depend on the GPU count
-// beyond float64 rounding of the partial sums.
+// Everything is a deterministic tree (no atomics): the same inputs give the same bits on every run.  What IS
+// bit-identical to the reference are the COSTS; u is held to 1e-5 of the control range (north_star's bound; the
+// reference's own update is unordered float32 atomics), and its last bits follow the summation tree: the tiles of
+// the rollout kernel that ran (64 rollouts; 32 for the time-parallel kernels, whose weights go through v_exp_f32 and
+// whose tile sums are float32 fma chains) and the shards of a multi-GPU run (float64 partial sums per rank).  For a
+// given kernel family and GPU count every path to u -- update launch, next-launch fold, all-gather + k_apply, peer
+// exchange -- runs the same expressions in the same order and gives the same bits (tests/test_gpu_reduce_fold.py,
+// tests/test_gpu_p2p.py, tests/test_gpu_multi.py).
 //
 // Exactness of the split across GPUs: with beta = min_g beta_g,
 //   sum_n exp(-(c_n-beta)/l) x_n = sum_g exp(-(beta_g-beta)/l) * sum_{n in g} exp(-(c_n-beta_g)/l) x_n

@@ -132,7 +132,10 @@ def _encode(obj, out):
         raise TypeError("hub: values of type %s are not exchanged" % type(obj).__name__)
 
 
-def _decode(buf, at=0):
+_MAX_DEPTH = 8  # what crosses the hub is at most a list of lists of arrays
+
+
+def _decode(buf, at=0, depth=0):
     import numpy as np
     tag = buf[at:at + 1]
     at += 1
@@ -150,21 +153,24 @@ def _decode(buf, at=0):
         if len(raw) != n:
             raise ValueError("hub: truncated message")
         return (raw if tag == b"B" else raw.decode("utf-8")), at + 4 + n
-    if tag == b"L":
+    if tag in (b"L", b"D"):
+        if depth >= _MAX_DEPTH:
+            raise ValueError("hub: message nested too deeply")
         (n,) = struct.unpack_from("<I", buf, at)
         at += 4
+        if n > len(buf) - at:  # (every item takes at least one byte)
+            raise ValueError("hub: malformed container")
+    if tag == b"L":
         items = []
         for _ in range(n):
-            item, at = _decode(buf, at)
+            item, at = _decode(buf, at, depth + 1)
             items.append(item)
         return items, at
     if tag == b"D":
-        (n,) = struct.unpack_from("<I", buf, at)
-        at += 4
         items = {}
         for _ in range(n):
-            key, at = _decode(buf, at)
-            items[key], at = _decode(buf, at)
+            key, at = _decode(buf, at, depth + 1)
+            items[key], at = _decode(buf, at, depth + 1)
         return items, at
     if tag == b"A":
         code, ndim = struct.unpack_from("<BB", buf, at)
@@ -195,7 +201,7 @@ def _send(sock, obj):
     sock.sendall(struct.pack("<Q", len(blob)) + blob)
 
 
-def _recv(sock):
+def _recv(sock, max_bytes=_MAX_MESSAGE):
     def exactly(n):
         buf = bytearray()
         while len(buf) < n:
@@ -205,7 +211,7 @@ def _recv(sock):
             buf += chunk
         return bytes(buf)
     (n,) = struct.unpack("<Q", exactly(8))
-    if n > _MAX_MESSAGE:
+    if n > max_bytes:
         raise ValueError("hub: message of %d bytes refused" % n)
     value, end = _decode(exactly(n))
     if end != n:
@@ -265,12 +271,14 @@ class Hub:
                 conn, _ = srv.accept()
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 conn.settimeout(timeout)
-                try:  # the first message must be [token, rank]; anything else is not one of ours
-                    hello = _recv(conn)
+                try:
+                    # the first message must be [token, rank] -- a couple of hundred bytes; whoever connects without the
+                    # token gets nothing decoded beyond that (no large allocation, no deep nesting) and is dropped
+                    hello = _recv(conn, max_bytes=256)
                     ok = (isinstance(hello, list) and len(hello) == 2 and isinstance(hello[0], str) and
-                          hmac.compare_digest(hello[0], token) and isinstance(hello[1], int) and
+                          hmac.compare_digest(hello[0], token) and type(hello[1]) is int and
                           1 <= hello[1] < world and hello[1] not in by_rank)
-                except (ValueError, ConnectionError, OSError, struct.error):
+                except (ValueError, ConnectionError, OSError, struct.error, RecursionError, MemoryError):
                     ok = False
                 if not ok:
                     conn.close()

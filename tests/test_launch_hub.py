@@ -116,6 +116,27 @@ def test_wire_format_round_trip_and_refusals():
         a.sendall(struct.pack("<Q", len(blob)) + blob)  # what the old protocol would have sent
         with pytest.raises(ValueError):
             launch._recv(b)
+        # a first message is read with a cap of a few hundred bytes, and nothing nests deeper than the hub's own messages
+        launch._send(a, ["x" * 64, 1])
+        assert launch._recv(b, max_bytes=256) == ["x" * 64, 1]
+        launch._send(a, ["x" * 4096, 1])
+        with pytest.raises(ValueError):
+            launch._recv(b, max_bytes=256)
+    finally:
+        a.close()
+        b.close()
+    a, b = socket.socketpair()
+    try:
+        import struct
+        deep = b"L" + struct.pack("<I", 1)
+        blob = deep * 50 + b"N"
+        a.sendall(struct.pack("<Q", len(blob)) + blob)
+        with pytest.raises(ValueError, match="nested"):
+            launch._recv(b)
+        blob = b"L" + struct.pack("<I", 0xffffffff)  # a container that claims four billion items
+        a.sendall(struct.pack("<Q", len(blob)) + blob)
+        with pytest.raises(ValueError):
+            launch._recv(b)
     finally:
         a.close()
         b.close()
@@ -163,9 +184,13 @@ def test_hub_turns_away_a_peer_without_the_token(tmp_path):
     intruder = socket.create_connection(("127.0.0.1", info["port"]))
     launch._send(intruder, ["not-the-token", 1])
     _time.sleep(0.1)
+    big = socket.create_connection(("127.0.0.1", info["port"]))
+    launch._send(big, [[["x" * 100000]], True])  # oversized, nested, a bool for the rank: dropped before any of it is decoded
+    _time.sleep(0.1)
     hub1 = launch.Hub(1, 2, path=path, timeout=30)
     got = hub1.all_gather("one")
     hub1.close()
     th.join(30)
     intruder.close()
+    big.close()
     assert got == ["zero", "one"] and result["gathered"] == ["zero", "one"]
