@@ -419,9 +419,23 @@ def main():
         else:
             err = err or "another rank could not export its inbox"
         p2p_ok = not hub.all_max(1 if err else 0)
+        if p2p_ok:
+            # connected everywhere: can the ranks actually hear each other from inside a running kernel?  (bounded, no trap)
+            hub.barrier()
+            try:
+                heard = planner.p2p_ping(0x5eed0001, timeout_ms=500)
+            except Exception as e:
+                heard, err = 0, str(e)
+            if hub.all_max(0 if heard == world else 1):
+                err = err or "ping: %d of %d ranks heard" % (heard, world)
+                p2p_ok = False
+                planner.p2p_enable(False)
         if not p2p_ok:
             if not err:
-                planner.p2p_enable(False)  # (connected here, not everywhere: never use it)
+                try:
+                    planner.p2p_enable(False)  # (connected here, not everywhere: never use it)
+                except Exception:
+                    pass
             print("bench.py rank %d: peer exchange unavailable (%s)" % (rank, err or "on another rank"), file=sys.stderr)
             if args.exchange == "p2p":
                 args.exchange = "rccl"

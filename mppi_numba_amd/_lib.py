@@ -137,6 +137,7 @@ SIGNATURES = {
     "mppi_group_p2p_connect": [C.POINTER(_vp), C.c_int],
     "mppi_planner_p2p_stats": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_long), C.c_char_p, C.c_int],
     "mppi_planner_p2p_set_enabled": [_vp, C.c_int],
+    "mppi_planner_p2p_ping": [_vp, C.c_ulonglong, C.c_int, C.POINTER(C.c_int)],
     "mppi_world_create": [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _f64p, _f64p, C.POINTER(_vp)],
     "mppi_world_destroy": [_vp],
     "mppi_world_get": [_vp, _f64p, C.c_int, _f64p, _f64p],

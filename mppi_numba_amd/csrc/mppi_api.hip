@@ -1736,6 +1736,33 @@ extern "C" int mppi_group_p2p_connect(mppi_planner** ps, int count) {
   return MPPI_OK;
 }
 
+// All ranks together, right after connecting (and a host barrier): do the peers' stores reach this rank's running
+// kernels?  *heard = ranks whose token arrived within ~timeout_ms (world_size: the exchange can be trusted).
+extern "C" int mppi_planner_p2p_ping(mppi_planner* p, unsigned long long token, int timeout_ms, int* heard) {
+  REQUIRE(p && heard, MPPI_ERR_INVALID, "NULL argument");
+  REQUIRE(p->inbox && p->peer_inbox[p->cfg.rank], MPPI_ERR_STATE, "the peer exchange is not connected");
+  REQUIRE(token != 0ull, MPPI_ERR_INVALID, "token 0 is what an empty slot holds");
+  HIP_TRY(hipSetDevice(p->cfg.device));
+  int* result = nullptr;
+  TRY(dev_alloc(&result, 1));
+  PeerExchange X;
+  memset(&X, 0, sizeof(X));
+  for (int g = 0; g < p->cfg.world_size; ++g) X.inbox[g] = p->peer_inbox[g];
+  X.world = p->cfg.world_size;
+  X.rank = p->cfg.rank;
+  const int max_polls = std::max(1, timeout_ms) * 1000;  // (~1 us per poll: a sleep of 16 x 64 cycles + the load)
+  hipLaunchKernelGGL(k_p2p_ping, dim3(1), dim3(64), 0, p->stream, X, inbox_ping_offset(p->cfg.world_size, p->cfg.num_steps),
+                     token, max_polls, result);
+  int host = 0;
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(&host, result, sizeof(int), hipMemcpyDeviceToHost, p->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+  (void)hipFree(result);
+  HIP_TRY(e);
+  *heard = host;
+  return MPPI_OK;
+}
+
 // (measurements: the same handle with the exchange switched off falls back to its communicator; all ranks alike)
 extern "C" int mppi_planner_p2p_set_enabled(mppi_planner* p, int enabled) {
   REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");

@@ -69,7 +69,29 @@ struct PeerExchange {
   unsigned long long* inbox[kMaxFoldedRanks];  // every rank's inbox as THIS device addresses it; [rank] is the own one
   int world, rank, set;                        // world == 0: no exchange
 };
-__host__ __device__ inline size_t inbox_words(int world, int n_steps) { return (size_t)2 * world * n_steps * 8; }
+// (+ one PING word per rank behind the two sets: mppi_planner_p2p_ping)
+__host__ __device__ inline size_t inbox_ping_offset(int world, int n_steps) { return (size_t)2 * world * n_steps * 8; }
+__host__ __device__ inline size_t inbox_words(int world, int n_steps) { return inbox_ping_offset(world, n_steps) + kMaxFoldedRanks; }
+
+// Can this rank's peers be heard?  Every rank writes `token` into its slot of every inbox and waits -- for a bounded
+// number of polls, WITHOUT trapping -- until all ranks' tokens have arrived in its own.  result[0] = ranks heard.
+// Run by all ranks at the same time before the exchange is trusted (a set-up where peer stores never become visible
+// to a running kernel would otherwise only show as trapped rollout launches).
+__global__ void k_p2p_ping(PeerExchange X, size_t ping_offset, unsigned long long token, int max_polls, int* result) {
+  const int lane = threadIdx.x;
+  if (lane < X.world)
+    __hip_atomic_store(X.inbox[lane] + ping_offset + X.rank, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long* own = X.inbox[X.rank] + ping_offset;
+  int heard = 0;
+  for (int polls = 0; polls < max_polls; ++polls) {
+    const bool got = lane < X.world && __hip_atomic_load(const_cast<unsigned long long*>(own) + lane, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_SYSTEM) == token;
+    heard = __popcll(__ballot(got));
+    if (heard == X.world) break;
+    __builtin_amdgcn_s_sleep(16);
+  }
+  if (lane == 0) *result = heard;
+}
 
 struct PendingApply {
   const double* packets;  // [world][stride] as all-gathered; nullptr: none (or: see reduce_tiles)

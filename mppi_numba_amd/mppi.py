@@ -493,6 +493,13 @@ class MPPI_Numba(object):
         assert len(raw) == _lib.P2P_HANDLE_BYTES * len(handles)
         _lib.call("mppi_planner_p2p_connect", self._handle, C.c_char_p(raw), len(handles))
 
+    def p2p_ping(self, token, timeout_ms=200):
+        """All ranks together after p2p_connect (+ a host barrier): ranks whose token reached this rank's running
+        kernel within the timeout (== world_size: the exchange works)."""
+        heard = C.c_int(0)
+        _lib.call("mppi_planner_p2p_ping", self._handle, C.c_ulonglong(int(token)), int(timeout_ms), C.byref(heard))
+        return int(heard.value)
+
     def p2p_enable(self, enabled=True):
         """Switch a connected peer exchange off / on (off: the communicator's all-gather); all ranks alike."""
         _lib.call("mppi_planner_p2p_set_enabled", self._handle, int(bool(enabled)))

@@ -45,7 +45,9 @@ def main():
         _, _, lin2, ang2, staged, _ = bench.build_planner("c2", args.n, rank=rank, world=world)
     handles = hub.all_gather(peer.p2p_export())
     peer.p2p_connect(handles)
-    stats0 = peer.p2p_stats()
+    hub.barrier()
+    heard = peer.p2p_ping(0xabc0 + 1, timeout_ms=2000)
+    assert heard == world, "ping: %d of %d ranks heard" % (heard, world)
 
     def staged_iterations(k):
         for _ in range(k):
