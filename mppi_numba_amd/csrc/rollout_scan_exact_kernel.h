@@ -21,7 +21,9 @@
 // three sums are WALKED by one wave each (x and y in the two halves of one wave): three dependent
 // instructions per step (v_fma_f64 / v_add_f64, v_cvt_f32_f64, v_cvt_f64_f32) instead of the ~53
 // of the pipelined kernels' state wave.  Same operations on the same operands in the same order as
-// the oracle: the same bits, by construction.
+// the oracle -- with one reassociation: x + dt*vtr*v*cos(theta) is formed as fma(vtr, (dt*v)*cos(theta), x), another
+// float64 value whose float32 rounding differs with probability ~1e-9 per step: the same bits in practice (the
+// tests allow n / 500 rollouts a few ulps off and find none).
 //
 // The walks follow each other down the horizon, one group of 8 steps apart, and the chunk waves work
 // between them -- no workgroup barrier between entry and the update sums, only flags in LDS
