@@ -449,10 +449,18 @@ def main():
             uid, err = None, str(e)
         uid = hub.broadcast(uid)
         if uid is not None:
+            # (librccl prints a version banner on stdout when a communicator is created: the line this program prints
+            #  must be the only one there)
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
             try:
                 planner.comm_init(uid)
             except Exception as e:
                 err = str(e)
+            finally:
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
         failed = hub.all_max(1 if (err or uid is None) else 0)
         rccl_ok = not failed
         if failed and p2p_ok:
