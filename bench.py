@@ -322,6 +322,12 @@ def main():
         # plain `python bench.py --gpus N`: start the N ranks (one per GPU) ourselves
         sys.exit(launch.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
+    # ONE line on stdout: everything else that writes to file descriptor 1 in this process -- librccl prints a version
+    # banner when a communicator is created, the mirror classes print like the reference does -- goes to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank, local_rank, world = launch.rank_from_env()
     if args.single_process:
         rank, local_rank, world = 0, 0, 1
@@ -449,18 +455,10 @@ def main():
             uid, err = None, str(e)
         uid = hub.broadcast(uid)
         if uid is not None:
-            # (librccl prints a version banner on stdout when a communicator is created: the line this program prints
-            #  must be the only one there)
-            sys.stdout.flush()
-            saved_fd = os.dup(1)
-            os.dup2(2, 1)
             try:
                 planner.comm_init(uid)
             except Exception as e:
                 err = str(e)
-            finally:
-                os.dup2(saved_fd, 1)
-                os.close(saved_fd)
         failed = hub.all_max(1 if (err or uid is None) else 0)
         rccl_ok = not failed
         if failed and p2p_ok:
@@ -694,8 +692,8 @@ def main():
         with quiet:
             out["cpu_baseline"] = cpu_baseline(w, params, lin, ang, planner)
         out["cpu_baseline_reference"] = reference_cpu_path()
-    print(json.dumps(out))
     sys.stdout.flush()
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
     barrier()
     hub.close()
 
