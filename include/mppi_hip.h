@@ -40,7 +40,7 @@ typedef enum mppi_status {
   MPPI_ERR_HIP = -2,       /* a HIP runtime call failed                        */
   MPPI_ERR_STATE = -3,     /* call sequence error (maps or params not set ...) */
   MPPI_ERR_NO_DEVICE = -4, /* no usable gfx950 device                          */
-  MPPI_ERR_COMM = -5       /* RCCL failure                                     */
+  MPPI_ERR_COMM = -5       /* RCCL failure, or a peer of the peer exchange that did not deliver */
 } mppi_status;
 
 /* which of the reference's solve_* variants the planner runs (mppi.py:193-211) */
@@ -378,8 +378,9 @@ int mppi_planner_comm_count(mppi_planner* p, int* ranks);
  *   p2p_connect  the handles of all `count` = world_size ranks, in rank order (the own one is ignored)
  *   group_p2p_connect  one process driving `count` devices: planners[g] is rank g
  *   p2p_stats    connected?, exchanges performed so far, how the inbox was allocated
- * A rank whose peers never send (a dead process) traps its kernel after about two seconds of polling: the call that
- * synchronises next returns MPPI_ERR_HIP instead of hanging the device. */
+ * A rank whose peers stop sending (a dead process) does not hang: after a few seconds of polling (MPPI_P2P_MAX_POLLS) its kernels raise
+ * a fault word and run on without waiting again; mppi_planner_solve / mppi_planner_synchronize then return
+ * MPPI_ERR_COMM (the control sequence of that call is not valid; reconnect before using the exchange again). */
 #define MPPI_P2P_HANDLE_BYTES 64
 int mppi_planner_p2p_export(mppi_planner* p, char handle[MPPI_P2P_HANDLE_BYTES]);
 int mppi_planner_p2p_connect(mppi_planner* p, const char* handles, int count);

@@ -200,6 +200,8 @@ struct mppi_planner {
   unsigned long long* peer_inbox[kMaxFoldedRanks] = {};
   bool peer_mapped[kMaxFoldedRanks] = {};  // opened with hipIpcOpenMemHandle: to be closed
   const char* inbox_kind = "";  // how the inbox was allocated (diagnostic)
+  unsigned int* p2p_fault_host = nullptr;  // pinned, device-mapped: a peer's numbers did not arrive (exchange_step)
+  unsigned int* p2p_fault_dev = nullptr;
   bool p2p_on = false;
   int p2p_index = 0;  // exchanges so far: its parity picks the inbox set (the same on every rank)
   uint64_t p2p_exchanges = 0;

@@ -417,6 +417,11 @@ static PeerExchange make_peer_exchange(mppi_planner* p) {
   for (int g = 0; g < p->cfg.world_size; ++g) X.inbox[g] = p->peer_inbox[g];
   X.world = p->cfg.world_size;
   X.rank = p->cfg.rank;
+  X.fault = p->p2p_fault_dev;
+  // how long a rank waits for its peers before it gives the call up (~0.3 us per poll: ~5 s by default; the ranks of a
+  // control loop call solve() together, but a host may be late by a map update or a garbage collection)
+  static const int max_polls = getenv("MPPI_P2P_MAX_POLLS") ? atoi(getenv("MPPI_P2P_MAX_POLLS")) : (1 << 24);
+  X.max_polls = max_polls;
   X.set = p->p2p_index & 1;
   ++p->p2p_index;
   ++p->p2p_exchanges;

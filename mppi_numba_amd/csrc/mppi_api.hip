@@ -464,6 +464,7 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   for (int g = 0; g < kMaxFoldedRanks; ++g)
     if (p->peer_mapped[g] && p->peer_inbox[g]) (void)hipIpcCloseMemHandle(p->peer_inbox[g]);
   if (p->inbox) (void)hipFree(p->inbox);
+  if (p->p2p_fault_host) (void)hipHostFree(p->p2p_fault_host);
   dev_free(p->inst_dev);
   if (p->u_host) (void)hipHostFree(p->u_host);
   if (p->u_stage) (void)hipHostFree(p->u_stage);
@@ -774,11 +775,22 @@ extern "C" int mppi_planner_iterate_async(mppi_planner* p, mppi_tdm* lin, mppi_t
   return run_iterations(p, lin, ang, iterations);
 }
 
+// after the stream has drained: did a peer fail to deliver (update_kernels.h, exchange_step)?
+static int check_peer_fault(mppi_planner* p) {
+  if (p->p2p_fault_host && *p->p2p_fault_host != 0u) {
+    p->p2p_on = false;  // (the inboxes are in an unknown state: reconnect before using the exchange again)
+    return fail(MPPI_ERR_COMM, "peer exchange: another rank's numbers did not arrive within the time limit "
+                               "(a rank died or stalled); the control sequence of this call is not valid");
+  }
+  return MPPI_OK;
+}
+
 extern "C" int mppi_planner_synchronize(mppi_planner* p) {
   REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
   HIP_TRY(hipSetDevice(p->cfg.device));
   HIP_TRY(hipStreamSynchronize(p->stream));
   review_speculation(p);
+  TRY(check_peer_fault(p));
   return finish_timing(p);
 }
 
@@ -798,6 +810,7 @@ extern "C" int mppi_planner_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang,
     HIP_TRY(hipMemcpyAsync(p->u_host, p->u, u_bytes, hipMemcpyDeviceToHost, p->stream));
   HIP_TRY(hipStreamSynchronize(p->stream));
   review_speculation(p);
+  TRY(check_peer_fault(p));
   memcpy(u_out, p->u_host, u_bytes);
   return finish_timing(p);
 }
@@ -1654,6 +1667,8 @@ static int p2p_alloc_inbox(mppi_planner* p, hipIpcMemHandle_t* handle) {
   return fail(MPPI_ERR_HIP, "could not allocate an exportable inbox for the peer exchange");
 }
 
+static int p2p_alloc_fault(mppi_planner* p);
+
 extern "C" int mppi_planner_p2p_export(mppi_planner* p, char handle[MPPI_P2P_HANDLE_BYTES]) {
   static_assert(sizeof(hipIpcMemHandle_t) <= MPPI_P2P_HANDLE_BYTES, "hipIpcMemHandle_t larger than expected");
   REQUIRE(p && handle, MPPI_ERR_INVALID, "NULL argument");
@@ -1661,8 +1676,18 @@ extern "C" int mppi_planner_p2p_export(mppi_planner* p, char handle[MPPI_P2P_HAN
   HIP_TRY(hipSetDevice(p->cfg.device));
   hipIpcMemHandle_t h;
   TRY(p2p_alloc_inbox(p, &h));
+  TRY(p2p_alloc_fault(p));
   memset(handle, 0, MPPI_P2P_HANDLE_BYTES);
   memcpy(handle, &h, sizeof(h));
+  return MPPI_OK;
+}
+
+static int p2p_alloc_fault(mppi_planner* p) {
+  if (!p->p2p_fault_host) {
+    HIP_TRY(hipHostMalloc((void**)&p->p2p_fault_host, sizeof(unsigned int), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void**)&p->p2p_fault_dev, p->p2p_fault_host, 0));
+  }
+  *p->p2p_fault_host = 0u;
   return MPPI_OK;
 }
 
@@ -1700,6 +1725,7 @@ extern "C" int mppi_planner_p2p_connect(mppi_planner* p, const char* handles, in
     p->peer_inbox[g] = static_cast<unsigned long long*>(ptr);
     p->peer_mapped[g] = true;
   }
+  TRY(p2p_alloc_fault(p));  // (and cleared)
   p->p2p_on = true;
   p->p2p_index = 0;
   return MPPI_OK;
@@ -1712,6 +1738,7 @@ extern "C" int mppi_group_p2p_connect(mppi_planner** ps, int count) {
     REQUIRE(ps[g] && ps[g]->cfg.world_size == count && ps[g]->cfg.rank == g, MPPI_ERR_INVALID, "planner %d is not rank %d of %d", g, g, count);
     HIP_TRY(hipSetDevice(ps[g]->cfg.device));
     TRY(p2p_alloc_inbox(ps[g], nullptr));
+    TRY(p2p_alloc_fault(ps[g]));
   }
   for (int g = 0; g < count; ++g) {
     mppi_planner* p = ps[g];

@@ -68,6 +68,8 @@ constexpr int kMaxFoldedRanks = 16;
 struct PeerExchange {
   unsigned long long* inbox[kMaxFoldedRanks];  // every rank's inbox as THIS device addresses it; [rank] is the own one
   int world, rank, set;                        // world == 0: no exchange
+  unsigned int* fault;                         // host-mapped word: raised when a peer's numbers did not arrive in time
+  int max_polls;                               // ... i.e. after this many polls (~0.3 us each)
 };
 // (+ one PING word per rank behind the two sets: mppi_planner_p2p_ping)
 __host__ __device__ inline size_t inbox_ping_offset(int world, int n_steps) { return (size_t)2 * world * n_steps * 8; }
@@ -218,8 +220,10 @@ __device__ __forceinline__ StepSums combine_step(const float* __restrict__ tile_
 
 // One wave, after it has combined the local tiles for step t: send, receive, and combine over the ranks with
 // k_apply's expressions in k_apply's order (the bits of the all-gather + k_apply path).  Returns the sums of the whole
-// job in S (beta as double in *beta_out).  Bounded polls: a rank that never sends (a dead peer) traps this kernel after
-// about two seconds instead of hanging the device.
+// job in S (beta as double in *beta_out).  Bounded polls: when a rank's numbers have not arrived after X.max_polls
+// polls (a few seconds by default: a dead or badly stalled peer) the wave raises X.fault -- a host-mapped word -- and goes on with what it has; every later wait
+// of this and the following launches sees the word and does not wait again, and the call that synchronises next
+// returns MPPI_ERR_COMM: garbage in u, but a running device and a process that can report.
 __device__ __forceinline__ StepSums exchange_step(const PeerExchange& X, const StepSums& mine, int t, int n_steps, float lambda,
                                                   int lane, double* beta_out) {
   const size_t set_words = (size_t)X.world * n_steps * 8;
@@ -258,7 +262,12 @@ __device__ __forceinline__ StepSums exchange_step(const PeerExchange& X, const S
       }
     }
     if (__all(all_there)) break;
-    if (polls > (1 << 21)) __builtin_trap();
+    if ((polls & 255) == 255 && X.fault &&
+        (polls > X.max_polls || __hip_atomic_load(X.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
+      if (lane == 0) __hip_atomic_store(X.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+    if (!X.fault && polls > (1 << 24)) __builtin_trap();
     __builtin_amdgcn_s_sleep(2);
   }
   // k_apply's lines over the ranks' numbers (wave-uniform: every lane computes the same)

@@ -49,3 +49,14 @@ def test_bench_line_with_the_peer_exchange():
     assert set(cfg["exchange_us_per_step"]) == {"p2p"} and cfg["exchange_us_per_step"]["p2p"] > 0
     assert "reduces_tiles=1" in cfg["rollout_kernel"] and res["roofline"]["frac"] > 0
     assert res["ms_per_step"] < 0.2   # (the host-staged exchange is ~0.2 ms per step, the peer exchange ~0.02)
+
+
+def test_a_dead_peer_is_an_error_code_not_a_hang():
+    """Rank 1 leaves before the loop: rank 0's launches wait for its numbers for a bounded time, raise the fault word
+    and run on; the call that synchronises returns MPPI_ERR_COMM -- no hung device, no aborted process."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MPPI_RDZV_FILE")}
+    env["MPPI_P2P_MAX_POLLS"] = str(1 << 20)  # (a fraction of a second instead of the default ~5 s)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "p2p_dead_peer.py")], capture_output=True, text=True,
+                         timeout=300, env=env, cwd=ROOT)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("DEAD_PEER_")]
+    assert out.returncode == 0 and len(lines) == 1 and lines[0].startswith("DEAD_PEER_OK"), (out.stdout[-800:], out.stderr[-800:])
