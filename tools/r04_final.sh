@@ -9,6 +9,12 @@ cd $ROOT
 timeout ${SUITE_LIMIT:-1200} python -m pytest tests -m gpu -q -p no:cacheprovider --timeout=200 --timeout-method=thread > $OUT/pytest_gpu.log 2>&1
 echo "pytest -m gpu rc=$?"; grep -E "passed|failed|FAILED|ERROR|Timeout" $OUT/pytest_gpu.log | tail -12 | cut -c1-230
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+# the flag-synchronised kernel's tests once more against the build whose LDS waits trap instead of spinning for ever
+# (make -C mppi_numba_amd/csrc bounded, before gpurun: the library travels with the snapshot)
+if [ -f $ROOT/build/libmppi_bounded.so ]; then
+  MPPI_HIP_LIB=$ROOT/build/libmppi_bounded.so timeout 600 python -m pytest tests/test_gpu_scan.py tests/test_gpu_fuzz.py tests/test_gpu_reduce_fold.py tests/test_gpu_semantic.py tests/test_gpu_soak.py -m gpu -q -p no:cacheprovider --timeout=200 > $OUT/pytest_bounded.log 2>&1
+  echo "bounded build rc=$?"; tail -2 $OUT/pytest_bounded.log | cut -c1-200
+fi
 timeout 300 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_style.json 2> $OUT/bench_driver_style.err
 timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_c2.json 2> $OUT/bench_c2.err
 for f in bench_driver_style bench_c2; do
