@@ -436,6 +436,20 @@ def main():
                 err = err or "ping: %d of %d ranks heard" % (heard, world)
                 p2p_ok = False
                 planner.p2p_enable(False)
+        if p2p_ok:
+            # ... and does a short loop over it come back?  A rank whose peers' numbers do not arrive gets MPPI_ERR_COMM
+            # after a few seconds (bounded waits, no trap): then every rank starts over with a fresh handle and RCCL.
+            try:
+                planner.solve()
+                planner.iterate_async(12)
+                planner.synchronize()
+            except Exception as e:
+                err = "trial loop: " + str(e)[:200]
+            if hub.all_max(1 if err else 0):
+                p2p_ok = False
+                err = err or "trial loop failed on another rank"
+                planner = MPPI_Numba(cfg, rank=rank, world_size=world)
+                planner.setup(params, lin, ang)
         if not p2p_ok:
             if not err:
                 try:

@@ -1797,6 +1797,10 @@ extern "C" int mppi_planner_p2p_set_enabled(mppi_planner* p, int enabled) {
   HIP_TRY(hipSetDevice(p->cfg.device));
   HIP_TRY(hipStreamSynchronize(p->stream));
   drop_graphs(p);
+  // (switching the exchange off after MPPI_ERR_COMM leaves a handle that works over RCCL or the host again -- with
+  // whatever u the broken call left, so set u before iterating; switching it ON again needs a new connect)
+  if (!enabled && p->p2p_fault_host) *p->p2p_fault_host = 0u;
+  REQUIRE(!enabled || !p->p2p_fault_host || *p->p2p_fault_host == 0u, MPPI_ERR_STATE, "the peer exchange failed: connect again first");
   p->p2p_on = enabled != 0;
   return MPPI_OK;
 }

@@ -330,10 +330,14 @@ __device__ __forceinline__ void publish_step(const PendingApply& A, StepSums S, 
 // every workgroup, one wave: the published sequence -> u_sh[0 .. Tp) (LDS); steps past the horizon are zero.
 // A lane polls the steps lane, lane + 64, ... and stops asking for a step once it has it.
 // Bounded: the publishers are the first workgroups of the grid, dispatched before any workgroup that waits for them,
-// so this cannot deadlock; should it ever poll for about a second, something else is broken: trap rather than hang.
+// so this cannot deadlock; should it ever poll for about a second (without a peer exchange), something else is broken:
+// trap rather than hang.
 __device__ __forceinline__ void collect_published(const PendingApply& A, int n_steps, int padded_steps, int lane,
                                                   float2* u_sh) {
   unsigned long long* words = A.published + (size_t)A.flag_set * n_steps * kPublishedStride;
+  // (with a peer exchange the publishers may themselves be waiting for another rank, up to peers.max_polls of THEIR
+  // polls, and then publish what they have and raise the fault word: the collectors must outlast that, not trap first)
+  const int limit = A.peers.world > 0 ? 8 * min(max(A.peers.max_polls, 1 << 17), 1 << 27) : (1 << 20);
   for (int base = 0; base < padded_steps; base += 128) {  // (one round for T <= 128)
     unsigned long long wx[2] = {0ull, 0ull}, wy[2] = {0ull, 0ull};
     for (int polls = 0;; ++polls) {
@@ -348,7 +352,7 @@ __device__ __forceinline__ void collect_published(const PendingApply& A, int n_s
         }
       }
       if (__all(all_there)) break;
-      if (polls > (1 << 20)) __builtin_trap();
+      if (polls > limit) __builtin_trap();
       __builtin_amdgcn_s_sleep(1);
     }
 #pragma unroll
