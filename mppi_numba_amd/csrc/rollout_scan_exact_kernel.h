@@ -666,6 +666,13 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
       for (int j = 0; j < CHL; ++j) e[j] = col[(size_t)min(t0 + j, T - 1) * 64];
     }
     MPPI_STAMP(stamp_wg && c < 16, stamp_base + 10);
+    // (the noise goes to LDS before the wait for the controls: less is left to do once they are there)
+#pragma unroll
+    for (int j = 0; j < CHL; ++j) {
+      e[j] = j < nvalid ? e[j] : make_float2(0.0f, 0.0f);
+      const int t = t0 + j;
+      e2[t * R + (r ^ (t & (R - 1)))] = e[j];
+    }
     if (folded) {  // (wave-uniform) the sequence this launch's update leaves: formed by wave 0 meanwhile
       (void)wait_for(&u_ready[0]);
 #pragma unroll
@@ -676,9 +683,6 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     for (int j = 0; j < CHL; ++j) {
       const bool valid = j < nvalid;
       ut[j] = valid ? ut[j] : make_float2(0.0f, 0.0f);
-      e[j] = valid ? e[j] : make_float2(0.0f, 0.0f);
-      const int t = t0 + j;
-      e2[t * R + (r ^ (t & (R - 1)))] = e[j];
       const float v = clip_f32(ut[j].x + e[j].x, Q.v_lo, Q.v_hi);
       const float w = clip_f32(ut[j].y + e[j].y, Q.w_lo, Q.w_hi);
       qx[j] = dt64 * (double)v;
