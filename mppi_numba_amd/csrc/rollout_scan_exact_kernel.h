@@ -691,8 +691,22 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     raise(&a_done[g], 1);
     if ((c & 3) == 0) __builtin_amdgcn_s_setprio(0);  // (beside the theta and x | y walks from here on)
     MPPI_STAMP(stamp_wg && c < 16, stamp_base + 1);
-    // (everything the walks do not wait for comes after their flags: the control-cost products last of all)
+    // (everything the walks do not wait for comes after their flags)
     const uint32_t ref = scan_lookup<POW2RES>(Q, cells16, Q.x0, Q.y0) & 0x3fffu;
+
+    // ---------------------------------------------------------------- the control-cost terms of this wave's steps:
+    // lambda * (u0/s0^2 * e0 + u1/s1^2 * e1) in float64 (mppi.py:1007-1009), needed after the terminal cost only.
+    // Here, while the theta walk has not reached this group yet (every group waits >= 0.5k cycles for its headings):
+    // at the end of the wave they competed with the late groups' lookups and records for the SIMD, and the noise
+    // stayed in registers all the way
+    if (lane < 8) {  // the control ratios of the 8 steps (float64 quotients: mppi.py:709)
+      const float2 ul = folded ? u_sh[8 * g + lane] : uq[min(8 * g + lane, T - 1)];
+      uos[8 * g + lane] = make_double2((double)ul.x / Q.s0sq, (double)ul.y / Q.s1sq);
+    }
+#pragma unroll
+    for (int j = 0; j < CHL; ++j) ccr[((size_t)k * R + r) * CHL + j] = control_cost(Q, uos[min(t0 + j, Tp - 1)], e[j]);
+    raise(&cc_done[g], 1);
+    MPPI_STAMP(stamp_wg && c < 16, stamp_base + 2);
 
     // ---------------------------------------------------------------- B: sin / cos of this wave's headings
     (void)wait_for(&th_done[g]);
@@ -846,16 +860,6 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     }
     raise(&c_done[g], group_pen ? 3 : 1);
     MPPI_STAMP(stamp_wg && c < 16, stamp_base + 6);
-    // ---------------------------------------------------------------- the control-cost terms of this wave's steps:
-    // lambda * (u0/s0^2 * e0 + u1/s1^2 * e1) in float64 (mppi.py:1007-1009), needed after the terminal cost only
-    if (lane < 8) {  // the control ratios of the 8 steps (float64 quotients: mppi.py:709)
-      const float2 ul = folded ? u_sh[8 * g + lane] : uq[min(8 * g + lane, T - 1)];
-      uos[8 * g + lane] = make_double2((double)ul.x / Q.s0sq, (double)ul.y / Q.s1sq);
-    }
-#pragma unroll
-    for (int j = 0; j < CHL; ++j) ccr[((size_t)k * R + r) * CHL + j] = control_cost(Q, uos[min(t0 + j, Tp - 1)], e[j]);
-    raise(&cc_done[g], 1);
-    MPPI_STAMP(stamp_wg && c < 16, stamp_base + 2);
   }
   lds_barrier();
   if (fallback.offset >= 0 && flags[0] != 0u) {  // (workgroup-uniform: every vote is in)
