@@ -602,6 +602,9 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
               cost = (float)((double)cost + s23.y);
             }
           }
+          // (stamps build: when the walk left groups 0, 6, 9 .. 12)
+          MPPI_STAMP(stamp_wg && (gi == 0 || gi == 6), stamp_base + (gi == 0 ? 5 : 6));
+          MPPI_STAMP(stamp_wg && gi >= 9 && gi <= 12, stamp_base + (gi == 9 ? 7 : gi));
           // (between two groups, as soon as the position walk is through: this wave mostly waits for records)
           if (!term_ready && peek(&xy_done[W - 1])) plain_terminal();
         });
@@ -758,6 +761,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
         hit_bits |= (n2[j] <= gt2 ? 1u : 0u) << j;
       }
       pin_memory_order();
+      MPPI_STAMP(stamp_wg && c < 16, stamp_base + 7);
 #pragma unroll
       for (int j = 0; j < CHL; ++j) {
         const uint32_t cl = cell[j];
@@ -767,6 +771,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
         pu[j] = (cl & 0x8000u) ? Q.unk_cost : 0.0f;
       }
     }
+    MPPI_STAMP(stamp_wg && c < 16, stamp_base + 11);
     const uint32_t vmask = (1u << nvalid) - 1u;
     const int s = __builtin_ctz((zero_bits & vmask) | (1u << CHL));
     const int hh = __builtin_ctz((hit_bits & vmask & ((1u << s) - 1u)) | (1u << CHL));
@@ -804,6 +809,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     // the events of ALL earlier chunks must be in evw when this wave looks: then the first event wins
     // (a chain from wave to wave that must stay short -- it is the last stage's critical path: publish and
     //  pass the baton, only then look who owns what)
+    MPPI_STAMP(stamp_wg && c < 16, stamp_base + 12);
     if (g > 0) (void)wait_for(&ev_done[g - 1]);
     if (ev != 0u) atomicOr(&evw[2 * r + ((2 * k) >> 5)], ev << ((2 * k) & 31));
     raise(&ev_done[g], 1);
@@ -823,6 +829,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
         // frozen position otherwise; a rollout without any event: the cost wave, from the final position
         term_sh[r] = (ev == 2u && !f_hit) ? sqrt(f_d2) / Q.v_post_den : 0.0;
       }
+      MPPI_STAMP(stamp_wg && c < 16, stamp_base + 13);
       if (__any(!dead && bad) && lane == 0) atomicOr(&flags[0], 1u);
       // the first event of the rollout, here or earlier: a stop?
       const int first = word != 0ull ? (__builtin_ctzll(word) >> 1) : 0;
@@ -839,6 +846,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
         f_begin = stopped ? first * CHL + (int)(bits & 3u) : 0;
         f_end = stopped ? ((bits & 4u) ? f_begin + 1 : T) : 0;
       }
+      MPPI_STAMP(stamp_wg && c < 16, stamp_base + 14);
       bool pen = false;
 #pragma unroll
       for (int j = 0; j < CHL; ++j) {
@@ -849,6 +857,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
         pen = pen || po[j] != 0.0f || pu[j] != 0.0f;
       }
       group_pen = __any(pen);
+      MPPI_STAMP(stamp_wg && c < 16, stamp_base + 15);
       // the group's records over its (consumed) position increments
       char* out = grp + (size_t)g * 4096 + (size_t)h * 2048 + (size_t)r * 64;
       double2* o2 = reinterpret_cast<double2*>(out);

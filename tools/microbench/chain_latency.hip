@@ -11,7 +11,7 @@
 // KIND: which chain.  `busy` waves (wave index >= 4, same SIMD as wave 0 when index % 4 == 0) spin on
 // integer multiply-adds until wave 0 has finished.
 template <int KIND>
-__global__ __launch_bounds__(1024) void k(unsigned long long* out, double c, double inc, double K, float pf, int busy_on_simd0) {
+__global__ __launch_bounds__(1024) void k(unsigned long long* out, double c, double inc, double K, float pf, int busy_on_simd0, int busy_kind = 0) {
   __shared__ float sink[64 * 8];
   __shared__ int stop;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -89,25 +89,51 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, double c, dou
       __hip_atomic_store(&stop, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   } else if ((wave & 3) == 0 ? (wave / 4 <= busy_on_simd0) : false) {
-    // a busy neighbour on SIMD 0: independent integer chains (Philox-like), lower priority
+    // a busy neighbour on SIMD 0, lower priority.  busy_kind 0: independent integer chains (Philox-like);
+    // 1: independent float64 fma streams; 2: float64 sqrt / rcp (transcendental unit) ; 3: LDS reads and writes
     unsigned a = lane, b = lane * 3, cc = lane * 7, d = lane * 11;
+    double f0 = 1.0 + lane, f1 = 2.0 + lane, f2 = 3.0 + lane, f3 = 4.0 + lane;
     while (__hip_atomic_load(&stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) {
+      if (busy_kind == 0) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        a = a * 0x9E3779B9u + b;
-        b = b * 0xBB67AE85u + cc;
-        cc = cc * 0xD2511F53u + d;
-        d = d * 0xCD9E8D57u + a;
+        for (int i = 0; i < 16; ++i) {
+          a = a * 0x9E3779B9u + b;
+          b = b * 0xBB67AE85u + cc;
+          cc = cc * 0xD2511F53u + d;
+          d = d * 0xCD9E8D57u + a;
+        }
+      } else if (busy_kind == 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(f0) : "v"(c), "v"(inc));
+          asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(f1) : "v"(c), "v"(inc));
+          asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(f2) : "v"(c), "v"(inc));
+          asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(f3) : "v"(c), "v"(inc));
+        }
+      } else if (busy_kind == 2) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          asm volatile("v_sqrt_f64 %0, %0" : "+v"(f0));
+          asm volatile("v_rcp_f64 %0, %0" : "+v"(f1));
+          asm volatile("v_sqrt_f64 %0, %0" : "+v"(f2));
+          asm volatile("v_rcp_f64 %0, %0" : "+v"(f3));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          sink[(lane + 64 * (i & 3)) & 511] = (float)f0;
+          f0 += (double)sink[(lane * 2 + i) & 511];
+        }
       }
     }
-    sink[lane] = (float)(a ^ b ^ cc ^ d);
+    sink[lane] = (float)(a ^ b ^ cc ^ d) + (float)(f0 + f1 + f2 + f3);
   }
 }
 
 template <int KIND>
-static double run(unsigned long long* dev, int busy) {
+static double run(unsigned long long* dev, int busy, int kind = 0) {
   // 16 waves: wave w sits on SIMD w % 4; waves 4, 8, 12 share SIMD 0 with the measured wave
-  hipLaunchKernelGGL((k<KIND>), dim3(1), dim3(1024), 0, 0, dev, 1.0000001, 1e-3, 536870912.0, 0.5f, busy);
+  hipLaunchKernelGGL((k<KIND>), dim3(1), dim3(1024), 0, 0, dev, 1.0000001, 1e-3, 536870912.0, 0.5f, busy, kind);
   unsigned long long h[2];
   hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost);
   return (double)h[0] / STEPS;
@@ -132,6 +158,9 @@ int main() {
   printf("%-56s %9s %9s %9s   (cycles per step, s_memtime/readcyclecounter units)\n", "chain", "alone", "+1 busy", "+3 busy");
 #define ROW(K) printf("%-56s %9.1f %9.1f %9.1f\n", names[K], run<K>(dev, 0), run<K>(dev, 1), run<K>(dev, 3));
   ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11) ROW(12)
+  printf("\nthe same chains beside THREE busy waves of another kind (lower priority, same SIMD): float64 fma | float64 sqrt, rcp | LDS\n");
+#define ROW2(K) printf("%-56s %9.1f %9.1f %9.1f\n", names[K], run<K>(dev, 3, 1), run<K>(dev, 3, 2), run<K>(dev, 3, 3));
+  ROW2(0) ROW2(2) ROW2(4) ROW2(12)
   // clock: readcyclecounter ticks per microsecond
   {
     hipEvent_t a, b;

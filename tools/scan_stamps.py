@@ -9,9 +9,12 @@ k_rollout_scan (math fast): per wave (chunk): entered (0), had its noise and con
 barrier 1 (2), barrier 2 (3), had its stage costs (4), reached barrier 3 (5), barrier 4 (6); wave 0 also:
 costs written (7); every wave: end (8); wave 0: stage additions done (9), frozen steps done (10), weights (11).
 k_rollout_scan_exact: wave 0 = heading walk, wave 1 = position walk: entered (0), walk done (1); wave 2 =
-cost walk: stage walk done (1), frozen steps (2), control-cost walk (3), weights written (4); waves 3.. =
+cost walk: stage walk done (1), frozen steps (2), control-cost walk (3), weights written (4), left group 0 (5), 6 (6),
+9 (7), 10 .. 12 (10 .. 12); waves 3.. =
 chunk waves: increments stored (1), sin / cos + position increments (3),
-positions arrived (4), events published (5), records stored (6); every wave: end (8), first barrier passed
+positions arrived (4), distances done and lookups requested (7), cells there (11), before the wait for the
+earlier groups' events (12), events published (5), own events looked up and terminal cost (13), stopped rollouts
+(14), selects (15), records stored (6); every wave: end (8), first barrier passed
 (9); chunk waves: noise generated (10), control-cost products (2: after the records)."""
 import argparse
 import contextlib
@@ -52,12 +55,12 @@ def main():
     # workgroup 5 and (exact kernel) workgroup 200; walkers of a launch that applies the previous update itself:
     # 5 combine begins, 6 published, 7 sequence collected
     for title, first in (("workgroup 5", 64), ("workgroup 200", 1024)):
-        rows = [st[first + 16 * c: first + 16 * c + 12] for c in range(16)]
+        rows = [st[first + 16 * c: first + 16 * c + 16] for c in range(16)]
         if not any(r[0] for r in rows):
             continue
         t0 = min(int(r[0]) for r in rows if r[0])
         print(title)
-        print(" wave  " + "".join("%8d" % k for k in range(12)))
+        print(" wave  " + "".join("%8d" % k for k in range(16)))
         for c, r in enumerate(rows):
             if r[0]:
                 print("%5d  " % c + "".join("%8s" % (int(v - t0) if v else "-") for v in r))
