@@ -63,8 +63,8 @@ constexpr int kMaxFoldedRanks = 16;
 // [2 sets][world][T steps][8 words]; rank g's numbers for step t -- the doubles beta_g, den_g, num_g[t].x, num_g[t].y of
 // its packet (packet_len) -- arrive as eight 8-byte words {uint32 half of a double; uint32 1}: each word carries its
 // own flag, so nothing orders them and nobody fences.  Set `set` is used by this exchange; the reader clears the
-// words of the OTHER set for its step before it sends (the peers write that set only after they have received what
-// is sent after the clearing).  world <= kMaxFoldedRanks.
+// words it has read (the peers write this set again two exchanges later, after they have received what this rank
+// sends in between, from its next launch: exchange_step).  world <= kMaxFoldedRanks.
 struct PeerExchange {
   unsigned long long* inbox[kMaxFoldedRanks];  // every rank's inbox as THIS device addresses it; [rank] is the own one
   int world, rank, set;                        // world == 0: no exchange
@@ -228,13 +228,8 @@ __device__ __forceinline__ StepSums exchange_step(const PeerExchange& X, const S
                                                   int lane, double* beta_out) {
   const size_t set_words = (size_t)X.world * n_steps * 8;
   unsigned long long* own = X.inbox[X.rank];
-  // clear the other set's words for this step (all ranks' slots), then make sure that is done before anything is sent
-  {
-    unsigned long long* other = own + (size_t)(X.set ^ 1) * set_words;
-    for (int i = lane; i < 8 * X.world; i += 64)
-      __hip_atomic_store(other + ((size_t)(i >> 3) * n_steps + t) * 8 + (i & 7), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  // (the words of this set for this step were cleared by this very workgroup when it had read them two exchanges ago
+  //  -- a launch boundary ago at least: see below)
   // this rank's eight words: lane i < 8 holds word i
   const double vals[4] = {(double)mine.beta, mine.den, mine.nx, mine.ny};
   unsigned long long word = 0ull;
@@ -270,6 +265,13 @@ __device__ __forceinline__ StepSums exchange_step(const PeerExchange& X, const S
     if (!X.fault && polls > (1 << 24)) __builtin_trap();
     __builtin_amdgcn_s_sleep(2);
   }
+  // Everything for this step has been read: clear the words for the exchange after next.  Nobody writes them before
+  // then -- a peer sends into this set again only after it has received what this rank sends in the NEXT exchange,
+  // which this rank's next launch does, and these stores are performed when this launch ends.  (Clearing the other
+  // set BEFORE sending, as the first version did, put a round trip to memory in front of every send.)
+  for (int i = lane; i < 8 * X.world; i += 64)
+    __hip_atomic_store(const_cast<unsigned long long*>(in) + ((size_t)(i >> 3) * n_steps + t) * 8 + (i & 7), 0ull,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // k_apply's lines over the ranks' numbers (wave-uniform: every lane computes the same)
   auto number = [&](int q, int k) {  // double k of rank q
     const unsigned int src = (q >= 8 ? got[1] : got[0]) & 0xffffffffu;

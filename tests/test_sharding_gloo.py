@@ -195,8 +195,8 @@ def doubles_of(words):
 
 def _peer_worker(rank, world, port, q):
     """Two ranks, every step of every iteration exchanged separately through per-rank inboxes [2 sets][world][T][8]
-    (gloo send / recv stand in for the stores into the peer's memory): the reader clears the other set's slots of
-    the step before it sends, the numbers are combined with k_apply's expressions.  Must equal the all-gather of
+    (gloo send / recv stand in for the stores into the peer's memory): the reader clears the slots it has read (the set
+    is written again two exchanges later), the numbers are combined with k_apply's expressions.  Must equal the all-gather of
     whole packets + apply_packets, bit for bit, over several iterations (both sets in use)."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -223,7 +223,6 @@ def _peer_worker(rank, world, port, q):
                 exchange += 1
                 u = np.empty_like(it["u_in"], dtype=np.float32)
                 for t in range(t_steps):
-                    inbox[s ^ 1, :, t, :] = 0  # (cleared before anything is sent for this step)
                     mine = words_of([packet[0], packet[1], packet[2 + 2 * t], packet[3 + 2 * t]])
                     inbox[s, rank, t] = mine
                     for peer in range(world):
@@ -238,6 +237,7 @@ def _peer_worker(rank, world, port, q):
                     rows = np.stack([doubles_of(inbox[s, g_, t]) for g_ in range(world)])  # beta, den, nx, ny per rank
                     step_packets = np.concatenate([rows[:, :2], rows[:, 2:]], axis=1)
                     u[t] = apply_packets(step_packets, P["lambda_weight"], it["u_in"][t:t + 1], P["vrange"], P["wrange"])[0]
+                    inbox[s, :, t, :] = 0  # (read: cleared for the exchange after next, update_kernels.h exchange_step)
                 gathered = [torch.zeros(packet.size, dtype=torch.float64) for _ in range(world)]
                 dist.all_gather(gathered, torch.from_numpy(packet))
                 want = apply_packets(np.stack([x.numpy() for x in gathered]), P["lambda_weight"], it["u_in"], P["vrange"], P["wrange"])
