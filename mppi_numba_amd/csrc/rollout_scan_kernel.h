@@ -197,9 +197,22 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
     fz_count[lane] = 0;
     if (lane == 0) flags[0] = 0u;
   }
-  // a sharded iteration's update applied here (update_kernels.h, PendingApply)
+  // a sharded iteration's update applied here (update_kernels.h, PendingApply) ...
   const bool folded = pend.packets != nullptr;
-  if (folded) {
+  // ... or, on one GPU, the previous launch's tile packets combined here (PendingApply::reduce_tiles, as in
+  // k_rollout_scan_exact): waves 0 and 1 of workgroup `tile` take steps tile, tile + gridDim.x (and on round), with
+  // the very function block t of k_combine_tiles runs; wave 0 then collects the published sequence.  The packets are
+  // requested before anything else and combined behind the Philox blocks: a trip of ~1.5 us either way.
+  const bool reducing = folded && pend.reduce_tiles != nullptr;
+  const int red_t = tile + c * n_rollout_blocks;
+  const bool reduce_here = reducing && c < 2 && red_t < T;
+  StepLoads red_loads;
+  float2 red_u = make_float2(0.0f, 0.0f);
+  if (reduce_here) {
+    red_loads = combine_step_issue(pend.reduce_tiles, pend.reduce_n_tiles, tile_packet_floats(T), red_t, lane);
+    red_u = uq[red_t];
+  }
+  if (folded && !reducing) {
     if (c == 0) pending_apply_prepare(pend, lane, scale_sh);
     lds_barrier();
   }
@@ -207,7 +220,9 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
   // ---------------------------------------------------------------- A: noise, controls, heading increments
   // (requested before the Philox blocks: their first touch is a trip to memory)
   float2 ut[CHL];
-  if (folded) {  // (wave-uniform) the 8 controls of this wave's steps from the ranks' packets
+  if (reducing) {
+    // (from LDS behind the barrier below)
+  } else if (folded) {  // (wave-uniform) the 8 controls of this wave's steps from the ranks' packets
     if (lane < 8) {
       const int t = 8 * c + lane;
       const float2 v = t < T ? pending_apply_control(pend, scale_sh, uq, t) : make_float2(0.0f, 0.0f);
@@ -246,12 +261,25 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
   }
 #pragma unroll
   for (int j = 0; j < CHL; ++j) {
-    const bool valid = j < nvalid;
-    ut[j] = valid ? ut[j] : make_float2(0.0f, 0.0f);
-    e[j] = valid ? e[j] : make_float2(0.0f, 0.0f);
+    e[j] = j < nvalid ? e[j] : make_float2(0.0f, 0.0f);
     const int t = t0 + j;
     e2[t * R + (r ^ (t & (R - 1)))] = e[j];
   }
+  if (reducing) {  // (workgroup-uniform)
+    if (reduce_here) {
+      const int stride = tile_packet_floats(T);
+      publish_step(pend, combine_step_finish(red_loads, pend.reduce_tiles, pend.reduce_n_tiles, stride, red_t, pend.lambda, lane),
+                   red_u, red_t, T, lane);
+      for (int tt = red_t + 2 * n_rollout_blocks; tt < T; tt += 2 * n_rollout_blocks)
+        publish_step(pend, combine_step(pend.reduce_tiles, pend.reduce_n_tiles, stride, tt, pend.lambda, lane), uq[tt], tt, T, lane);
+    }
+    if (c == 0) collect_published(pend, T, 8 * W, lane, u_sh);
+    lds_barrier();
+#pragma unroll
+    for (int j = 0; j < CHL; ++j) ut[j] = u_sh[t0 + j];
+  }
+#pragma unroll
+  for (int j = 0; j < CHL; ++j) ut[j] = j < nvalid ? ut[j] : make_float2(0.0f, 0.0f);
   MPPI_STAMP(stamp_wg && c < 16, stamp_base + 1);
   const double vtr0 = fma(Q.lin_ratio, (double)(int)(ref & 127u), Q.lin_lo);
   const double wtr0 = fma(Q.ang_ratio, (double)(int)((ref >> 7) & 127u), Q.ang_lo);

@@ -19,12 +19,12 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def build(n, t=None, seed=1):
+def build(n, t=None, seed=1, math="exact"):
     if t is not None:
         saved = dict(bench.WORKLOADS["c2"])
         bench.WORKLOADS["c2"] = dict(saved, t=t)
     try:
-        return bench.build_planner("c2", n, seed=seed)
+        return bench.build_planner("c2", n, seed=seed, math=math)
     finally:
         if t is not None:
             bench.WORKLOADS["c2"] = saved
@@ -130,3 +130,38 @@ def test_the_loop_noise_of_a_folded_iteration_against_the_oracle():
     rel = np.abs(costs - want) / np.maximum(np.abs(want), 30.0)
     print("\nfolded second iteration vs oracle on the twin's u: bit-identical %.4f, max rel %.2e" % ((costs == want).mean(), rel.max()))
     assert (costs == want).mean() >= 0.999 and rel.max() <= 1e-6
+
+
+@pytest.mark.parametrize("n,t", [(8192, 100), (8192, 128), (4096, 30), (1000, 100), (200, 100), (40, 17), (64, 100)])
+def test_fast_mode_loop_with_the_fold_equals_the_loop_with_update_launches(n, t):
+    """math="fast" (k_rollout_scan, the tolerance kernel): the same fold, the same statement -- u and costs of the loop
+    with one launch per iteration are the bits of the loop with an update launch per iteration."""
+    _, _, _, _, folded, params = build(n, t, math="fast")
+    _, _, _, _, plain, _ = build(n, t, math="fast")
+    plain.set_debug_flags(_lib.DEBUG_NO_REDUCE_FOLD)
+    for planner in (folded, plain):
+        planner.solve()
+    for iterations in (1, 2, 5, 8):
+        u_f, c_f = run(folded, iterations)
+        u_p, c_p = run(plain, iterations)
+        name = folded.last_rollout_kernel()
+        assert name.startswith("k_rollout_scan ") or name.startswith("k_rollout_scan_exact"), name
+        if name.startswith("k_rollout_scan "):
+            tile = int(name.split("tile=")[1].split()[0])
+            can_fold = 4 * ((n + tile - 1) // tile) >= t
+            assert ("reduces_tiles=1" in name) == (iterations > 1 and can_fold), (iterations, name)
+        assert "reduces_tiles" not in plain.last_rollout_kernel()
+        assert np.array_equal(u_f, u_p), (iterations, float((np.abs(u_f - u_p) / span(params)).max()))
+        assert np.array_equal(c_f, c_p), iterations
+
+
+def test_fast_mode_graph_replay_of_the_folded_loop_has_the_bits_of_the_direct_loop():
+    _, _, _, _, direct, _ = build(4096, math="fast")
+    _, _, _, _, graphed, _ = build(4096, math="fast")
+    graphed.set_graph_replay(True, iterations_per_graph=2)
+    for planner in (direct, graphed):
+        planner.solve()
+    for chunk in (1, 2, 7, 12, 3):
+        u_d, c_d = run(direct, chunk)
+        u_g, c_g = run(graphed, chunk)
+        assert np.array_equal(u_d, u_g) and np.array_equal(c_d, c_g), chunk
