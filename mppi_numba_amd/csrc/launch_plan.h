@@ -477,7 +477,7 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
   if (p->reduce_pending) {
     // the previous launch's tile packets, combined and applied by this launch (no update kernel ran); several GPUs:
     // with the peer exchange in between
-    REQUIRE(!p->apply_pending && (plan.exact || !p->p2p_on), MPPI_ERR_STATE, "internal: tile packets left to a launch that cannot reduce them");
+    REQUIRE(!p->apply_pending, MPPI_ERR_STATE, "internal: tile packets left to a launch that cannot reduce them");
     REQUIRE(tiles_can_reduce(tiles, T) && plan.tile == p->scan_tile, MPPI_ERR_STATE, "internal: %d workgroups cannot combine the tile packets of %d steps", tiles, T);
     pend.packets = p->packets;  // (not read in this mode; non-null: "an update is pending")
     pend.world = 1;
@@ -1243,11 +1243,11 @@ static bool next_rollout_applies_updates(const mppi_planner* p) {
 }
 
 // Several GPUs without a collective: the peer exchange is connected and the kernels that carry it will run (the
-// time-parallel exact kernel leaves tile packets; one problem per handle).  Decided from things every rank has alike.
+// time-parallel kernels leave tile packets; one problem per handle).  Decided from things every rank has alike.
 static bool p2p_usable(const mppi_planner* p) {
   ScanPlan plan;
   return p->p2p_on && p->cfg.world_size > 1 && p->cfg.world_size <= kMaxFoldedRanks && p->B == 1 && !p->inst_set &&
-         p->m_count == 1 && p->cfg.mode == MPPI_MODE_DET && scan_plan(p, &plan) && plan.exact;
+         p->m_count == 1 && p->cfg.mode == MPPI_MODE_DET && scan_plan(p, &plan);
 }
 
 // Whether the NEXT rollout launch can combine and apply the tile packets of this one (no update kernel).
@@ -1256,7 +1256,7 @@ static bool next_rollout_reduces_tiles(const mppi_planner* p) {
   ScanPlan plan;
   return !disabled && !(p->debug_flags & (MPPI_DEBUG_NO_FOLDED_APPLY | MPPI_DEBUG_NO_REDUCE_FOLD)) && p->B == 1 && !p->inst_set &&
          p->m_count == 1 && ((p->cfg.world_size == 1 && !p->comm) || p2p_usable(p)) && p->cfg.mode == MPPI_MODE_DET && !p->mirror_now &&
-         scan_plan(p, &plan) && (plan.exact || p->cfg.world_size == 1) && plan.tile == p->scan_tile &&
+         scan_plan(p, &plan) && plan.tile == p->scan_tile &&
          tiles_can_reduce(ceil_div(p->n_local, plan.tile), p->cfg.num_steps);
 }
 

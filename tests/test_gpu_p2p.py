@@ -34,6 +34,16 @@ def test_ranks_sharing_the_device_through_ipc_have_the_bits_of_the_k_apply_loop(
     assert "max|du|=0.000e+00" in line, line
 
 
+@pytest.mark.parametrize("ranks,n,t,iterations", [(2, 2048, 100, 6), (3, 1024, 64, 5)])
+def test_ranks_in_the_tolerance_mode_have_the_bits_of_the_k_apply_loop(ranks, n, t, iterations):
+    """math="fast": k_rollout_scan carries the same exchange (publish_step is shared)."""
+    line = run_ranks("--ranks", str(ranks), "--n", str(n), "--t", str(t), "--iterations", str(iterations), "--math", "fast")
+    print("\n" + line)
+    assert line.startswith("P2P_OK") and "world=%d" % ranks in line, line
+    assert "k_rollout_scan+reduces_tiles" in line, line
+    assert "max|du|=0.000e+00" in line, line
+
+
 def test_bench_line_with_the_peer_exchange():
     """bench.py --gpus 2: both exchanges are tried; two ranks on one device cannot have an RCCL communicator, so the
     line is the peer exchange's and says so."""

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--iterations", type=int, default=6)
     ap.add_argument("--calls", type=int, default=3)
     ap.add_argument("--time", type=int, default=0, help="also time this many iterations of each exchange")
+    ap.add_argument("--math", default="exact", choices=["exact", "fast"])
     args = ap.parse_args()
     from mppi_numba_amd import launch
     if not launch.launched_by_a_launcher():
@@ -41,8 +42,8 @@ def main():
     saved = dict(bench.WORKLOADS["c2"])
     bench.WORKLOADS["c2"] = dict(saved, t=args.t)
     with contextlib.redirect_stdout(io.StringIO()):
-        _, _, lin, ang, peer, params = bench.build_planner("c2", args.n, rank=rank, world=world)
-        _, _, lin2, ang2, staged, _ = bench.build_planner("c2", args.n, rank=rank, world=world)
+        _, _, lin, ang, peer, params = bench.build_planner("c2", args.n, rank=rank, world=world, math=args.math)
+        _, _, lin2, ang2, staged, _ = bench.build_planner("c2", args.n, rank=rank, world=world, math=args.math)
     handles = hub.all_gather(peer.p2p_export())
     peer.p2p_connect(handles)
     hub.barrier()
