@@ -303,6 +303,8 @@ def main():
     ap.add_argument("--graph", type=int, default=0, metavar="ITERATIONS",
                     help="hipGraph replay of the iteration loop, that many (even) iterations per graph; "
                          "0 = direct launches (single GPU; same results)")
+    ap.add_argument("--pre-warm", type=int, default=500, dest="pre_warm",
+                    help="untimed iterations before the W warmup + K timed steps (brings the device to its working state)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "p2p", "rccl", "host"],
                     help="multi-GPU packet exchange.  p2p: every rank writes its numbers straight into its peers' "
                          "inboxes from inside the rollout launch (IPC-mapped fine-grained memory; no collective, an "
@@ -524,10 +526,16 @@ def main():
     if args.graph and world == 1 and group_size == 1:
         planner.set_graph_replay(True, args.graph)
 
-    # warm start: one full solve (samples the grids) + 10 iterations
+    # warm start: one full solve (samples the grids) + 10 iterations ...
     runner.solve()
     runner.iterate_async(10)
     runner.synchronize()
+    # ... and the device brought to its working state before the contract's W + K steps: a region of K = 20 iterations
+    # is a third of a millisecond, and the first such regions after start-up read 0.3-1 us per iteration above the
+    # ones that follow (ms_per_step_regions of any line); `--pre-warm` iterations, untimed, said in the line
+    if args.pre_warm > 0:
+        runner.iterate_async(args.pre_warm)
+        runner.synchronize()
 
     # ---- timed region ------------------------------------------------------------
     def timed_region():
@@ -654,6 +662,7 @@ def main():
                                 "RCCL all-gather on the planner's stream" if args.exchange == "rccl" else
                                 (exchange_note or "host-staged through the rendezvous hub (--exchange host)")),
                    "exchange_us_per_step": exchange_us or None,
+                   "pre_warm_iterations": args.pre_warm,
                    "n_ranks_seen_by_rccl": rccl_ranks,
                    "launcher": ("one process, %d devices (mppi_group_*)" % group_size) if group_size > 1 else
                                ("one process per GPU, %s" % ("external launcher (RANK/WORLD_SIZE)"
