@@ -51,3 +51,27 @@ def test_twenty_thousand_iterations_against_the_barrier_synchronised_kernel():
     assert np.array_equal(loop.u_cur_d.copy_to_host(), plain.u_cur_d.copy_to_host())
     assert np.array_equal(loop.costs_d.copy_to_host(), plain.costs_d.copy_to_host())
     print("\n%d iterations, %d checked bit for bit against k_rollout_deep: 0 costs differ" % (ROUNDS * PER_ROUND, ROUNDS))
+
+
+def test_ten_thousand_iterations_of_the_tolerance_kernel_with_and_without_the_fold():
+    """math="fast": 10 000 iterations in calls of uneven length, one launch per iteration against an update launch per
+    iteration: the same control sequence and costs at every check, finite throughout."""
+    _, _, _, _, loop, _ = bench.build_planner("c2", math="fast")
+    _, _, _, _, plain, _ = bench.build_planner("c2", math="fast")
+    plain.set_debug_flags(_lib.DEBUG_NO_REDUCE_FOLD)
+    for planner in (loop, plain):
+        planner.solve()
+    done = 0
+    for call in range(400):
+        k = (7, 25, 1, 64, 28)[call % 5]
+        loop.iterate_async(k)
+        plain.iterate_async(k)
+        done += k
+        if call % 40 == 39:
+            loop.synchronize()
+            plain.synchronize()
+            u, c = loop.u_cur_d.copy_to_host(), loop.costs_d.copy_to_host()
+            assert np.isfinite(u).all() and np.isfinite(c).all()
+            assert np.array_equal(u, plain.u_cur_d.copy_to_host()), done
+            assert np.array_equal(c, plain.costs_d.copy_to_host()), done
+    assert "reduces_tiles=1" in loop.last_rollout_kernel() and done == 10000, (done, loop.last_rollout_kernel())
