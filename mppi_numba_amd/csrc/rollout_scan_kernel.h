@@ -204,8 +204,9 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
   // the very function block t of k_combine_tiles runs; wave 0 then collects the published sequence.  The packets are
   // requested before anything else and combined behind the Philox blocks: a trip of ~1.5 us either way.
   const bool reducing = folded && pend.reduce_tiles != nullptr;
+  const int n_red = min(2, W);  // (a horizon of <= 8 steps is one wave)
   const int red_t = tile + c * n_rollout_blocks;
-  const bool reduce_here = reducing && c < 2 && red_t < T;
+  const bool reduce_here = reducing && c < n_red && red_t < T;
   StepLoads red_loads;
   float2 red_u = make_float2(0.0f, 0.0f);
   if (reduce_here) {
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16
       const int stride = tile_packet_floats(T);
       publish_step(pend, combine_step_finish(red_loads, pend.reduce_tiles, pend.reduce_n_tiles, stride, red_t, pend.lambda, lane),
                    red_u, red_t, T, lane);
-      for (int tt = red_t + 2 * n_rollout_blocks; tt < T; tt += 2 * n_rollout_blocks)
+      for (int tt = red_t + n_red * n_rollout_blocks; tt < T; tt += n_red * n_rollout_blocks)
         publish_step(pend, combine_step(pend.reduce_tiles, pend.reduce_n_tiles, stride, tt, pend.lambda, lane), uq[tt], tt, T, lane);
     }
     if (c == 0) collect_published(pend, T, 8 * W, lane, u_sh);

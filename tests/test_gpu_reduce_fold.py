@@ -132,7 +132,7 @@ def test_the_loop_noise_of_a_folded_iteration_against_the_oracle():
     assert (costs == want).mean() >= 0.999 and rel.max() <= 1e-6
 
 
-@pytest.mark.parametrize("n,t", [(8192, 100), (8192, 128), (4096, 30), (1000, 100), (200, 100), (40, 17), (64, 100)])
+@pytest.mark.parametrize("n,t", [(8192, 100), (8192, 128), (4096, 30), (1000, 100), (200, 100), (40, 17), (64, 100), (40, 5), (100, 8)])
 def test_fast_mode_loop_with_the_fold_equals_the_loop_with_update_launches(n, t):
     """math="fast" (k_rollout_scan, the tolerance kernel): the same fold, the same statement -- u and costs of the loop
     with one launch per iteration are the bits of the loop with an update launch per iteration."""
