@@ -326,7 +326,11 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     }
     for (int i = lane; i < 8 * 16; i += 64) a_done[i] = 0;
   }
-  lds_barrier();  // (every wave has only just started)
+  // The workgroup's one barrier before the flags are used.  In a launch that combines the previous launch's tile
+  // packets (reducing) every wave takes it where it would otherwise wait for the updated controls -- the chunk waves
+  // behind their Philox blocks, wave 0 when it has collected the sequence -- so that nobody stands at a barrier while
+  // the packets are on their way, and the barrier's release is the hand-over of u_sh.
+  if (!reducing || c == 1 || (walker < 0 && g < 0)) lds_barrier();  // (every wave has only just started; the cost walker and a wave without a group have nothing else to do)
   MPPI_STAMP(stamp_wg && c < 16, stamp_base + 9);
   // Everything a flag guards is in LDS, and the LDS executes one wave's instructions in the order they
   // were issued: a flag written after the data IS after the data for every other wave.  No s_waitcnt
@@ -380,6 +384,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
       MPPI_STAMP(stamp_wg, stamp_base + 6);
       if (walker == 0) collect_published(pend, T, Tp, lane, u_sh);
       MPPI_STAMP(stamp_wg, stamp_base + 7);
+      lds_barrier();  // (the workgroup's barrier: u_sh is there for everybody behind it)
     } else if (walker == 0) {
       // Several GPUs: the packets were all-gathered before the launch.  k_apply's expressions in k_apply's
       // order: the same bits in every workgroup and on every rank.
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
         pend.stats[1] = scale_sh[kMaxFoldedRanks];
       }
     }
-    if (walker == 0) raise(&u_ready[0], 1);
+    if (walker == 0 && !reducing) raise(&u_ready[0], 1);
   }
 
   // Groups handed to a walker.  Two register sets: while one group is walked the next one's operands
@@ -677,7 +682,8 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
       e2[t * R + (r ^ (t & (R - 1)))] = e[j];
     }
     if (folded) {  // (wave-uniform) the sequence this launch's update leaves: formed by wave 0 meanwhile
-      (void)wait_for(&u_ready[0]);
+      if (reducing) lds_barrier();
+      else (void)wait_for(&u_ready[0]);
 #pragma unroll
       for (int j = 0; j < CHL; ++j) ut[j] = u_sh[t0 + j];
     }
