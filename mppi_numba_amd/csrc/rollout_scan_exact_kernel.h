@@ -289,6 +289,10 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     red_u = uq[red_t];
   }
 
+  // the start cell (the traction every visited cell is assumed to carry): requested at once -- the theta walk needs
+  // it for its very first step
+  const uint32_t ref = scan_lookup<POW2RES>(Q, cells16, Q.x0, Q.y0) & 0x3fffu;
+
   char* base = reinterpret_cast<char*>(scan_lds);
   float2* e2 = reinterpret_cast<float2*>(base);                                  // [Tp][R] (swizzled)
   double* ccr = reinterpret_cast<double*>(base + L::e2(W));                      // [2W][R][CHL]
@@ -518,7 +522,6 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     // cycles: what counts is the instruction count -- one pointer per group, immediate offsets (the
     // row stride is a compile-time constant of each of the two instances below)
     __builtin_amdgcn_s_setprio(3);
-    const uint32_t ref = scan_lookup<POW2RES>(Q, cells16, Q.x0, Q.y0) & 0x3fffu;
     auto walk = [&](auto stride_tag, double coeff, float start, float* out, size_t half, const int* in_flags,
                     int* out_flags) {
       constexpr int OS = decltype(stride_tag)::value;  // floats per row
@@ -701,7 +704,6 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     if ((c & 3) == 0) __builtin_amdgcn_s_setprio(0);  // (beside the theta and x | y walks from here on)
     MPPI_STAMP(stamp_wg && c < 16, stamp_base + 1);
     // (everything the walks do not wait for comes after their flags)
-    const uint32_t ref = scan_lookup<POW2RES>(Q, cells16, Q.x0, Q.y0) & 0x3fffu;
 
     // ---------------------------------------------------------------- the control-cost terms of this wave's steps:
     // lambda * (u0/s0^2 * e0 + u1/s1^2 * e1) in float64 (mppi.py:1007-1009), needed after the terminal cost only.
