@@ -567,7 +567,7 @@ static int planner_alloc(mppi_planner* p) {
       HIP_TRY(hipMemsetAsync(p->tile_packets[b], 0, tiles * (size_t)tile_packet_floats((int)T) * sizeof(float), p->stream));
     }
     TRY(dev_alloc(&p->published, published_words((int)T)));
-    HIP_TRY(hipMemsetAsync(p->published, 0, sizeof(unsigned long long) * published_words((int)T), p->stream));
+    HIP_TRY(hipMemsetAsync(p->published, 0xff, sizeof(unsigned long long) * published_words((int)T), p->stream));  // (kNotPublished)
   }
   TRY(dev_alloc(&p->stats, 2 * B));
   TRY(dev_alloc(&p->state_rollout, (size_t)c.num_vis_state_rollouts * (T + 1) * 3));

@@ -105,13 +105,13 @@ struct PendingApply {
   // One GPU, iteration loop of the time-parallel exact kernel (round 4): the previous launch left one packet per
   // TILE and no update kernel ran.  Workgroup t of this launch (t < T; its otherwise idle theta walker) combines the
   // tile packets for step t exactly as block t of k_combine_tiles would -- the same function, the same bits -- and
-  // publishes u[t] to every other workgroup through `published`: two 8-byte words {float value; uint32 1} per step,
+  // publishes u[t] to every other workgroup through `published`: one 8-byte word {float x; float y} per step (kNotPublished until then),
   // written and polled at agent scope (the word carries its own flag: no fence, no second round trip).  Set
   // `flag_set` is used by this launch and the other one is cleared for the launch after next; k_combine_tiles, which
   // closes every loop, clears both.
   const float* reduce_tiles;        // [reduce_n_tiles][tile_packet_floats(T)]; nullptr: not this mode
   int reduce_n_tiles;
-  unsigned long long* published;    // [2][T][kPublishedStride] words, two used per step
+  unsigned long long* published;    // [2][T][kPublishedStride] words, one used per step
   int flag_set;
   // Several GPUs in that mode (round 4, the peer exchange): the workgroup that has combined the LOCAL tiles for
   // step t writes this rank's four numbers for that step -- beta_g, den_g, num_g[t] -- straight into every rank's
@@ -297,16 +297,19 @@ __device__ __forceinline__ StepSums exchange_step(const PeerExchange& X, const S
   return S;
 }
 
-// The published sequence: the two words of step t, {float u.x; uint32 1} {float u.y; uint32 1}, sit 4 KiB apart
-// from the next step's -- 256 workgroups poll them while ~100 publish: next to each other they are one hot spot of
-// a dozen cache lines behind one memory channel.
+// The published sequence: ONE 8-byte word per step, {float u.x; float u.y}; a word that has not been written holds
+// kNotPublished (all ones: a pair of NaNs with a payload no arithmetic produces; a control that did come out as that
+// very pattern is published with its lowest bit flipped -- still a NaN).  The words sit 4 KiB apart -- 256 workgroups
+// poll them while ~100 publish: next to each other they are one hot spot behind one memory channel.
 constexpr int kPublishedStride = 512;  // words per step
+constexpr unsigned long long kNotPublished = ~0ull;
 __host__ __device__ inline size_t published_words(int n_steps) { return (size_t)2 * n_steps * kPublishedStride; }
-__device__ __forceinline__ unsigned long long published_word(float v) {
-  return (1ull << 32) | (unsigned long long)__float_as_uint(v);
+__device__ __forceinline__ unsigned long long published_word(float2 v) {
+  const unsigned long long w = ((unsigned long long)__float_as_uint(v.y) << 32) | (unsigned long long)__float_as_uint(v.x);
+  return w == kNotPublished ? w ^ 1ull : w;
 }
 
-// PendingApply::reduce_tiles, one wave of workgroup `tile`: step t of the update -> both published words (and the
+// PendingApply::reduce_tiles, one wave of workgroup `tile`: step t of the update -> its published word (and the
 // handle's other control buffer, u_prev, the update's {beta, den}); the words of the other set are cleared
 __device__ __forceinline__ void publish_step(const PendingApply& A, StepSums S, float2 u_old, int t, int n_steps,
                                              int lane) {
@@ -316,10 +319,8 @@ __device__ __forceinline__ void publish_step(const PendingApply& A, StepSums S, 
     const float2 ut = updated_control(u_old, S.nx, S.ny, S.den, A.v_lo, A.v_hi, A.w_lo, A.w_hi);
     unsigned long long* mine = A.published + ((size_t)A.flag_set * n_steps + t) * kPublishedStride;
     unsigned long long* other = A.published + ((size_t)(A.flag_set ^ 1) * n_steps + t) * kPublishedStride;
-    __hip_atomic_store(mine, published_word(ut.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(mine + 1, published_word(ut.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    other[0] = 0ull;  // (polled again two launches from now at the earliest)
-    other[1] = 0ull;
+    __hip_atomic_store(mine, published_word(ut), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    other[0] = kNotPublished;  // (polled again two launches from now at the earliest)
     A.u_out[t] = ut;
     A.u_prev[t] = ut;
     if (t == 0) {
@@ -341,16 +342,15 @@ __device__ __forceinline__ void collect_published(const PendingApply& A, int n_s
   // polls, and then publish what they have and raise the fault word: the collectors must outlast that, not trap first)
   const int limit = A.peers.world > 0 ? 8 * min(max(A.peers.max_polls, 1 << 17), 1 << 27) : (1 << 20);
   for (int base = 0; base < padded_steps; base += 128) {  // (one round for T <= 128)
-    unsigned long long wx[2] = {0ull, 0ull}, wy[2] = {0ull, 0ull};
+    unsigned long long w[2] = {kNotPublished, kNotPublished};
     for (int polls = 0;; ++polls) {
       bool all_there = true;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int t = base + lane + 64 * q;
-        if (t < n_steps && ((wx[q] & wy[q]) >> 32) == 0ull) {
-          wx[q] = __hip_atomic_load(words + (size_t)t * kPublishedStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          wy[q] = __hip_atomic_load(words + (size_t)t * kPublishedStride + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          all_there = all_there && ((wx[q] & wy[q]) >> 32) != 0ull;
+        if (t < n_steps && w[q] == kNotPublished) {
+          w[q] = __hip_atomic_load(words + (size_t)t * kPublishedStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          all_there = all_there && w[q] != kNotPublished;
         }
       }
       if (__all(all_there)) break;
@@ -361,7 +361,7 @@ __device__ __forceinline__ void collect_published(const PendingApply& A, int n_s
     for (int q = 0; q < 2; ++q) {
       const int t = base + lane + 64 * q;
       if (t < padded_steps)
-        u_sh[t] = t < n_steps ? make_float2(__uint_as_float((unsigned int)wx[q]), __uint_as_float((unsigned int)wy[q]))
+        u_sh[t] = t < n_steps ? make_float2(__uint_as_float((unsigned int)w[q]), __uint_as_float((unsigned int)(w[q] >> 32)))
                               : make_float2(0.0f, 0.0f);
     }
   }
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(64) void k_combine_tiles(const float* __restrict__ 
                                                       unsigned long long* __restrict__ published, PeerExchange peers) {
   if (gen_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *gen_counter += gen_bump;
   const int t = blockIdx.x, inst = blockIdx.y, lane = threadIdx.x;
-  if (published && inst == 0 && lane < 4) published[((size_t)(lane >> 1) * n_steps + t) * kPublishedStride + (lane & 1)] = 0ull;
+  if (published && inst == 0 && lane < 2) published[((size_t)lane * n_steps + t) * kPublishedStride] = kNotPublished;
   [[maybe_unused]] const bool stamp_wg = (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && blockIdx.y == 0;
   [[maybe_unused]] const int stamp_base = blockIdx.x == 0 ? 520 : 528;
   MPPI_STAMP(stamp_wg, stamp_base + 0);
