@@ -386,7 +386,7 @@ int mppi_planner_p2p_export(mppi_planner* p, char handle[MPPI_P2P_HANDLE_BYTES])
 int mppi_planner_p2p_connect(mppi_planner* p, const char* handles, int count);
 int mppi_group_p2p_connect(mppi_planner** planners, int count);
 int mppi_planner_p2p_stats(mppi_planner* p, int* connected, long* exchanges, char* kind, int capacity);
-/* all ranks together, after connecting: every rank writes `token` (non-zero, the same on all ranks, new for every
+/* all ranks together, after connecting: every rank writes `token` (neither 0 nor all ones, the same on all ranks, new for every
  * call) into every inbox and waits up to ~timeout_ms for the others' -- without trapping.  *heard == world_size: peer
  * stores reach this rank's running kernels, the exchange can be trusted; otherwise switch it off on ALL ranks. */
 int mppi_planner_p2p_ping(mppi_planner* p, unsigned long long token, int timeout_ms, int* heard);

@@ -1638,6 +1638,9 @@ extern "C" int mppi_group_iterate_async(mppi_planner** ps, mppi_tdm** lins, mppi
 // ---- the peer exchange (include/mppi_hip.h; update_kernels.h: PeerExchange) -----------------------------------
 static int p2p_alloc_inbox(mppi_planner* p, hipIpcMemHandle_t* handle) {
   if (p->inbox) {
+    // (exported again, i.e. about to be connected again -- after a fault the words of a broken exchange may still be here)
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemset(p->inbox, 0xff, sizeof(unsigned long long) * inbox_words(p->cfg.world_size, p->cfg.num_steps)));
     if (handle) HIP_TRY(hipIpcGetMemHandle(handle, p->inbox));
     return MPPI_OK;
   }
@@ -1661,7 +1664,7 @@ static int p2p_alloc_inbox(mppi_planner* p, hipIpcMemHandle_t* handle) {
     if (handle) *handle = h;
     p->inbox = static_cast<unsigned long long*>(ptr);
     p->inbox_kind = k.name;
-    HIP_TRY(hipMemset(p->inbox, 0, bytes));
+    HIP_TRY(hipMemset(p->inbox, 0xff, bytes));  // (kNotArrived everywhere; the ping words: any token but all ones)
     return MPPI_OK;
   }
   return fail(MPPI_ERR_HIP, "could not allocate an exportable inbox for the peer exchange");
@@ -1768,7 +1771,7 @@ extern "C" int mppi_group_p2p_connect(mppi_planner** ps, int count) {
 extern "C" int mppi_planner_p2p_ping(mppi_planner* p, unsigned long long token, int timeout_ms, int* heard) {
   REQUIRE(p && heard, MPPI_ERR_INVALID, "NULL argument");
   REQUIRE(p->inbox && p->peer_inbox[p->cfg.rank], MPPI_ERR_STATE, "the peer exchange is not connected");
-  REQUIRE(token != 0ull, MPPI_ERR_INVALID, "token 0 is what an empty slot holds");
+  REQUIRE(token != 0ull && token != ~0ull, MPPI_ERR_INVALID, "tokens 0 and all-ones are what empty slots hold");
   HIP_TRY(hipSetDevice(p->cfg.device));
   int* result = nullptr;
   TRY(dev_alloc(&result, 1));

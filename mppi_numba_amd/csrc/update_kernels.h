@@ -60,9 +60,9 @@ __device__ __forceinline__ void apply_update(float2* u, float2* u_prev, float2* 
 constexpr int kMaxFoldedRanks = 16;
 
 // The peer exchange (no RCCL on the iteration's path).  Every rank owns an INBOX in fine-grained device memory:
-// [2 sets][world][T steps][8 words]; rank g's numbers for step t -- the doubles beta_g, den_g, num_g[t].x, num_g[t].y of
-// its packet (packet_len) -- arrive as eight 8-byte words {uint32 half of a double; uint32 1}: each word carries its
-// own flag, so nothing orders them and nobody fences.  Set `set` is used by this exchange; the reader clears the
+// [2 sets][world][T steps][4 words]; rank g's numbers for step t -- the doubles beta_g, den_g, num_g[t].x, num_g[t].y of
+// its packet (packet_len) -- arrive as four 8-byte words, the doubles themselves, over kNotArrived (all ones): each word
+// is its own flag, so nothing orders them and nobody fences.  Set `set` is used by this exchange; the reader clears the
 // words it has read (the peers write this set again two exchanges later, after they have received what this rank
 // sends in between, from its next launch: exchange_step).  world <= kMaxFoldedRanks.
 struct PeerExchange {
@@ -72,7 +72,9 @@ struct PeerExchange {
   int max_polls;                               // ... i.e. after this many polls (~0.3 us each)
 };
 // (+ one PING word per rank behind the two sets: mppi_planner_p2p_ping)
-__host__ __device__ inline size_t inbox_ping_offset(int world, int n_steps) { return (size_t)2 * world * n_steps * 8; }
+constexpr int kInboxWords = 4;                          // words per (rank, step): beta_g, den_g, num_g[t].x, num_g[t].y
+constexpr unsigned long long kNotArrived = ~0ull;       // (a NaN no arithmetic produces; a number that IS that pattern is sent with its lowest bit flipped)
+__host__ __device__ inline size_t inbox_ping_offset(int world, int n_steps) { return (size_t)2 * world * n_steps * kInboxWords; }
 __host__ __device__ inline size_t inbox_words(int world, int n_steps) { return inbox_ping_offset(world, n_steps) + kMaxFoldedRanks; }
 
 // Can this rank's peers be heard?  Every rank writes `token` into its slot of every inbox and waits -- for a bounded
@@ -226,34 +228,32 @@ __device__ __forceinline__ StepSums combine_step(const float* __restrict__ tile_
 // returns MPPI_ERR_COMM: garbage in u, but a running device and a process that can report.
 __device__ __forceinline__ StepSums exchange_step(const PeerExchange& X, const StepSums& mine, int t, int n_steps, float lambda,
                                                   int lane, double* beta_out) {
-  const size_t set_words = (size_t)X.world * n_steps * 8;
+  constexpr int NW = kInboxWords;
+  const size_t set_words = (size_t)X.world * n_steps * NW;
   unsigned long long* own = X.inbox[X.rank];
   // (the words of this set for this step were cleared by this very workgroup when it had read them two exchanges ago
   //  -- a launch boundary ago at least: see below)
-  // this rank's eight words: lane i < 8 holds word i
+  // this rank's four words: lane i < 4 holds number i
   const double vals[4] = {(double)mine.beta, mine.den, mine.nx, mine.ny};
   unsigned long long word = 0ull;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(vals[k]);
-    if (lane == 2 * k) word = (1ull << 32) | (bits >> 32);
-    if (lane == 2 * k + 1) word = (1ull << 32) | (bits & 0xffffffffull);
-  }
+  for (int k = 0; k < 4; ++k)
+    if (lane == k) word = (unsigned long long)__double_as_longlong(vals[k]);
+  word = word == kNotArrived ? word ^ 1ull : word;
   const size_t slot = ((size_t)X.set * X.world + X.rank) * n_steps + t;  // (the same place in every inbox)
   for (int q = 0; q < X.world; ++q)
-    if (lane < 8) __hip_atomic_store(X.inbox[q] + slot * 8 + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  // receive: lane i polls word i & 7 of rank i >> 3 (and of rank 8 + (i >> 3) when there are more than 8)
-  unsigned long long got[2] = {0ull, 0ull};
+    if (lane < NW) __hip_atomic_store(X.inbox[q] + slot * NW + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // receive: lane i polls number i & 3 of rank i >> 2 (world <= 16: one word per lane)
+  unsigned long long got = kNotArrived;
   const unsigned long long* in = own + (size_t)X.set * set_words;
   for (int polls = 0;; ++polls) {
     bool all_there = true;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int q = 8 * h + (lane >> 3);
-      if (q < X.world && (got[h] >> 32) == 0ull) {
-        got[h] = __hip_atomic_load(const_cast<unsigned long long*>(in) + ((size_t)q * n_steps + t) * 8 + (lane & 7), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_SYSTEM);
-        all_there = all_there && (got[h] >> 32) != 0ull;
+    {
+      const int q = lane >> 2;
+      if (q < X.world && got == kNotArrived) {
+        got = __hip_atomic_load(const_cast<unsigned long long*>(in) + ((size_t)q * n_steps + t) * NW + (lane & 3), __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_SYSTEM);
+        all_there = got != kNotArrived;
       }
     }
     if (__all(all_there)) break;
@@ -269,14 +269,14 @@ __device__ __forceinline__ StepSums exchange_step(const PeerExchange& X, const S
   // then -- a peer sends into this set again only after it has received what this rank sends in the NEXT exchange,
   // which this rank's next launch does, and these stores are performed when this launch ends.  (Clearing the other
   // set BEFORE sending, as the first version did, put a round trip to memory in front of every send.)
-  for (int i = lane; i < 8 * X.world; i += 64)
-    __hip_atomic_store(const_cast<unsigned long long*>(in) + ((size_t)(i >> 3) * n_steps + t) * 8 + (i & 7), 0ull,
+  if (lane < NW * X.world)
+    __hip_atomic_store(const_cast<unsigned long long*>(in) + ((size_t)(lane >> 2) * n_steps + t) * NW + (lane & 3), kNotArrived,
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // k_apply's lines over the ranks' numbers (wave-uniform: every lane computes the same)
+  const unsigned int got_lo = (unsigned int)got, got_hi = (unsigned int)(got >> 32);
   auto number = [&](int q, int k) {  // double k of rank q
-    const unsigned int src = (q >= 8 ? got[1] : got[0]) & 0xffffffffu;
-    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)src, 8 * (q & 7) + 2 * k);
-    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)src, 8 * (q & 7) + 2 * k + 1);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)got_hi, NW * q + k);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)got_lo, NW * q + k);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
   };
   double beta = number(0, 0);

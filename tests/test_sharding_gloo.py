@@ -178,23 +178,24 @@ def test_shard_ranges_cover_all_rollouts():
 
 
 # ---- the peer exchange (update_kernels.h: PeerExchange / exchange_step), restated ------------------------------
+NOT_ARRIVED = np.uint64(0xffffffffffffffff)  # update_kernels.h: kNotArrived
+
+
 def words_of(values):
-    """Four doubles -> eight 8-byte words {uint32 half; uint32 1}: every word carries its own flag."""
-    bits = np.asarray(values, dtype=np.float64).view(np.uint64)
-    out = np.empty(8, dtype=np.uint64)
-    out[0::2] = (np.uint64(1) << np.uint64(32)) | (bits >> np.uint64(32))
-    out[1::2] = (np.uint64(1) << np.uint64(32)) | (bits & np.uint64(0xffffffff))
-    return out
+    """Four doubles -> four 8-byte words, the doubles themselves: a word is its own flag (anything but all ones has
+    arrived; a number that IS that pattern is sent with its lowest bit flipped)."""
+    bits = np.asarray(values, dtype=np.float64).view(np.uint64).copy()
+    bits[bits == NOT_ARRIVED] ^= np.uint64(1)
+    return bits
 
 
 def doubles_of(words):
-    assert ((words >> np.uint64(32)) == 1).all(), "a word that has not arrived"
-    half = words & np.uint64(0xffffffff)
-    return ((half[0::2] << np.uint64(32)) | half[1::2]).view(np.float64)
+    assert (words != NOT_ARRIVED).all(), "a word that has not arrived"
+    return words.view(np.float64)
 
 
 def _peer_worker(rank, world, port, q):
-    """Two ranks, every step of every iteration exchanged separately through per-rank inboxes [2 sets][world][T][8]
+    """Two ranks, every step of every iteration exchanged separately through per-rank inboxes [2 sets][world][T][4]
     (gloo send / recv stand in for the stores into the peer's memory): the reader clears the slots it has read (the set
     is written again two exchanges later), the numbers are combined with k_apply's expressions.  Must equal the all-gather of
     whole packets + apply_packets, bit for bit, over several iterations (both sets in use)."""
@@ -212,7 +213,7 @@ def _peer_worker(rank, world, port, q):
         P = params_from_golden(g)
         its = iterations(g)
         t_steps = its[0]["u_in"].shape[0]
-        inbox = np.zeros((2, world, t_steps, 8), dtype=np.uint64)
+        inbox = np.full((2, world, t_steps, 4), NOT_ARRIVED, dtype=np.uint64)
         exchange = 0
         for rep in range(3):
             for it in its:
@@ -228,16 +229,16 @@ def _peer_worker(rank, world, port, q):
                     for peer in range(world):
                         if peer == rank:
                             continue
-                        got = torch.zeros(8, dtype=torch.int64)
+                        got = torch.zeros(4, dtype=torch.int64)
                         reqs = [dist.isend(torch.from_numpy(mine.view(np.int64).copy()), peer), dist.irecv(got, peer)]
                         for r in reqs:
                             r.wait()
-                        assert (inbox[s, peer, t] == 0).all(), "slot not cleared"
+                        assert (inbox[s, peer, t] == NOT_ARRIVED).all(), "slot not cleared"
                         inbox[s, peer, t] = got.numpy().view(np.uint64)
                     rows = np.stack([doubles_of(inbox[s, g_, t]) for g_ in range(world)])  # beta, den, nx, ny per rank
                     step_packets = np.concatenate([rows[:, :2], rows[:, 2:]], axis=1)
                     u[t] = apply_packets(step_packets, P["lambda_weight"], it["u_in"][t:t + 1], P["vrange"], P["wrange"])[0]
-                    inbox[s, :, t, :] = 0  # (read: cleared for the exchange after next, update_kernels.h exchange_step)
+                    inbox[s, :, t, :] = NOT_ARRIVED  # (read: cleared for the exchange after next, update_kernels.h exchange_step)
                 gathered = [torch.zeros(packet.size, dtype=torch.float64) for _ in range(world)]
                 dist.all_gather(gathered, torch.from_numpy(packet))
                 want = apply_packets(np.stack([x.numpy() for x in gathered]), P["lambda_weight"], it["u_in"], P["vrange"], P["wrange"])
