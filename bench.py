@@ -303,7 +303,7 @@ def main():
     ap.add_argument("--graph", type=int, default=0, metavar="ITERATIONS",
                     help="hipGraph replay of the iteration loop, that many (even) iterations per graph; "
                          "0 = direct launches (single GPU; same results)")
-    ap.add_argument("--pre-warm", type=int, default=500, dest="pre_warm",
+    ap.add_argument("--pre-warm", type=int, default=2000, dest="pre_warm",
                     help="untimed iterations before the W warmup + K timed steps (brings the device to its working state)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "p2p", "rccl", "host"],
                     help="multi-GPU packet exchange.  p2p: every rank writes its numbers straight into its peers' "
@@ -533,9 +533,13 @@ def main():
     # ... and the device brought to its working state before the contract's W + K steps: a region of K = 20 iterations
     # is a third of a millisecond, and the first such regions after start-up read 0.3-1 us per iteration above the
     # ones that follow (ms_per_step_regions of any line); `--pre-warm` iterations, untimed, said in the line
-    if args.pre_warm > 0:
-        runner.iterate_async(args.pre_warm)
+    # (in calls of K iterations like the timed ones: host and device in the rhythm of the timed region)
+    done = 0
+    while done < args.pre_warm:
+        k = min(max(1, args.steps), args.pre_warm - done)
+        runner.iterate_async(k)
         runner.synchronize()
+        done += k
 
     # ---- timed region ------------------------------------------------------------
     def timed_region():
