@@ -320,7 +320,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   int* ev_done = xy_done + 16;                      // [16] freeze / goal events of the group and of all before it (chunk wave)
   int* c_done = ev_done + 16;                       // [16] records (chunk wave): 1, or 3 = a penalty in the group
   int* cc_done = c_done + 16;                       // [16] control-cost terms (chunk wave)
-  int* u_ready = cc_done + 16;                      // [0] the updated control sequence is in u_sh (wave 0; folded launches)
+  int* u_ready = cc_done + 16;                      // [0] the updated control sequence is in u_sh (wave 0; launches that apply all-gathered packets: one that combines tile packets hands u_sh over at the workgroup's barrier)
   double2* stop_sh = reinterpret_cast<double2*>(u_ready + 16);  // [2W][R] {stage cost of a rollout stopped in this chunk; bits}
   if (c == 4) {
     if (lane < R) {
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   if (folded && (walker == 0 || walker == 1)) {
     __builtin_amdgcn_s_setprio(3);
     // The update this launch owes (update_kernels.h, PendingApply), while the chunk waves draw their Philox
-    // blocks; the chunk waves pick the new sequence up from LDS behind u_ready.  (Here, next to the entry code, not
+    // blocks; the chunk waves pick the new sequence up from LDS behind u_ready or the barrier.  (Here, next to the entry code, not
     // inside the walkers' branch: a cold instruction fetch is ~1k cycles for a lone wave.)
     if (reducing) {
       // One GPU: this wave's step(s) of the update, exactly as block t of k_combine_tiles forms them, published to
