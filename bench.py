@@ -24,6 +24,7 @@ configuration BASELINE.json's metric is quoted on):
   c2  use_det_dynamics, N=8192 per GPU, T=100, 256x256 nominal traction grid
   c3  use_tdm (CVaR), N=4096 x M=128, 16-bin PMF, 256x256
   c4  use_det_dynamics, N=65536 per GPU, T=200, CVaR-bin traction
+  ns  use_det_dynamics, N=65536 per GPU, T=100, nominal grid: north_star's target shape on one GPU
   c5  batched multi-query: 64 independent problems (own start / goal) x N=4096 per GPU, T=100,
       one launch over (problem, rollout); with several GPUs every rank solves its own 64
       problems (no exchange at all)
@@ -59,7 +60,7 @@ def synthetic_world(workload, rng):
     for m in (obstacle, unknown):
         m[12:20, 12:20] = 0
         m[236:244, 236:244] = 0
-    if workload == "c2":
+    if workload in ("c2", "ns"):
         bins = 2
         pmf = np.zeros((bins, rows, cols), dtype=np.int8)
         pmf[-1] = 100  # nominal traction (README.md:136-151 recipe)
@@ -111,6 +112,9 @@ def make_params(workload):
 WORKLOADS = {
     "c2": dict(n=8192, t=100, m=1, mode=dict(use_det_dynamics=True),
                label="Unicycle MPPI det-dyn, N=8192/GPU, T=100, 256x256 nominal traction grid"),
+    # north_star's own target shape on ONE GPU: the denominator of "scaling 1 -> 8 GPUs at N=65536, T=100" 
+    "ns": dict(n=65536, t=100, m=1, mode=dict(use_det_dynamics=True),
+               label="Unicycle MPPI det-dyn, N=65536/GPU, T=100, 256x256 nominal traction grid (north_star's shape on one GPU)"),
     # the C2 shape on maps the time-parallel kernel's assumption does not hold on
     "c2s": dict(n=8192, t=100, m=1, mode=dict(use_det_dynamics=True),
                 label="Unicycle MPPI det-dyn, N=8192/GPU, T=100, 256x256 SEMANTIC map: 4 terrain types in patches of 4-16 m"),

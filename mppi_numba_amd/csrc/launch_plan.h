@@ -787,7 +787,7 @@ static int try_launch_pipe(mppi_planner* p, DevParams& d, const DetRegime& r, bo
     if (p->inst_set) while (p->inst_tiles % pairs != 0) --pairs;
     const size_t budget = (size_t)p->lds_per_cu - 1024;
     auto ring_bytes = [&](int chunk) {
-      return (size_t)pairs * (2 * (size_t)chunk * 64 * (sizeof(float2) + sizeof(double2)) + 2 * (size_t)chunk * 64);
+      return (size_t)pairs * (2 * (size_t)chunk * 64 * (sizeof(float2) + sizeof(double2)) + 2 * (size_t)chunk * 64 * 2);
     };
     int chunk = 0;
     for (;;) {  // fewer triples per workgroup (more workgroups than CUs) before giving the kernel up

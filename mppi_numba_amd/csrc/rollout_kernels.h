@@ -507,9 +507,116 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
 template <int C>
 struct PipeRing {
   static constexpr int kHalf = C * 64;  // entries per buffer
-  // xy[2][C][64] float2 + qd[2][C][64] double2 {dt*v, dt*w} + flags[2][C][64] bytes
-  static constexpr int kBytesPerPair = 2 * kHalf * (int)sizeof(float2) + 2 * kHalf * (int)sizeof(double2) + 2 * kHalf;
+  // xy[2][C][64] float2 + qd[2][C][64] double2 {dt*v, dt*w} + cell[2][C][64] uint16 (the 16-bit cell a step started in)
+  static constexpr int kBytesPerPair = 2 * kHalf * (int)sizeof(float2) + 2 * kHalf * (int)sizeof(double2) + 2 * kHalf * 2;
 };
+
+// ---- the state role of the exact schedule: one chunk of C steps (round 5) --------------------------------------
+// Per step and rollout the chain is  cell of (x, y) -> LDS lookup -> traction -> x, y, theta (float64 products, one
+// float32 rounding each: mppi.py:977-990) -> next cell.  A lone wave issues one instruction per ~5 cycles whatever its
+// type, so a step costs what the wave issues plus whatever latency nothing covers.  Round 1-4 issued the lookup of
+// step t and waited for it (~100 cycles of an LDS gather with bank conflicts) with four instructions behind it; here
+// the lookup of step t + 1 is issued the moment x_{t+1}, y_{t+1} exist, and the 24 instructions that do not need it
+// (float64 copies of the new state, the rotation of (cos, sin) by the exact heading increment, the ring stores) run in
+// its shadow (sched_barrier keeps the compiler from moving them back in front).  The instruction count per step is
+// cut as well: both cell coordinates in one packed float32 subtract and one packed fma; no clamp (negative
+// coordinates saturate to 0 in v_cvt_u32_f32 and an LDS address beyond the window -- unreachable within the horizon,
+// host-proved; only the ignored steps past the horizon of the last chunk can get there -- reads whatever bytes are
+// there or, past the allocation, zero: nothing faults, nothing is used); the raw 16-bit cell goes to the cost wave
+// instead of a shifted byte.  Same operations on the same operands as before: the oracle's bits.
+typedef float pipe_f2 __attribute__((ext_vector_type(2)));
+
+template <bool POW2RES>
+struct PipeWindow {
+  pipe_f2 lo, origin;     // {xlo, ylo}, {win_c0, win_r0}
+  float inv_res, res;
+  int pitch_bytes, c0, r0, cols, rows;
+  uint32_t base;          // LDS byte address of the window
+  __device__ __forceinline__ PipeWindow(const DevParams& P, const uint16_t* lds_map) {
+    lo = pipe_f2{P.xlo, P.ylo};
+    origin = pipe_f2{(float)P.win_c0, (float)P.win_r0};
+    inv_res = P.inv_res; res = P.res;
+    pitch_bytes = 2 * P.win_cols;
+    c0 = P.win_c0; r0 = P.win_r0; cols = P.win_cols; rows = P.win_rows;
+    base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint16_t*)lds_map;
+  }
+  // LDS byte address of the cell of (x, y)
+  __device__ __forceinline__ uint32_t address(float x, float y) const {
+    uint32_t xi, yi;
+    if (POW2RES) {
+      // d = fl(pos - lo) is the reference's float32 difference; d * inv_res and the subtraction of the integer window
+      // origin are exact (device_math.h, cell_coord_pow2); the truncating conversion is the floor for q >= 0
+      const pipe_f2 q = __builtin_elementwise_fma(pipe_f2{x, y} - lo, pipe_f2{inv_res, inv_res}, -origin);
+      xi = (uint32_t)q.x;  // v_cvt_u32_f32
+      yi = (uint32_t)q.y;
+    } else {
+      xi = (uint32_t)clamp_index(floordiv_to_int(x - lo.x, res, inv_res) - c0, cols);
+      yi = (uint32_t)clamp_index(floordiv_to_int(y - lo.y, res, inv_res) - r0, rows);
+    }
+    uint32_t row, a;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(row) : "v"(yi), "s"(pitch_bytes), "v"(base));  // (one SGPR per VOP3 on gfx9)
+    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(a) : "v"(xi), "v"(row));
+    return a;
+  }
+  // The request only: the value stays a 16-bit load result until pipe_cell_arrived() -- a zero extension next to the
+  // load would be the load's first user, and the wait for the lookup with it.
+  __device__ __forceinline__ uint16_t lookup(float x, float y) const {
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t*>(address(x, y));
+  }
+};
+__device__ __forceinline__ uint32_t pipe_cell_arrived(uint16_t raw) {
+  asm volatile("" : "+v"(raw));  // (the compiler's s_waitcnt for the lookup lands here)
+  return (uint32_t)raw;
+}
+
+struct PipeState {
+  float x, y;
+  double x64, y64, th64, s, c;
+  uint16_t cell;  // the 16-bit cell of (x, y): requested when x, y were formed
+};
+
+// (st.cell: the caller requests the start cell once the window is in LDS -- win.lookup(st.x, st.y))
+__device__ __forceinline__ PipeState pipe_state_init(const DevParams& P) {
+  PipeState st;
+  st.x = P.x0; st.y = P.y0;
+  st.x64 = (double)P.x0; st.y64 = (double)P.y0; st.th64 = (double)P.th0;
+  sincos_f64<false>(st.th64, st.s, st.c);
+  st.cell = 0;
+  return st;
+}
+
+// C steps: reads {dt*v, dt*w} of step j from in_qd[j*64 + lane]; leaves (x, y) after the step in out_xy and the cell the
+// step STARTED in (its obstacle / unknown bits are what the step pays: mppi.py:971-998) in out_cell.
+template <int C, bool POW2RES, bool CHECK_ROTATION>
+__device__ __forceinline__ void pipe_state_chunk(const DevParams& P, const PipeWindow<POW2RES>& win, PipeState& st,
+                                                 const double2* in_qd, float2* out_xy, uint16_t* out_cell, int lane) {
+  double2 qd[C];
+#pragma unroll
+  for (int j = 0; j < C; ++j) qd[j] = in_qd[j * 64 + lane];  // exact products of float32 factors
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    const uint32_t c16 = pipe_cell_arrived(st.cell);
+    const double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), P.lin_lo);
+    const double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), P.ang_lo);
+    const float x = (float)fma(vtr, qd[j].x * st.c, st.x64);
+    const float y = (float)fma(vtr, qd[j].x * st.s, st.y64);
+    const float th = (float)fma(wtr, qd[j].y, st.th64);
+    st.cell = win.lookup(x, y);
+    __builtin_amdgcn_sched_barrier(0);  // ---- everything below runs while the lookup is in flight
+    st.x = x; st.y = y;
+    st.x64 = (double)x;
+    st.y64 = (double)y;
+    const double th_new = (double)th;
+    // exact increment of the ROUNDED heading (beyond the rotation's range -- never with the reference's parameters,
+    // host-proved for k_rollout_pipe -- the full evaluation)
+    if (!CHECK_ROTATION || __all(fabs(th_new - st.th64) <= 0.36)) rotate_sincos_f64(th_new - st.th64, st.s, st.c);
+    else sincos_f64<false>(th_new, st.s, st.c);
+    st.th64 = th_new;
+    out_xy[j * 64 + lane] = make_float2(x, y);
+    out_cell[j * 64 + lane] = (uint16_t)c16;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 
 // Roles of the waves of one workgroup (W = blockDim / 192 triples, triple i = waves
 // i, W+i, 2W+i):  producer -> state -> cost, each one chunk behind the previous.
@@ -547,7 +654,7 @@ __device__ __forceinline__ void pipe_tile_body(DevParams P, const uint16_t* __re
   using Ring = PipeRing<C>;
   float2* ring_xy = reinterpret_cast<float2*>(ring_base + (size_t)triple * Ring::kBytesPerPair);
   double2* ring_qd = reinterpret_cast<double2*>(ring_xy + 2 * Ring::kHalf);
-  uint8_t* ring_flags = reinterpret_cast<uint8_t*>(ring_qd + 2 * Ring::kHalf);
+  uint16_t* ring_cell = reinterpret_cast<uint16_t*>(ring_qd + 2 * Ring::kHalf);
   // control-cost products of this triple's 64 rollouts, [T][64] float64, when LDS has room
   double* cc_lds = reinterpret_cast<double*>(ring_base + (size_t)W * Ring::kBytesPerPair) + (size_t)triple * T * 64;
 
@@ -579,50 +686,16 @@ __device__ __forceinline__ void pipe_tile_body(DevParams P, const uint16_t* __re
   // chunk 0, then one per k = 0..K
 
   if (role == 0) {
-    float x = P.x0, y = P.y0, th = P.th0;
-    double x64 = (double)x, y64 = (double)y, th64 = (double)th;
-    double s, c;
-    sincos_f64<false>(th64, s, c);
-    const float win_c0f = (float)P.win_c0, win_r0f = (float)P.win_r0;
-    const float win_last_col = (float)(P.win_cols - 1), win_last_row = (float)(P.win_rows - 1);
-    const int win_pitch_bytes = 2 * P.win_cols;
-    const char* lds_bytes = reinterpret_cast<const char*>(lds_map);
-    __syncthreads();  // controls of chunk 0 are in the ring
+    const PipeWindow<POW2RES> win(P, lds_map);
+    PipeState st = pipe_state_init(P);
+    __syncthreads();  // controls of chunk 0 are in the ring; the window is in LDS
+    st.cell = win.lookup(st.x, st.y);
     MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 2);
     for (int k = 0; k <= K; ++k) {
-      if (k < K) {
-        const double2* in_qd = ring_qd + (size_t)(k & 1) * Ring::kHalf;
-        float2* out_xy = ring_xy + (size_t)(k & 1) * Ring::kHalf;
-        uint8_t* out_flags = ring_flags + (size_t)(k & 1) * Ring::kHalf;
-#pragma unroll
-        for (int j = 0; j < C; ++j) {
-          double2 qd = in_qd[j * 64 + lane];  // {dt*v, dt*w}: exact products of float32 factors
-          // the window holds every cell reachable within the horizon (host-proved); the
-          // clamp is for memory safety only
-          int xi, yi;
-          if (POW2RES) {  // res is a power of two: see cell_coord_pow2
-            xi = cell_coord_pow2(x, P.xlo, P.inv_res, win_c0f, win_last_col);
-            yi = cell_coord_pow2(y, P.ylo, P.inv_res, win_r0f, win_last_row);
-          } else {
-            xi = clamp_index(floordiv_to_int(x - P.xlo, P.res, P.inv_res) - P.win_c0, P.win_cols);
-            yi = clamp_index(floordiv_to_int(y - P.ylo, P.res, P.inv_res) - P.win_r0, P.win_rows);
-          }
-          // 24-bit multiply-add (full rate) straight to the byte offset
-          uint32_t c16 = *reinterpret_cast<const uint16_t*>(lds_bytes + (__mul24(yi, win_pitch_bytes) + (xi << 1)));
-          double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), P.lin_lo);
-          double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), P.ang_lo);
-          x = (float)fma(vtr, qd.x * c, x64);
-          y = (float)fma(vtr, qd.x * s, y64);
-          th = (float)fma(wtr, qd.y, th64);
-          x64 = (double)x;
-          y64 = (double)y;
-          double th_new = (double)th;
-          rotate_sincos_f64(th_new - th64, s, c);  // exact increment of the ROUNDED heading
-          th64 = th_new;
-          out_xy[j * 64 + lane] = make_float2(x, y);
-          out_flags[j * 64 + lane] = (uint8_t)(c16 >> 14);  // obstacle | unknown << 1 of the cell just left
-        }
-      }
+      if (k < K)
+        pipe_state_chunk<C, POW2RES, false>(P, win, st, ring_qd + (size_t)(k & 1) * Ring::kHalf,
+                                            ring_xy + (size_t)(k & 1) * Ring::kHalf,
+                                            ring_cell + (size_t)(k & 1) * Ring::kHalf, lane);
       MPPI_STAMP(stamp_wg && triple == 0 && k < 32, stamp_base + 3 + k);
       __syncthreads();
     }
@@ -633,16 +706,32 @@ __device__ __forceinline__ void pipe_tile_body(DevParams P, const uint16_t* __re
     const float2* col = noise + (tile_ok ? tile_base : (size_t)0);
     double* my_cc = CC_LDS ? cc_lds + lane : cc_scratch + tile_base;
     float2 e_cur[C], e_nxt[C];
+    // Round 5: the staged controls and ratios of the whole chunk are read first (the same addresses in every lane:
+    // broadcasts) and everything is stored after the arithmetic -- one wait per chunk.  Before, every step read its
+    // u[t], waited, stored, read its ratio inside a predicated block, waited again (each wait also drains the store
+    // in front of it): ~350 cycles per step, the slowest of the three roles (stamps: profiles/r05_pipe_notes.md).
+    // Steps past the horizon repeat step T - 1: the same products to the same address.
     auto produce = [&](int chunk, const float2 (&e)[C]) {
       double2* out_qd = ring_qd + (size_t)(chunk & 1) * Ring::kHalf;
       const double dt64 = (double)P.dt;
+      float2 ut[C];
+      double2 ur[C];
 #pragma unroll
       for (int j = 0; j < C; ++j) {
-        int t = min(chunk * C + j, T - 1);  // steps past the horizon are produced and ignored
-        float2 ut = us[t];
-        out_qd[j * 64 + lane] = make_double2(dt64 * (double)clip_f32(ut.x + e[j].x, P.v_lo, P.v_hi),
-                                             dt64 * (double)clip_f32(ut.y + e[j].y, P.w_lo, P.w_hi));
-        if (tile_ok && chunk * C + j < T) my_cc[(size_t)t * 64] = control_cost(P, uos[t], e[j]);
+        const int t = min(chunk * C + j, T - 1);
+        ut[j] = us[t];
+        ur[j] = uos[t];
+      }
+      double cc[C];
+#pragma unroll
+      for (int j = 0; j < C; ++j) {
+        out_qd[j * 64 + lane] = make_double2(dt64 * (double)clip_f32(ut[j].x + e[j].x, P.v_lo, P.v_hi),
+                                             dt64 * (double)clip_f32(ut[j].y + e[j].y, P.w_lo, P.w_hi));
+        cc[j] = control_cost(P, ur[j], e[j]);
+      }
+      if (tile_ok) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) my_cc[(size_t)min(chunk * C + j, T - 1) * 64] = cc[j];
       }
     };
 #pragma unroll
@@ -674,12 +763,12 @@ __device__ __forceinline__ void pipe_tile_body(DevParams P, const uint16_t* __re
       if (k >= 1) {
         const int t0 = (k - 1) * C;
         const float2* in_xy = ring_xy + (size_t)((k - 1) & 1) * Ring::kHalf;
-        const uint8_t* in_flags = ring_flags + (size_t)((k - 1) & 1) * Ring::kHalf;
+        const uint16_t* in_cell = ring_cell + (size_t)((k - 1) & 1) * Ring::kHalf;
         const int count = min(C, T - t0);
         auto cost_step = [&](int j) {
           float2 xy = in_xy[j * 64 + lane];
-          // obstacle / unknown bits of the cell the step STARTED in (mppi.py:971-998)
-          uint32_t fl = in_flags[j * 64 + lane];
+          // obstacle / unknown bits (14, 15) of the cell the step STARTED in (mppi.py:971-998)
+          uint32_t fl = (uint32_t)in_cell[j * 64 + lane] >> 14;
           double dx = (double)(P.xg - xy.x), dy = (double)(P.yg - xy.y);
           double nd2 = fma(dx, dx, dy * dy);
           float c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(nd2), dt64));

@@ -122,7 +122,7 @@ __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const 
   char* ring_base = reinterpret_cast<char*>(lds_map) + map_bytes;
   float2* ring_xy = reinterpret_cast<float2*>(ring_base);
   double2* ring_qd = reinterpret_cast<double2*>(ring_xy + 2 * Ring::kHalf);
-  uint8_t* ring_flags = reinterpret_cast<uint8_t*>(ring_qd + 2 * Ring::kHalf);
+  uint16_t* ring_cell = reinterpret_cast<uint16_t*>(ring_qd + 2 * Ring::kHalf);
   const int r = lane & (R - 1);
   const int K = (T + C - 1) / C;
   // the window and the controls: everybody; the walks' data under them is dead
@@ -148,50 +148,16 @@ __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const 
       if (k + 1 < K) produce(k + 1);
       __syncthreads();
     }
-  } else if (c == 0) {  // ---- state: pipe_tile_body's role 0
-    float x = P.x0, y = P.y0, th = P.th0;
-    double x64 = (double)x, y64 = (double)y, th64 = (double)th;
-    double sn, cs;
-    sincos_f64<false>(th64, sn, cs);
-    const float win_c0f = (float)P.win_c0, win_r0f = (float)P.win_r0;
-    const float win_last_col = (float)(P.win_cols - 1), win_last_row = (float)(P.win_rows - 1);
-    const int win_pitch_bytes = 2 * P.win_cols;
-    const char* lds_bytes = reinterpret_cast<const char*>(lds_map);
+  } else if (c == 0) {  // ---- state: pipe_tile_body's role 0 (rollout_kernels.h, pipe_state_chunk)
+    const PipeWindow<POW2RES> win(P, lds_map);
+    PipeState st = pipe_state_init(P);
     __syncthreads();
+    st.cell = win.lookup(st.x, st.y);
     for (int k = 0; k <= K; ++k) {
-      if (k < K) {
-        const double2* in_qd = ring_qd + (size_t)(k & 1) * Ring::kHalf;
-        float2* out_xy = ring_xy + (size_t)(k & 1) * Ring::kHalf;
-        uint8_t* out_flags = ring_flags + (size_t)(k & 1) * Ring::kHalf;
-#pragma unroll
-        for (int j = 0; j < C; ++j) {
-          const double2 qd = in_qd[j * 64 + lane];
-          int xi, yi;
-          if (POW2RES) {
-            xi = cell_coord_pow2(x, P.xlo, P.inv_res, win_c0f, win_last_col);
-            yi = cell_coord_pow2(y, P.ylo, P.inv_res, win_r0f, win_last_row);
-          } else {
-            xi = clamp_index(floordiv_to_int(x - P.xlo, P.res, P.inv_res) - P.win_c0, P.win_cols);
-            yi = clamp_index(floordiv_to_int(y - P.ylo, P.res, P.inv_res) - P.win_r0, P.win_rows);
-          }
-          const uint32_t c16 = *reinterpret_cast<const uint16_t*>(lds_bytes + (__mul24(yi, win_pitch_bytes) + (xi << 1)));
-          const double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), P.lin_lo);
-          const double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), P.ang_lo);
-          x = (float)fma(vtr, qd.x * cs, x64);
-          y = (float)fma(vtr, qd.x * sn, y64);
-          th = (float)fma(wtr, qd.y, th64);
-          x64 = (double)x;
-          y64 = (double)y;
-          const double th_new = (double)th;
-          // exact increment of the ROUNDED heading; beyond the rotation's range (never with the reference's
-          // parameters) the full evaluation
-          if (__all(fabs(th_new - th64) <= 0.36)) rotate_sincos_f64(th_new - th64, sn, cs);
-          else sincos_f64<false>(th_new, sn, cs);
-          th64 = th_new;
-          out_xy[j * 64 + lane] = make_float2(x, y);
-          out_flags[j * 64 + lane] = (uint8_t)(c16 >> 14);  // obstacle | unknown << 1 of the cell just left
-        }
-      }
+      if (k < K)
+        pipe_state_chunk<C, POW2RES, true>(P, win, st, ring_qd + (size_t)(k & 1) * Ring::kHalf,
+                                           ring_xy + (size_t)(k & 1) * Ring::kHalf,
+                                           ring_cell + (size_t)(k & 1) * Ring::kHalf, lane);
       __syncthreads();
     }
   } else if (c == 1) {  // ---- cost: pipe_tile_body's role 1
@@ -203,11 +169,11 @@ __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const 
       if (k >= 1) {
         const int t0 = (k - 1) * C;
         const float2* in_xy = ring_xy + (size_t)((k - 1) & 1) * Ring::kHalf;
-        const uint8_t* in_flags = ring_flags + (size_t)((k - 1) & 1) * Ring::kHalf;
+        const uint16_t* in_cell = ring_cell + (size_t)((k - 1) & 1) * Ring::kHalf;
         const int count = min(C, T - t0);
         for (int j = 0; j < count; ++j) {
           const float2 xy = in_xy[j * 64 + lane];
-          const uint32_t fl = in_flags[j * 64 + lane];
+          const uint32_t fl = (uint32_t)in_cell[j * 64 + lane] >> 14;
           const double dx = (double)(P.xg - xy.x), dy = (double)(P.yg - xy.y);
           const double nd2 = fma(dx, dx, dy * dy);
           float c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(nd2), dt64));

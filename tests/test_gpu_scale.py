@@ -28,7 +28,8 @@ def oracle_costs(w, params, lin, ang, noise, u):
 
 
 # which rollout kernel each BASELINE configuration must take (bench.py runs the same objects)
-EXPECTED_KERNEL = {"c2": "k_rollout_scan_exact", "c3": "k_rollout_tdm_fast", "c4": "k_rollout_fused"}
+EXPECTED_KERNEL = {"c2": "k_rollout_scan_exact", "c3": "k_rollout_tdm_fast", "c4": "k_rollout_fused",
+                   "ns": "k_rollout_fused"}
 
 
 def costs_and_update_margin(workload, n):
@@ -63,11 +64,11 @@ def costs_and_update_margin(workload, n):
     return margin
 
 
-@pytest.mark.parametrize("workload,n", [("c2", None), ("c4", None), ("c3", None), ("c4", 16384), ("c3", 192)])
+@pytest.mark.parametrize("workload,n", [("c2", None), ("c4", None), ("c3", None), ("c4", 16384), ("c3", 192), ("ns", None)])
 def test_costs_and_update_vs_oracle_at_scale(workload, n):
     """BASELINE configs[1..3] at FULL size -- C2 N=8192, T=100; C4 N=65536, T=200 (the fused
     throughput kernel); C3 N=4096 x M=128 -- the very objects bench.py times, against the C
-    restatement; plus two reduced cases that take other kernels (C4 at N=16384: pipelined kernel
+    restatement; `ns` = north_star's target shape on one GPU (N=65536, T=100, nominal map); plus two reduced cases that take other kernels (C4 at N=16384: pipelined kernel
     at T=200)."""
     costs_and_update_margin(workload, n)
 
