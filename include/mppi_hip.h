@@ -40,7 +40,10 @@ typedef enum mppi_status {
   MPPI_ERR_HIP = -2,       /* a HIP runtime call failed                        */
   MPPI_ERR_STATE = -3,     /* call sequence error (maps or params not set ...) */
   MPPI_ERR_NO_DEVICE = -4, /* no usable gfx950 device                          */
-  MPPI_ERR_COMM = -5       /* RCCL failure, or a peer of the peer exchange that did not deliver */
+  MPPI_ERR_COMM = -5,      /* RCCL failure, or a peer of the peer exchange that did not deliver */
+  MPPI_ERR_BUSY = -6       /* the device did not run all workgroups of a rollout launch side by side (another tenant, a
+                              CU mask): the controls handed over inside that launch did not arrive in time; the control
+                              sequence of the call is not valid, later calls update through a launch of their own */
 } mppi_status;
 
 /* which of the reference's solve_* variants the planner runs (mppi.py:193-211) */
@@ -299,7 +302,17 @@ int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity)
 #define MPPI_DEBUG_SCAN_FULL_TILES 128   /* workgroups of 64 rollouts (one lane per rollout) instead of 32 (two) */
 #define MPPI_DEBUG_NO_FOLDED_APPLY 256   /* sharded handle: every iteration's update by its own k_apply launch, never by the next rollout launch */
 #define MPPI_DEBUG_NO_REDUCE_FOLD 512    /* one GPU: every iteration's update by its own k_combine_tiles launch, never reduced and applied by the next rollout launch */
+#define MPPI_DEBUG_NO_SCAN_DIRECT 1024   /* a map the planner has stopped speculating on: k_rollout_pipe + k_update_rows (round 4) instead of k_rollout_scan_exact on its exact schedule (one launch per iteration) */
 int mppi_planner_set_debug_flags(mppi_planner* p, int flags);
+/* How long a workgroup of a rollout launch polls for the controls its sibling workgroups publish inside the launch
+ * (update folded into the next rollout launch: rollout_scan*_kernel.h) before it gives the launch up: `polls` of
+ * ~0.3-1 us each (default 2^20, about a second; test hook).  After a give-up the next synchronising call returns
+ * MPPI_ERR_BUSY and the handle stops folding (mppi_planner_fold_state: folding, faults so far). */
+int mppi_planner_set_fold_poll_limit(mppi_planner* p, int polls);
+int mppi_planner_fold_state(mppi_planner* p, int* folding, long* faults);
+/* developer / test hook: occupy `workgroups` compute units of `device` (one workgroup each: 100 KiB of LDS) for
+ * `milliseconds` on a stream of its own, so that a rollout launch beside it cannot have all its workgroups resident */
+int mppi_debug_occupy_cus(int device, int workgroups, int milliseconds);
 int mppi_selftest_philox(int device, int* mismatches);
 /* developer instrumentation: in-kernel clock stamps of a -DMPPI_STAMPS build
  * (csrc/Makefile target `stamps`, tools/stamp_timeline.py); MPPI_ERR_STATE otherwise */

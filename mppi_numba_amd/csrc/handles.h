@@ -126,7 +126,13 @@ struct mppi_planner {
   int tpk_cur = 0;         // the buffer the last such launch wrote
   int scan_tile = 32;      // rollouts per tile of the last such launch
   bool scan_packets_fresh = false;  // ... written by the last rollout launch for the current costs
-  unsigned long long* published = nullptr;  // [2][T][kPublishedStride] words {float u; uint32 flag}; all zero between loops (k_combine_tiles)
+  unsigned long long* published = nullptr;  // [2][T][kPublishedStride] words, one used per step: {float u.x; float u.y}, kNotPublished (all ones) until written and between loops (planner_alloc, k_combine_tiles): update_kernels.h
+  // the in-launch hand-over of the controls is bounded and fails soft (update_kernels.h, PendingApply::fault)
+  unsigned int* fold_fault_host = nullptr;  // pinned, device-mapped: a workgroup gave up waiting for a published step
+  unsigned int* fold_fault_dev = nullptr;
+  int fold_max_polls = 1 << 20;             // ... after this many polls (~a second)
+  bool fold_off = false;                    // ... after which this handle updates through launches of their own
+  uint64_t fold_faults = 0;
   bool reduce_pending = false;  // the last launch's tile packets hold an update that the next rollout launch applies
   int reduce_index = 0;         // such launches since the loop began: picks the flag set
   uint64_t reduced_applies = 0;

@@ -352,16 +352,46 @@ struct ScanPlan {
   size_t lds = 0;
   bool pow2res = false;
   bool exact = false;  // k_rollout_scan_exact: the three running sums walked with the reference's roundings
+  // k_rollout_scan_exact on a map the planner has stopped speculating on (round 5): every tile runs the exact
+  // three-wave schedule at once (ScanFallback::direct) -- noise, folded update and tile packets as ever, so the
+  // iteration stays one launch and the kernel family does not depend on the map
+  bool direct = false;
+  int fallback_offset = -1, fallback_map_bytes = 0, small_offset = 0;  // where the exact schedule's controls | window | ring and the small arrays live (direct)
 };
+
+// Where k_rollout_scan_exact re-executes a tile on the exact schedule: in the LDS of the walks' groups and positions
+// (dead by then; unused in direct mode), or behind everything.  Returns the total LDS of the launch, 0: no room.
+static size_t scan_fallback_place(const mppi_planner* p, const DevParams& d, int W, size_t lds_now, int* offset, int* map_bytes_out) {
+  const size_t map_bytes = (size_t)d.win_rows * (size_t)d.win_cols * sizeof(uint16_t);
+  const size_t need = ScanFallback::bytes(8 * W, (int)map_bytes);
+  const size_t budget = (size_t)p->lds_per_cu - 1024;
+  const size_t total = (ScanExactLds::total(W) + 15) & ~(size_t)15;
+  if (need <= ScanExactLds::grp(W) + ScanExactLds::p2(W)) {
+    *offset = (int)(ScanExactLds::e2(W) + ScanExactLds::ccr(W));
+    *map_bytes_out = (int)map_bytes;
+    return lds_now;
+  }
+  if (total + need <= budget) {
+    *offset = (int)total;
+    *map_bytes_out = (int)map_bytes;
+    return std::max(lds_now, total + need);
+  }
+  return 0;
+}
 
 static bool scan_plan(const mppi_planner* p, ScanPlan* out) {
   static const bool disabled = getenv("MPPI_NO_SCAN") != nullptr;  // developer switch (ablation)
   if (disabled || (p->debug_flags & MPPI_DEBUG_NO_SCAN_KERNEL)) return false;
   if (p->cfg.mode != MPPI_MODE_DET) return false;
   if (!p->cells16_valid || p->cells16_with_risk) return false;
-  if (p->speculation_off && !(p->debug_flags & MPPI_DEBUG_KEEP_SPECULATING)) return false;
+  const bool direct = p->speculation_off && !(p->debug_flags & MPPI_DEBUG_KEEP_SPECULATING);
+  static const bool no_direct = getenv("MPPI_NO_SCAN_DIRECT") != nullptr;  // developer switch (ablation): k_rollout_pipe as in round 4
+  if (direct && (no_direct || (p->debug_flags & MPPI_DEBUG_NO_SCAN_DIRECT) || p->cfg.math != MPPI_MATH_EXACT || p->inst_set ||
+                 !p->packed_lin || !p->packed_ang))
+    return false;
   const int T = p->cfg.num_steps;
   ScanPlan plan;
+  plan.direct = direct;
   plan.exact = p->cfg.math == MPPI_MATH_EXACT;
   plan.chunk_waves = ceil_div(T, 8);
   if (plan.exact && plan.chunk_waves > ScanExactLds::kMaxChunkWaves) return false;  // (T <= 104; beyond, k_rollout_deep)
@@ -379,6 +409,23 @@ static bool scan_plan(const mppi_planner* p, ScanPlan* out) {
   if (plan.lds > (size_t)p->lds_per_cu - 1024) return false;
   int res_exp = 0;
   plan.pow2res = std::frexp((double)p->params.res, &res_exp) == 0.5;  // res == 2^k exactly
+  if (plan.direct) {
+    // the exact schedule needs the 16-bit window of the cells reachable within the horizon in LDS, next to the noise,
+    // and the exact-increment rotation (|dt * w * traction| <= 0.36 rad): else k_rollout_pipe / the general kernels
+    DevParams d = make_dev_params(p, p->packed_lin, p->packed_ang);
+    size_t lds_win = 0;
+    if (!plan_lds_window(const_cast<mppi_planner*>(p), d, &lds_win)) return false;  // (single problem: nothing of p changes)
+    // LDS of a direct launch: noise | control-cost terms | {controls, window, ring} | small arrays (the walks' groups
+    // and positions do not exist)
+    const int W = plan.chunk_waves;
+    const size_t map_bytes = (size_t)d.win_rows * (size_t)d.win_cols * sizeof(uint16_t);
+    const size_t need = (ScanFallback::bytes(8 * W, (int)map_bytes) + 15) & ~(size_t)15;
+    plan.fallback_offset = (int)(ScanExactLds::e2(W) + ScanExactLds::ccr(W));
+    plan.fallback_map_bytes = (int)map_bytes;
+    plan.small_offset = plan.fallback_offset + (int)need;
+    plan.lds = std::max((size_t)plan.small_offset + ScanExactLds::small(W), (size_t)40 * 1024);
+    if (plan.lds > (size_t)p->lds_per_cu - 1024) return false;
+  }
   if (out) *out = plan;
   return true;
 }
@@ -485,32 +532,36 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
     pend.reduce_n_tiles = ceil_div(N, p->scan_tile);
     pend.published = p->published;
     pend.flag_set = p->reduce_index & 1;
+    pend.fault = p->fold_fault_dev;
+    pend.max_polls = p->fold_max_polls;
     if (p->p2p_on) pend.peers = make_peer_exchange(p);  // (advances the inbox set)
   }
-  p->spec_launches += 1;
+  if (!plan.direct) p->spec_launches += 1;
   // Exact kernel: where a tile whose vote fails is re-executed (rollout_scan_exact_kernel.h, scan_exact_reexecute):
   // controls, 16-bit map window and one chunk ring in the LDS of the walks' groups and positions, dead by then --
   // or behind everything when the horizon is too short for that region to hold them.
-  ScanFallback fallback = {-1, 0};
+  ScanFallback fallback = {-1, 0, 0, 0, 0};
+  {  // the exact-increment rotation of the state role applies (as launch_rollout_det's rot_ok)
+    const mppi_params& a = p->params;
+    const double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
+    const double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
+    const double dmax = (double)a.dt * wmax * trmax;
+    fallback.rot_ok = (std::isfinite(dmax) && dmax <= 0.36) ? 1 : 0;
+  }
   static const bool no_fast_fallback = getenv("MPPI_SCAN_SLOW_FALLBACK") != nullptr;  // developer switch (ablation)
-  if (plan.exact && have_window && !no_fast_fallback) {
-    const int W = plan.chunk_waves;
-    const size_t map_bytes = (size_t)d.win_rows * (size_t)d.win_cols * sizeof(uint16_t);
-    const size_t need = ScanFallback::bytes(8 * W, (int)map_bytes);
-    const size_t budget = (size_t)p->lds_per_cu - 1024;
-    const size_t total = (ScanExactLds::total(W) + 15) & ~(size_t)15;
-    if (need <= ScanExactLds::grp(W) + ScanExactLds::p2(W)) {
-      fallback.offset = (int)(ScanExactLds::e2(W) + ScanExactLds::ccr(W));
-      fallback.map_bytes = (int)map_bytes;
-    } else if (total + need <= budget) {
-      fallback.offset = (int)total;
-      fallback.map_bytes = (int)map_bytes;
-      plan.lds = std::max(plan.lds, total + need);
-    }
+  if (plan.direct) {
+    REQUIRE(have_window && plan.fallback_offset >= 0, MPPI_ERR_STATE, "internal: direct exact schedule without its map window");
+    fallback.offset = plan.fallback_offset;
+    fallback.map_bytes = plan.fallback_map_bytes;
+    fallback.small_offset = plan.small_offset;
+    fallback.direct = 1;
+  } else if (plan.exact && have_window && !no_fast_fallback) {
+    const size_t lds = scan_fallback_place(p, d, plan.chunk_waves, plan.lds, &fallback.offset, &fallback.map_bytes);
+    if (lds) plan.lds = lds;
   }
 #define MPPI_LAUNCH_SCAN_EXACT(P2, GEN)                                                                    \
   do {                                                                                                    \
-    auto kern = k_rollout_scan_exact<P2, GEN>;                                                            \
+    auto kern = plan.direct ? k_rollout_scan_exact<P2, GEN, true> : k_rollout_scan_exact<P2, GEN, false>; \
     if (plan.lds > 64 * 1024)                                                                             \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));            \
@@ -557,11 +608,11 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
     p->apply_pending = p->reduce_pending = false;
   }
   p->tpk_cur ^= 1;
-  char buf[256];
+  char buf[384];
   snprintf(buf, sizeof(buf),
            "k_rollout_scan%s tile=%d waves=%d pow2res=%d noise=%s lds=%zu noise_blocks=%d problems=%d%s%s",
            plan.exact ? "_exact" : "", plan.tile, plan.waves, (int)plan.pow2res, gen ? "in-kernel" : "read", plan.lds, extra,
-           p->inst_set ? p->B : 0, !plan.exact ? "" : (fallback.offset >= 0 ? " failed_tiles=pipelined" : " failed_tiles=one_wave"), applied_here ? (pend.reduce_tiles ? " applies_update=1 reduces_tiles=1" : " applies_update=1") : "");
+           p->inst_set ? p->B : 0, !plan.exact ? "" : (plan.direct ? " direct=1 (exact three-wave schedule, no speculation)" : (fallback.offset >= 0 ? " failed_tiles=pipelined" : " failed_tiles=one_wave")), applied_here ? (pend.reduce_tiles ? " applies_update=1 reduces_tiles=1" : " applies_update=1") : "");
   p->last_rollout = buf;
   p->tile_packets_fresh = false;  // (w_rel is relative to this kernel's own tiles: tbeta, not tile_beta)
   p->scan_packets_fresh = true;
@@ -1254,7 +1305,7 @@ static bool p2p_usable(const mppi_planner* p) {
 static bool next_rollout_reduces_tiles(const mppi_planner* p) {
   static const bool disabled = getenv("MPPI_NO_REDUCE_FOLD") != nullptr;  // developer switch (ablation)
   ScanPlan plan;
-  return !disabled && !(p->debug_flags & (MPPI_DEBUG_NO_FOLDED_APPLY | MPPI_DEBUG_NO_REDUCE_FOLD)) && p->B == 1 && !p->inst_set &&
+  return !disabled && !p->fold_off && !(p->debug_flags & (MPPI_DEBUG_NO_FOLDED_APPLY | MPPI_DEBUG_NO_REDUCE_FOLD)) && p->B == 1 && !p->inst_set &&
          p->m_count == 1 && ((p->cfg.world_size == 1 && !p->comm) || p2p_usable(p)) && p->cfg.mode == MPPI_MODE_DET && !p->mirror_now &&
          scan_plan(p, &plan) && plan.tile == p->scan_tile &&
          tiles_can_reduce(ceil_div(p->n_local, plan.tile), p->cfg.num_steps);
@@ -1434,10 +1485,23 @@ static void review_speculation(mppi_planner* p) {
   }
   const uint64_t failed = *p->spec_fail_host;
   // A launch lasts as long as its slowest tile, and a tile whose vote fails is rolled out twice: ONE failing tile
-  // makes its launch slower than the exact kernel would have been (C2 shape, round 4: 40 us against 29 us with
-  // k_rollout_pipe; 16 us when every vote holds), so speculation pays while fewer than about half of the LAUNCHES
-  // contain one.  The kernels count failed tiles: at least one per two launches -> stop.
-  if (2 * failed >= p->spec_launches) p->speculation_off = true;
+  // makes its launch slower than the exact schedule would have been.  Every speculative kernel runs ONE round of
+  // workgroups (k_rollout_scan*: a tile per CU; k_rollout_deep: a tile per CU; k_rollout_spec: up to three tiles in
+  // one workgroup per CU), so the criterion is per launch for all of them.  C2 shape, round 5: 15.2 us when every
+  // vote holds, 21.6 us on the exact schedule (direct), ~40 us with a failing tile -- speculation pays while
+  // P(fail) * (40 - 21.6) < (1 - P) * (21.6 - 15.2), i.e. fewer than one launch in four fails (the longer horizons'
+  // k_rollout_deep against k_rollout_pipe: 36 / 48 / 85 us, the same quarter).  The kernels count failed tiles: at
+  // least one per four launches -> stop.
+  if (4 * failed >= p->spec_launches) {
+    p->speculation_off = true;
+    // Several GPUs on the peer exchange: which tiles fail their vote differs from rank to rank (every rank rolls out
+    // its own noise), so ranks reach this point in different iterations -- and the exchange only works while all of
+    // them launch kernels that carry it.  Stopping is therefore allowed where the kernel FAMILY survives it
+    // (k_rollout_scan_exact on its exact schedule: ScanPlan::direct -- same packets, same exchange, whatever the
+    // other ranks run); where it would mean another family (window too large, tolerance kernel) this rank keeps
+    // speculating: slower on such a map, never a rank that has left the exchange its peers still wait in.
+    if (p->p2p_on && p->cfg.world_size > 1 && !scan_plan(p, nullptr)) p->speculation_off = false;
+  }
   *p->spec_fail_host = 0u;
   p->spec_launches = 0;
 }

@@ -465,6 +465,7 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
     if (p->peer_mapped[g] && p->peer_inbox[g]) (void)hipIpcCloseMemHandle(p->peer_inbox[g]);
   if (p->inbox) (void)hipFree(p->inbox);
   if (p->p2p_fault_host) (void)hipHostFree(p->p2p_fault_host);
+  if (p->fold_fault_host) (void)hipHostFree(p->fold_fault_host);
   dev_free(p->inst_dev);
   if (p->u_host) (void)hipHostFree(p->u_host);
   if (p->u_stage) (void)hipHostFree(p->u_stage);
@@ -568,6 +569,9 @@ static int planner_alloc(mppi_planner* p) {
     }
     TRY(dev_alloc(&p->published, published_words((int)T)));
     HIP_TRY(hipMemsetAsync(p->published, 0xff, sizeof(unsigned long long) * published_words((int)T), p->stream));  // (kNotPublished)
+    HIP_TRY(hipHostMalloc((void**)&p->fold_fault_host, sizeof(unsigned int), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void**)&p->fold_fault_dev, p->fold_fault_host, 0));
+    *p->fold_fault_host = 0u;
   }
   TRY(dev_alloc(&p->stats, 2 * B));
   TRY(dev_alloc(&p->state_rollout, (size_t)c.num_vis_state_rollouts * (T + 1) * 3));
@@ -785,13 +789,79 @@ static int check_peer_fault(mppi_planner* p) {
   return MPPI_OK;
 }
 
+// after the stream has drained: did a workgroup give up waiting for the controls its siblings publish inside a
+// rollout launch (update_kernels.h, collect_published)?  Then not all workgroups of that launch were resident side by
+// side -- the device is shared or masked -- and this handle stops folding its updates into rollout launches.
+static int check_fold_fault(mppi_planner* p) {
+  if (p->fold_fault_host && *p->fold_fault_host != 0u) {
+    *p->fold_fault_host = 0u;
+    p->fold_off = true;
+    ++p->fold_faults;
+    drop_graphs(p);  // (captured loops fold)
+    p->graph_warm = false;
+    // (the words of the loop that broke off: a later k_combine_tiles clears them as well; the handle does not fold again)
+    (void)hipMemsetAsync(p->published, 0xff, sizeof(unsigned long long) * published_words(p->cfg.num_steps), p->stream);
+    return fail(MPPI_ERR_BUSY, "a rollout launch could not hand the updated controls over between its workgroups in time: "
+                               "not all of them were running side by side (device shared or masked); the control sequence "
+                               "of this call is not valid -- set it again; from now on this handle updates through a "
+                               "launch of its own per iteration");
+  }
+  return MPPI_OK;
+}
+
 extern "C" int mppi_planner_synchronize(mppi_planner* p) {
   REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
   HIP_TRY(hipSetDevice(p->cfg.device));
   HIP_TRY(hipStreamSynchronize(p->stream));
   review_speculation(p);
   TRY(check_peer_fault(p));
+  TRY(check_fold_fault(p));
   return finish_timing(p);
+}
+
+extern "C" int mppi_planner_set_fold_poll_limit(mppi_planner* p, int polls) {
+  REQUIRE(p && polls >= 1, MPPI_ERR_INVALID, "bad argument");
+  p->fold_max_polls = polls;
+  drop_graphs(p);  // (a by-value argument of the captured launches)
+  return MPPI_OK;
+}
+
+extern "C" int mppi_planner_fold_state(mppi_planner* p, int* folding, long* faults) {
+  REQUIRE(p && folding && faults, MPPI_ERR_INVALID, "NULL argument");
+  *folding = p->fold_off ? 0 : 1;
+  *faults = (long)p->fold_faults;
+  return MPPI_OK;
+}
+
+// test hook: workgroups that do nothing but hold a compute unit (100 KiB of LDS each) for a while
+__global__ __launch_bounds__(64) void k_debug_occupy(unsigned long long ticks, int* sink) {
+  extern __shared__ int occupy_lds[];
+  occupy_lds[threadIdx.x] = (int)threadIdx.x;
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+  if (sink && occupy_lds[threadIdx.x ^ 1] == -1) *sink = 1;
+}
+
+extern "C" int mppi_debug_occupy_cus(int device, int workgroups, int milliseconds) {
+  REQUIRE(workgroups >= 1 && workgroups <= 4096 && milliseconds >= 1 && milliseconds <= 2000, MPPI_ERR_INVALID, "bad argument");
+  HIP_TRY(hipSetDevice(device));
+  static hipStream_t side = nullptr;  // (a test hook: one stream, never destroyed)
+  if (!side) {
+    // a stream of another priority: the runtime maps streams of one priority onto a small pool of hardware queues,
+    // and two streams that share a queue run one after the other (measured: the planner's loop simply waited)
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, greatest));
+  }
+  int rate_khz = 0;
+  HIP_TRY(hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, device));
+  if (rate_khz <= 0) rate_khz = 100000;
+  const size_t lds = 100 * 1024;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_occupy), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_debug_occupy, dim3(workgroups), dim3(64), lds, side, (unsigned long long)rate_khz * (unsigned long long)milliseconds,
+                     (int*)nullptr);
+  HIP_TRY(hipGetLastError());
+  return MPPI_OK;
 }
 
 extern "C" int mppi_planner_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, float* u_out) {
@@ -811,6 +881,7 @@ extern "C" int mppi_planner_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang,
   HIP_TRY(hipStreamSynchronize(p->stream));
   review_speculation(p);
   TRY(check_peer_fault(p));
+  TRY(check_fold_fault(p));
   memcpy(u_out, p->u_host, u_bytes);
   return finish_timing(p);
 }
@@ -1030,6 +1101,7 @@ extern "C" int mppi_planner_closed_loop(mppi_planner* p, mppi_tdm* lin, mppi_tdm
       TraceRange tr_wait("mppi:closed_loop_check");
       HIP_TRY(hipStreamSynchronize(p->stream));
       review_speculation(p);  // (the host has waited anyway: is speculating on this map paying?)
+      TRY(check_fold_fault(p));
       if (*p->loop_done_count >= B) break;
       // the host-side guards of the next launches (|theta| bounds of the incremental trig, window
       // plan) look at the start states: bring the mirror of the per-problem records up to date
@@ -1579,9 +1651,26 @@ extern "C" int mppi_group_iterate_async(mppi_planner** ps, mppi_tdm** lins, mppi
     bool all_p2p = count > 1;
     for (int g = 0; g < count && all_p2p; ++g) all_p2p = ps[g] && ps[g]->params_set && p2p_usable(ps[g]);
     if (all_p2p) {
+      // Every launch of device g spins inside the kernel until the other devices' numbers for the same iteration have
+      // arrived, so no device may be handed more launches than its queue takes before the others have theirs: a few
+      // iterations per device in turn, round robin (all of device 0's first could fill its launch queue and block this
+      // thread with nothing enqueued anywhere else -- until the poll limit raises the fault word).
+      constexpr int kTurn = 4;
       for (int g = 0; g < count; ++g) {
         HIP_TRY(hipSetDevice(ps[g]->cfg.device));
-        TRY(run_iterations(ps[g], lins[g], angs[g], iterations));
+        HIP_TRY(hipEventRecord(ps[g]->ev_begin, ps[g]->stream));
+      }
+      for (int k = 0; k < iterations; k += kTurn)
+        for (int g = 0; g < count; ++g) {
+          HIP_TRY(hipSetDevice(ps[g]->cfg.device));
+          TRY(run_iterations(ps[g], lins[g], angs[g], std::min(kTurn, iterations - k), /*timed=*/false));
+        }
+      for (int g = 0; g < count; ++g) {
+        mppi_planner* p = ps[g];
+        HIP_TRY(hipSetDevice(p->cfg.device));
+        HIP_TRY(hipEventRecord(p->ev_end, p->stream));
+        p->elapsed_pending = true;
+        p->last_iterations = iterations;
       }
       return MPPI_OK;
     }
@@ -1675,7 +1764,8 @@ static int p2p_alloc_fault(mppi_planner* p);
 extern "C" int mppi_planner_p2p_export(mppi_planner* p, char handle[MPPI_P2P_HANDLE_BYTES]) {
   static_assert(sizeof(hipIpcMemHandle_t) <= MPPI_P2P_HANDLE_BYTES, "hipIpcMemHandle_t larger than expected");
   REQUIRE(p && handle, MPPI_ERR_INVALID, "NULL argument");
-  REQUIRE(p->cfg.mode == MPPI_MODE_DET && p->B == 1, MPPI_ERR_INVALID, "the peer exchange serves single-problem deterministic-dynamics handles");
+  REQUIRE(p->cfg.mode == MPPI_MODE_DET && p->B == 1 && p->m_count == 1, MPPI_ERR_INVALID,
+          "the peer exchange serves single-problem deterministic-dynamics handles with all their traction samples");
   HIP_TRY(hipSetDevice(p->cfg.device));
   hipIpcMemHandle_t h;
   TRY(p2p_alloc_inbox(p, &h));
@@ -1737,11 +1827,34 @@ extern "C" int mppi_planner_p2p_connect(mppi_planner* p, const char* handles, in
 // one process, several devices: the handles' inboxes addressed directly (peer access)
 extern "C" int mppi_group_p2p_connect(mppi_planner** ps, int count) {
   REQUIRE(ps && count >= 1 && count <= kMaxFoldedRanks, MPPI_ERR_INVALID, "bad group of %d", count);
+  bool several_devices = false;
   for (int g = 0; g < count; ++g) {
     REQUIRE(ps[g] && ps[g]->cfg.world_size == count && ps[g]->cfg.rank == g, MPPI_ERR_INVALID, "planner %d is not rank %d of %d", g, g, count);
+    REQUIRE(ps[g]->m_count == 1 && ps[g]->cfg.mode == MPPI_MODE_DET && ps[g]->B == 1, MPPI_ERR_INVALID,
+            "the peer exchange serves single-problem deterministic-dynamics handles with all their traction samples");
+    several_devices = several_devices || ps[g]->cfg.device != ps[0]->cfg.device;
+  }
+  // peer access first: memory allocated afterwards is mapped for the peers that have it enabled
+  for (int g = 0; g < count; ++g) {
+    HIP_TRY(hipSetDevice(ps[g]->cfg.device));
+    for (int q = 0; q < count; ++q) {
+      if (ps[q]->cfg.device == ps[g]->cfg.device) continue;
+      int can = 0;
+      HIP_TRY(hipDeviceCanAccessPeer(&can, ps[g]->cfg.device, ps[q]->cfg.device));
+      REQUIRE(can, MPPI_ERR_HIP, "device %d cannot access device %d", ps[g]->cfg.device, ps[q]->cfg.device);
+      hipError_t e = hipDeviceEnablePeerAccess(ps[q]->cfg.device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e);
+      (void)hipGetLastError();
+    }
+  }
+  for (int g = 0; g < count; ++g) {
     HIP_TRY(hipSetDevice(ps[g]->cfg.device));
     TRY(p2p_alloc_inbox(ps[g], nullptr));
     TRY(p2p_alloc_fault(ps[g]));
+    // (coarse-grained memory is coherent at kernel boundaries only: good enough for ranks that share ONE device, the
+    //  test set-up; across devices a running kernel would never see its peers' stores)
+    REQUIRE(!several_devices || strcmp(ps[g]->inbox_kind, "coarse-grained") != 0, MPPI_ERR_HIP,
+            "device %d: no fine-grained memory for the peer exchange's inbox", ps[g]->cfg.device);
   }
   for (int g = 0; g < count; ++g) {
     mppi_planner* p = ps[g];
@@ -1749,19 +1862,47 @@ extern "C" int mppi_group_p2p_connect(mppi_planner** ps, int count) {
     HIP_TRY(hipStreamSynchronize(p->stream));
     p2p_disconnect(p);
     drop_graphs(p);
-    for (int q = 0; q < count; ++q) {
-      if (ps[q]->cfg.device != p->cfg.device) {
-        int can = 0;
-        HIP_TRY(hipDeviceCanAccessPeer(&can, p->cfg.device, ps[q]->cfg.device));
-        REQUIRE(can, MPPI_ERR_HIP, "device %d cannot access device %d", p->cfg.device, ps[q]->cfg.device);
-        hipError_t e = hipDeviceEnablePeerAccess(ps[q]->cfg.device, 0);
-        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(e);
-        (void)hipGetLastError();
-      }
-      p->peer_inbox[q] = ps[q]->inbox;
-    }
+    for (int q = 0; q < count; ++q) p->peer_inbox[q] = ps[q]->inbox;
     p->p2p_on = true;
     p->p2p_index = 0;
+  }
+  // Do the peers' stores reach kernels that are already running?  All ranks ping at once (their kernels wait for each
+  // other, so every device gets its launch before any is waited for); a group that cannot hear itself is not connected.
+  {
+    std::vector<int*> results((size_t)count, nullptr);
+    int rc = MPPI_OK;
+    for (int g = 0; g < count && rc == MPPI_OK; ++g) {
+      mppi_planner* p = ps[g];
+      if (hipSetDevice(p->cfg.device) != hipSuccess) { rc = fail(MPPI_ERR_HIP, "hipSetDevice failed"); break; }
+      rc = dev_alloc(&results[(size_t)g], 1);
+      if (rc != MPPI_OK) break;
+      PeerExchange X;
+      memset(&X, 0, sizeof(X));
+      for (int q = 0; q < count; ++q) X.inbox[q] = p->peer_inbox[q];
+      X.world = count;
+      X.rank = g;
+      hipLaunchKernelGGL(k_p2p_ping, dim3(1), dim3(64), 0, p->stream, X, inbox_ping_offset(count, p->cfg.num_steps),
+                         0x70696e67ull /* "ping" */, 2000 * 1000, results[(size_t)g]);
+    }
+    for (int g = 0; g < count; ++g) {
+      mppi_planner* p = ps[g];
+      int heard = 0;
+      if (rc == MPPI_OK && results[(size_t)g]) {
+        (void)hipSetDevice(p->cfg.device);
+        if (hipStreamSynchronize(p->stream) != hipSuccess ||
+            hipMemcpy(&heard, results[(size_t)g], sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+          rc = fail(MPPI_ERR_HIP, "peer exchange ping on device %d failed", p->cfg.device);
+        else if (heard != count)
+          rc = fail(MPPI_ERR_COMM, "peer exchange: device %d heard %d of %d ranks (stores of peers do not reach running kernels)",
+                    p->cfg.device, heard, count);
+      }
+      dev_free(results[(size_t)g]);
+    }
+    if (rc != MPPI_OK) {
+      for (int g = 0; g < count; ++g) p2p_disconnect(ps[g]);
+      return rc;
+    }
+    // (the ping words hold the token now; a later mppi_planner_p2p_ping uses another one)
   }
   return MPPI_OK;
 }

@@ -263,6 +263,33 @@ __device__ __forceinline__ void copy_window_to_lds(const DevParams& P, const uin
   }
 }
 
+// The same copy without the trip through registers (round 5): global_load_lds_dwordx4 writes 64 lanes x 16 bytes
+// straight into LDS at M0 + lane * 16, so a wave keeps ALL its vectors in flight (the register version above has 8 per
+// lane and pays the memory latency once per batch: 2 556 vectors at C2 = three round trips of ~2.3k cycles for two
+// waves, 7k cycles between kernel entry and the first barrier; profiles/r05_pipe_notes.md).  Vector v of the window
+// (row-major, win_cols / 8 per row) lands at lds_map + 16 v; the row of v by a float reciprocal (exact: v < 2^16,
+// rows < 2^10).  The caller waits (s_waitcnt vmcnt(0)) before the barrier that publishes the window.
+__device__ __forceinline__ void copy_window_to_lds_direct(const DevParams& P, const uint16_t* __restrict__ cells16,
+                                                          uint16_t* lds_map, int first_thread, int n_threads) {
+  const int tid = (int)threadIdx.x - first_thread;
+  if (tid < 0 || tid >= n_threads) return;  // (whole waves: both bounds are multiples of 64)
+  const int vec_per_row = P.win_cols >> 3;
+  const int total = P.win_rows * vec_per_row;
+  const int src_pitch = P.pitch16 >> 3;
+  const uint4* src = reinterpret_cast<const uint4*>(cells16) + ((size_t)P.win_r0 * P.pitch16 + P.win_c0) / 8;
+  const float inv_vpr = 1.0f / (float)vec_per_row;
+  const int lane = tid & 63;
+  const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+  for (int base = wave_base; base < total; base += n_threads) {
+    const int v = base + lane;
+    const int r = (int)(((float)v + 0.5f) * inv_vpr);
+    const uint4* g = src + (size_t)r * src_pitch + (v - r * vec_per_row);
+    if (v < total)
+      __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)(reinterpret_cast<uint4*>(lds_map) + base),
+                                       16, 0, 0);
+  }
+}
+
 // LDS: [T] double2 control ratios | [T] float2 u | (LDSMAP) window of 16-bit cells
 template <int KIND, bool EXACT, bool BOUNDED, bool LDSMAP>
 __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
@@ -585,37 +612,51 @@ __device__ __forceinline__ PipeState pipe_state_init(const DevParams& P) {
   return st;
 }
 
-// C steps: reads {dt*v, dt*w} of step j from in_qd[j*64 + lane]; leaves (x, y) after the step in out_xy and the cell the
-// step STARTED in (its obstacle / unknown bits are what the step pays: mppi.py:971-998) in out_cell.
+// One step: {dt*v, dt*w} in qd (exact products of float32 factors); leaves (x, y) after the step in *out_xy and the cell
+// the step STARTED in (its obstacle / unknown bits are what the step pays: mppi.py:971-998) in *out_cell.
+template <bool POW2RES, bool CHECK_ROTATION>
+__device__ __forceinline__ void pipe_state_step(const DevParams& P, const PipeWindow<POW2RES>& win, PipeState& st,
+                                                const double2 qd, float2* out_xy, uint16_t* out_cell) {
+  const uint32_t c16 = pipe_cell_arrived(st.cell);
+  const double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), P.lin_lo);
+  const double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), P.ang_lo);
+  const float x = (float)fma(vtr, qd.x * st.c, st.x64);
+  const float y = (float)fma(vtr, qd.x * st.s, st.y64);
+  const float th = (float)fma(wtr, qd.y, st.th64);
+  st.cell = win.lookup(x, y);
+  __builtin_amdgcn_sched_barrier(0);  // ---- everything below runs while the lookup is in flight
+  st.x = x; st.y = y;
+  st.x64 = (double)x;
+  st.y64 = (double)y;
+  const double th_new = (double)th;
+  // exact increment of the ROUNDED heading (beyond the rotation's range -- never with the reference's parameters,
+  // host-proved where CHECK_ROTATION is off -- the full evaluation)
+  if (!CHECK_ROTATION || __all(fabs(th_new - st.th64) <= 0.36)) rotate_sincos_f64(th_new - st.th64, st.s, st.c);
+  else sincos_f64<false>(th_new, st.s, st.c);
+  st.th64 = th_new;
+  *out_xy = make_float2(x, y);
+  *out_cell = (uint16_t)c16;
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// C steps: reads {dt*v, dt*w} of step j from in_qd[j*64 + lane] (all C requests first), stores to out_xy / out_cell[j*64 + lane]
 template <int C, bool POW2RES, bool CHECK_ROTATION>
 __device__ __forceinline__ void pipe_state_chunk(const DevParams& P, const PipeWindow<POW2RES>& win, PipeState& st,
                                                  const double2* in_qd, float2* out_xy, uint16_t* out_cell, int lane) {
   double2 qd[C];
 #pragma unroll
-  for (int j = 0; j < C; ++j) qd[j] = in_qd[j * 64 + lane];  // exact products of float32 factors
+  for (int j = 0; j < C; ++j) qd[j] = in_qd[j * 64 + lane];
 #pragma unroll
-  for (int j = 0; j < C; ++j) {
-    const uint32_t c16 = pipe_cell_arrived(st.cell);
-    const double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), P.lin_lo);
-    const double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), P.ang_lo);
-    const float x = (float)fma(vtr, qd[j].x * st.c, st.x64);
-    const float y = (float)fma(vtr, qd[j].x * st.s, st.y64);
-    const float th = (float)fma(wtr, qd[j].y, st.th64);
-    st.cell = win.lookup(x, y);
-    __builtin_amdgcn_sched_barrier(0);  // ---- everything below runs while the lookup is in flight
-    st.x = x; st.y = y;
-    st.x64 = (double)x;
-    st.y64 = (double)y;
-    const double th_new = (double)th;
-    // exact increment of the ROUNDED heading (beyond the rotation's range -- never with the reference's parameters,
-    // host-proved for k_rollout_pipe -- the full evaluation)
-    if (!CHECK_ROTATION || __all(fabs(th_new - st.th64) <= 0.36)) rotate_sincos_f64(th_new - st.th64, st.s, st.c);
-    else sincos_f64<false>(th_new, st.s, st.c);
-    st.th64 = th_new;
-    out_xy[j * 64 + lane] = make_float2(x, y);
-    out_cell[j * 64 + lane] = (uint16_t)c16;
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  for (int j = 0; j < C; ++j)
+    pipe_state_step<POW2RES, CHECK_ROTATION>(P, win, st, qd[j], out_xy + j * 64 + lane, out_cell + j * 64 + lane);
+}
+// ... the horizon's last, shorter chunk: `count` < C steps (the steps past the horizon used to be integrated and ignored:
+// 4 x 265 cycles at T = 100)
+template <bool POW2RES, bool CHECK_ROTATION>
+__device__ __forceinline__ void pipe_state_tail(const DevParams& P, const PipeWindow<POW2RES>& win, PipeState& st,
+                                                const double2* in_qd, float2* out_xy, uint16_t* out_cell, int lane, int count) {
+  for (int j = 0; j < count; ++j)
+    pipe_state_step<POW2RES, CHECK_ROTATION>(P, win, st, in_qd[j * 64 + lane], out_xy + j * 64 + lane, out_cell + j * 64 + lane);
 }
 
 // Roles of the waves of one workgroup (W = blockDim / 192 triples, triple i = waves
@@ -673,8 +714,7 @@ __device__ __forceinline__ void pipe_tile_body(DevParams P, const uint16_t* __re
   }
   [[maybe_unused]] const int stamp_base = 64 + 64 * role;
   MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 0);
-  // (24 loads in flight per lane instead of 8 was measured: no change)
-  copy_window_to_lds(P, cells16, lds_map, 0, 128 * W);  // waves of roles 0 and 1
+  copy_window_to_lds_direct(P, cells16, lds_map, 0, 128 * W);  // waves of roles 0 and 1; all vectors in flight
   MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 1);
 
   const int tile = blockIdx.x * W + triple;  // 64 consecutive rollouts
@@ -688,14 +728,18 @@ __device__ __forceinline__ void pipe_tile_body(DevParams P, const uint16_t* __re
   if (role == 0) {
     const PipeWindow<POW2RES> win(P, lds_map);
     PipeState st = pipe_state_init(P);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the window has landed
     __syncthreads();  // controls of chunk 0 are in the ring; the window is in LDS
     st.cell = win.lookup(st.x, st.y);
     MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 2);
     for (int k = 0; k <= K; ++k) {
-      if (k < K)
-        pipe_state_chunk<C, POW2RES, false>(P, win, st, ring_qd + (size_t)(k & 1) * Ring::kHalf,
-                                            ring_xy + (size_t)(k & 1) * Ring::kHalf,
-                                            ring_cell + (size_t)(k & 1) * Ring::kHalf, lane);
+      if (k < K) {
+        const double2* in_qd = ring_qd + (size_t)(k & 1) * Ring::kHalf;
+        float2* out_xy = ring_xy + (size_t)(k & 1) * Ring::kHalf;
+        uint16_t* out_cell = ring_cell + (size_t)(k & 1) * Ring::kHalf;
+        if (T - k * C >= C) pipe_state_chunk<C, POW2RES, false>(P, win, st, in_qd, out_xy, out_cell, lane);
+        else pipe_state_tail<POW2RES, false>(P, win, st, in_qd, out_xy, out_cell, lane, T - k * C);
+      }
       MPPI_STAMP(stamp_wg && triple == 0 && k < 32, stamp_base + 3 + k);
       __syncthreads();
     }
@@ -757,6 +801,7 @@ __device__ __forceinline__ void pipe_tile_body(DevParams P, const uint16_t* __re
     double d2 = 1e9;
     bool done = false, reached = false;
     const double* my_cc = CC_LDS ? cc_lds + lane : cc_scratch + (live ? tile_base : (size_t)lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the window has landed
     __syncthreads();
     MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 2);
     for (int k = 0; k <= K; ++k) {
@@ -796,28 +841,33 @@ __device__ __forceinline__ void pipe_tile_body(DevParams P, const uint16_t* __re
     // products were written by the producer wave of this workgroup before its last barrier
     double term = (reached ? 0.0 : 1.0) * sqrt(d2) / P.v_post_den;
     cost = (float)((double)cost + term);
-    // two batches of loads in flight (they come back from L2 with a long latency).
-    // Starting them inside the step loop made the compiler keep the 96 batch registers
-    // live across it and cost 7 us; wider single batches were no better.
+    // Two batches of loads in flight (from the global scratch they come back from L2 with a long latency), in two
+    // register sets used in turn (round 5; before, one set was copied into the other after every batch -- two moves
+    // per step on a chain of three instructions: 52 cycles per addition, now ~30).  Starting the loads inside the step
+    // loop made the compiler keep the batch registers live across it and cost 7 us; wider single batches were no better.
     constexpr int kTailBatch = 24;
     double ca[kTailBatch], cb[kTailBatch];
+    auto tail_load = [&](double (&dst)[kTailBatch], int t0) {
 #pragma unroll
-    for (int j = 0; j < kTailBatch; ++j) ca[j] = my_cc[(size_t)min(j, T - 1) * 64];
-#pragma unroll
-    for (int j = 0; j < kTailBatch; ++j) cb[j] = my_cc[(size_t)min(kTailBatch + j, T - 1) * 64];
-    for (int t0 = 0; t0 < T; t0 += kTailBatch) {
+      for (int j = 0; j < kTailBatch; ++j) dst[j] = my_cc[(size_t)min(t0 + j, T - 1) * 64];
+    };
+    auto tail_add = [&](const double (&src)[kTailBatch], int t0) {
       if (t0 + kTailBatch <= T) {
 #pragma unroll
-        for (int j = 0; j < kTailBatch; ++j) cost = (float)((double)cost + ca[j]);
+        for (int j = 0; j < kTailBatch; ++j) cost = (float)((double)cost + src[j]);
       } else {
 #pragma unroll
         for (int j = 0; j < kTailBatch; ++j)
-          if (t0 + j < T) cost = (float)((double)cost + ca[j]);
+          if (t0 + j < T) cost = (float)((double)cost + src[j]);
       }
-#pragma unroll
-      for (int j = 0; j < kTailBatch; ++j) ca[j] = cb[j];
-#pragma unroll
-      for (int j = 0; j < kTailBatch; ++j) cb[j] = my_cc[(size_t)min(t0 + 2 * kTailBatch + j, T - 1) * 64];
+    };
+    tail_load(ca, 0);
+    for (int t0 = 0; t0 < T; t0 += 2 * kTailBatch) {
+      tail_load(cb, t0 + kTailBatch);
+      tail_add(ca, t0);
+      if (t0 + kTailBatch >= T) break;
+      tail_load(ca, t0 + 2 * kTailBatch);
+      tail_add(cb, t0 + kTailBatch);
     }
     MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 41);
     if (live) costs[n] = cost;

@@ -106,18 +106,40 @@ struct ScanExactLds {
 struct ScanFallback {
   int offset;     // bytes from the start of the dynamic LDS: [Tp] float2 controls | window | ring; < 0: no room,
   int map_bytes;  // ... the tile is rolled out step by step by one wave (global cells)
+  // Round 5: a map on which the planner has stopped speculating (review_speculation) -- traction changes along the
+  // paths: the reference's own semantic maps, CVaR-bin maps -- used to leave this kernel for k_rollout_pipe +
+  // k_update_rows (two launches, noise through memory).  direct != 0: the launch skips the time-parallel attempt and
+  // runs every tile on the exact three-wave schedule at once: the noise still comes from the Philox counters into LDS,
+  // the update of the previous launch is still folded in front (combine_step / publish / collect) and the tile's update
+  // sums still leave as a packet -- the iteration stays ONE launch and the kernel family (and with it the peer
+  // exchange of a multi-GPU run) does not change with the map.  The window copy is requested at kernel entry (LDS
+  // nobody else uses in this mode), by the cost wave, straight into LDS.
+  int direct;
+  // the host has proved |dt * w * traction| <= 0.36 rad for every step (launch_rollout_det's rot_ok): the state role
+  // rotates (cos, sin) by the exact heading increment without looking at it.  (With the test inside the loop the
+  // compiler lays the full evaluation out in line and the rotation behind a taken branch: 416 instead of 265 cycles
+  // per step -- profiles/r05_pipe_notes.md)
+  int rot_ok;
+  // direct mode: the walks' groups and positions do not exist; the region sits right behind the control-cost terms and
+  // the small arrays (control ratios, weights, flags, u_sh ...) behind it, at this offset
+  int small_offset;
   static constexpr int kRingBytes = PipeRing<8>::kBytesPerPair;
   __host__ __device__ static constexpr size_t bytes(int Tp, int map_bytes) { return (size_t)Tp * 8 + (size_t)map_bytes + kRingBytes; }
 };
 
-template <bool POW2RES>
+// us_ready (direct mode): the controls of the launch, [Tp] float2 in LDS already (u_sh), the window copied and a
+// workgroup barrier behind both -- nothing is staged and the schedule starts at once.  background(): what the waves
+// without a role still owe (direct mode: the control-cost terms of their groups), run behind the first barrier of the
+// schedule, where they would only wait; the producer wave runs it after its last chunk.
+template <bool POW2RES, typename Background>
 __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const uint16_t* __restrict__ cells16, char* fb,
                                                       int map_bytes, const float2* e2, const float2* u_src, int T,
-                                                      int c, int lane) {
+                                                      int c, int lane, const float2* us_ready, bool rot_ok,
+                                                      Background&& background) {
   constexpr int C = 8, R = ScanExactLds::R;
   using Ring = PipeRing<C>;
   const int Tp = (T + 7) & ~7;
-  float2* us = reinterpret_cast<float2*>(fb);
+  float2* us_stage = reinterpret_cast<float2*>(fb);
   uint16_t* lds_map = reinterpret_cast<uint16_t*>(fb + (size_t)Tp * 8);
   char* ring_base = reinterpret_cast<char*>(lds_map) + map_bytes;
   float2* ring_xy = reinterpret_cast<float2*>(ring_base);
@@ -125,10 +147,18 @@ __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const 
   uint16_t* ring_cell = reinterpret_cast<uint16_t*>(ring_qd + 2 * Ring::kHalf);
   const int r = lane & (R - 1);
   const int K = (T + C - 1) / C;
-  // the window and the controls: everybody; the walks' data under them is dead
-  copy_window_to_lds(P, cells16, lds_map, 0, (int)blockDim.x);
-  for (int t = threadIdx.x; t < Tp; t += blockDim.x) us[t] = t < T ? u_src[t] : make_float2(0.0f, 0.0f);
-  __syncthreads();
+  [[maybe_unused]] const bool stamp_wg = blockIdx.x == 5 && c < 3;  // (stamps build: slots 11 .. 15 of the three roles' rows)
+  [[maybe_unused]] const int stamp_base = 64 + 16 * c;
+  MPPI_STAMP(stamp_wg, stamp_base + 11);
+  const float2* us = us_ready;
+  if (us_ready == nullptr) {
+    // the window and the controls: everybody; the walks' data under them is dead
+    copy_window_to_lds(P, cells16, lds_map, 0, (int)blockDim.x);
+    for (int t = threadIdx.x; t < Tp; t += blockDim.x) us_stage[t] = t < T ? u_src[t] : make_float2(0.0f, 0.0f);
+    __syncthreads();
+    us = us_stage;
+  }
+  if (c < 3) __builtin_amdgcn_s_setprio(3);  // (the waves without a role may share a SIMD with one that has)
   float cost = 0.0f;
   if (c == 2) {  // ---- producer: {dt * v, dt * w} of chunk k + 1 while the state wave integrates chunk k
     const double dt64 = (double)P.dt;
@@ -142,30 +172,52 @@ __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const 
                                              dt64 * (double)clip_f32(ut.y + e.y, P.w_lo, P.w_hi));
       }
     };
+    MPPI_STAMP(stamp_wg, stamp_base + 12);
     produce(0);
     __syncthreads();
+    // (this wave reaches every barrier ~1k cycles before the state wave: what it still owes -- direct mode: the control-
+    //  cost terms of its group, which the cost wave waits for in front of its last walk -- fits into one of those gaps)
+    const int bg_at = min(2, K);
     for (int k = 0; k <= K; ++k) {
       if (k + 1 < K) produce(k + 1);
+      if (k == bg_at) background();
+      MPPI_STAMP(stamp_wg && (k == 0 || k == 6), stamp_base + (k == 0 ? 13 : 14));
       __syncthreads();
     }
+    MPPI_STAMP(stamp_wg, stamp_base + 15);
+    __builtin_amdgcn_s_setprio(0);
   } else if (c == 0) {  // ---- state: pipe_tile_body's role 0 (rollout_kernels.h, pipe_state_chunk)
     const PipeWindow<POW2RES> win(P, lds_map);
     PipeState st = pipe_state_init(P);
     __syncthreads();
     st.cell = win.lookup(st.x, st.y);
-    for (int k = 0; k <= K; ++k) {
-      if (k < K)
-        pipe_state_chunk<C, POW2RES, true>(P, win, st, ring_qd + (size_t)(k & 1) * Ring::kHalf,
-                                           ring_xy + (size_t)(k & 1) * Ring::kHalf,
-                                           ring_cell + (size_t)(k & 1) * Ring::kHalf, lane);
-      __syncthreads();
-    }
+    MPPI_STAMP(stamp_wg, stamp_base + 12);
+    auto run = [&](auto check) {
+      for (int k = 0; k <= K; ++k) {
+        if (k < K) {
+          constexpr bool CHK = decltype(check)::value != 0;
+          const double2* in_qd = ring_qd + (size_t)(k & 1) * Ring::kHalf;
+          float2* out_xy = ring_xy + (size_t)(k & 1) * Ring::kHalf;
+          uint16_t* out_cell = ring_cell + (size_t)(k & 1) * Ring::kHalf;
+          if (T - k * C >= C) pipe_state_chunk<C, POW2RES, CHK>(P, win, st, in_qd, out_xy, out_cell, lane);
+          else pipe_state_tail<POW2RES, CHK>(P, win, st, in_qd, out_xy, out_cell, lane, T - k * C);
+        }
+        MPPI_STAMP(stamp_wg && (k == 0 || k == 6), stamp_base + (k == 0 ? 13 : 14));
+        __syncthreads();
+      }
+    };
+    if (rot_ok) run(PhaseTag<0>());
+    else run(PhaseTag<1>());
+    MPPI_STAMP(stamp_wg, stamp_base + 15);
+    __builtin_amdgcn_s_setprio(0);
   } else if (c == 1) {  // ---- cost: pipe_tile_body's role 1
     const double dt64 = (double)P.dt, gt2 = (double)P.gt2;
     double d2 = 1e9;
     bool done = false, reached = false;
     __syncthreads();
+    MPPI_STAMP(stamp_wg, stamp_base + 12);
     for (int k = 0; k <= K; ++k) {
+      MPPI_STAMP(stamp_wg && (k == 1 || k == 7), stamp_base + (k == 1 ? 13 : 14));
       if (k >= 1) {
         const int t0 = (k - 1) * C;
         const float2* in_xy = ring_xy + (size_t)((k - 1) & 1) * Ring::kHalf;
@@ -188,15 +240,17 @@ __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const 
       }
       __syncthreads();
     }
+    MPPI_STAMP(stamp_wg, stamp_base + 15);
     cost = (float)((double)cost + (reached ? 0.0 : 1.0) * sqrt(d2) / P.v_post_den);
   } else {
     __syncthreads();
+    background();
     for (int k = 0; k <= K; ++k) __syncthreads();
   }
   return cost;
 }
 
-template <bool POW2RES, bool GEN>
+template <bool POW2RES, bool GEN, bool DIRECT = false>
 __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const uint16_t* __restrict__ cells16,
                                                              const uint32_t* __restrict__ cells,
                                                              const float2* __restrict__ noise, NoiseJob gen,
@@ -260,6 +314,15 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   const uint32_t ref = scan_lookup<POW2RES>(Q, cells16, Q.x0, Q.y0) & 0x3fffu;
 
   char* base = reinterpret_cast<char*>(scan_lds);
+  // no time-parallel attempt (see ScanFallback): an instantiation of its own -- the speculative launch must not carry
+  // a single instruction of this (its schedule is a local optimum the compiler leaves at the slightest change:
+  // profiles/r04_scan_notes.md section 6; a run-time flag cost the C2 launch 1.2 us)
+  constexpr bool direct = DIRECT;
+  // the 16-bit map window: waves 5.. their shares, all vectors in flight, waited for before the barrier in front of
+  // the schedule (not the walkers of a folded launch, waves 0 and 4: a wait for "all vector memory operations" would
+  // also wait for the stores of the step they publish, ~4k cycles)
+  if (direct && c >= 5)
+    copy_window_to_lds_direct(Q, cells16, reinterpret_cast<uint16_t*>(base + fallback.offset + (size_t)Tp * 8), 320, (int)blockDim.x - 320);
   float2* e2 = reinterpret_cast<float2*>(base);                                  // [Tp][R] (swizzled)
   double* ccr = reinterpret_cast<double*>(base + L::e2(W));                      // [2W][R][CHL]
   char* grp = base + L::e2(W) + L::ccr(W);                                       // [W] x 4 KiB
@@ -269,7 +332,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   // of steps <= t, which the chunk waves up to step t's have consumed (b_done); and a heading row is
   // written (the theta walk runs ahead) into a position row of a LATER step, not yet written.
   float* th_sh = reinterpret_cast<float*>(pos) + (size_t)Tp * R;                 // [Tp + 1][R]
-  char* small = reinterpret_cast<char*>(pos) + L::p2(W);
+  char* small = DIRECT ? base + fallback.small_offset : reinterpret_cast<char*>(pos) + L::p2(W);
   double2* uos = reinterpret_cast<double2*>(small);                              // [Tp] u / std^2
   double* term_sh = reinterpret_cast<double*>(uos + Tp);                         // [R]
   uint32_t* evw = reinterpret_cast<uint32_t*>(term_sh + R);                      // [R][2]
@@ -482,7 +545,22 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     MPPI_STAMP(stamp_wg, stamp_base + 4);
   };
 
-  if (walker == 0 || walker == 1) {
+  // a chunk wave's noise (registers, from its Philox blocks to its control-cost terms) and the control-cost terms of
+  // its steps: lambda * (u0/s0^2 * e0 + u1/s1^2 * e1) in float64 (mppi.py:1007-1009), needed after the terminal cost only
+  float2 e[CHL];
+  auto chunk_ccr = [&]() {
+    if (lane < 8) {  // the control ratios of the 8 steps (float64 quotients: mppi.py:709)
+      const float2 ul = folded ? u_sh[8 * g + lane] : uq[min(8 * g + lane, T - 1)];
+      uos[8 * g + lane] = make_double2((double)ul.x / Q.s0sq, (double)ul.y / Q.s1sq);
+    }
+#pragma unroll
+    for (int j = 0; j < CHL; ++j) ccr[((size_t)k * R + r) * CHL + j] = control_cost(Q, uos[min(t0 + j, Tp - 1)], e[j]);
+    raise(&cc_done[g], 1);
+  };
+
+  if (direct && walker >= 0) {
+    // (direct mode: nothing to walk; the three roles of the exact schedule start behind the barrier below)
+  } else if (walker == 0 || walker == 1) {
     // ================================================================ the theta walk (wave 0), the x | y walk (wave 4)
     // one running sum rounded to float32 after every fma; a lone wave issues an instruction per ~5
     // cycles: what counts is the instruction count -- one pointer per group, immediate offsets (the
@@ -627,7 +705,6 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
 #pragma unroll
       for (int j = 0; j < CHL; ++j) ut[j] = uq[min(t0 + j, T - 1)];
     }
-    float2 e[CHL];
     if constexpr (GEN) {
       const uint64_t epoch = gen.epoch + (gen.gen_counter ? *gen.gen_counter : 0ull);
       const unsigned int pairs = (unsigned int)(T + 1) / 2u;
@@ -656,6 +733,8 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
 #pragma unroll
       for (int j = 0; j < CHL; ++j) ut[j] = u_sh[t0 + j];
     }
+    if (!direct) {  // (wave-uniform; direct mode: the noise is all this wave owes before the exact schedule starts; its
+                    //  control-cost terms follow behind the schedule's first barrier -- chunk_ccr as background)
     double qx[CHL];  // dt * clipped speed: exact products of float32 factors
 #pragma unroll
     for (int j = 0; j < CHL; ++j) {
@@ -671,18 +750,11 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     MPPI_STAMP(stamp_wg && c < 16, stamp_base + 1);
     // (everything the walks do not wait for comes after their flags)
 
-    // ---------------------------------------------------------------- the control-cost terms of this wave's steps:
-    // lambda * (u0/s0^2 * e0 + u1/s1^2 * e1) in float64 (mppi.py:1007-1009), needed after the terminal cost only.
+    // ---------------------------------------------------------------- the control-cost terms of this wave's steps.
     // Here, while the theta walk has not reached this group yet (every group waits >= 0.5k cycles for its headings):
     // at the end of the wave they competed with the late groups' lookups and records for the SIMD, and the noise
     // stayed in registers all the way
-    if (lane < 8) {  // the control ratios of the 8 steps (float64 quotients: mppi.py:709)
-      const float2 ul = folded ? u_sh[8 * g + lane] : uq[min(8 * g + lane, T - 1)];
-      uos[8 * g + lane] = make_double2((double)ul.x / Q.s0sq, (double)ul.y / Q.s1sq);
-    }
-#pragma unroll
-    for (int j = 0; j < CHL; ++j) ccr[((size_t)k * R + r) * CHL + j] = control_cost(Q, uos[min(t0 + j, Tp - 1)], e[j]);
-    raise(&cc_done[g], 1);
+    chunk_ccr();
     MPPI_STAMP(stamp_wg && c < 16, stamp_base + 2);
 
     // ---------------------------------------------------------------- B: sin / cos of this wave's headings
@@ -843,18 +915,34 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     }
     raise(&c_done[g], group_pen ? 3 : 1);
     MPPI_STAMP(stamp_wg && c < 16, stamp_base + 6);
+    }  // !direct
   }
-  lds_barrier();
-  if (fallback.offset >= 0 && flags[0] != 0u) {  // (workgroup-uniform: every vote is in)
-    // ---- a failed vote: the tile again, on the exact pipelined schedule (scan_exact_reexecute above)
-    if (c == 1 && lane == 0 && Q.spec_failures) atomicAdd_system(Q.spec_failures, 1u);  // (the host decides whether this map pays)
-    const float cost = scan_exact_reexecute<POW2RES>(Q, cells16, base + fallback.offset, fallback.map_bytes, e2,
-                                                     folded ? u_sh : uq, T, c, lane);
+  if (direct) {
+    // ---- no time-parallel attempt (ScanFallback::direct): the noise is in e2, the controls in u_sh (a folded launch) or
+    //      in memory, the window's vectors were requested at entry
+    if (c >= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the map window has landed in LDS
+    lds_barrier();
+    const float cost = scan_exact_reexecute<POW2RES>(Q, cells16, base + fallback.offset, fallback.map_bytes, e2, uq, T, c, lane,
+                                                     folded ? u_sh : (const float2*)nullptr, fallback.rot_ok != 0,
+                                                     [&]() { if (g >= 0) chunk_ccr(); });
     if (c == 1) {
       __builtin_amdgcn_s_setprio(3);
       finish_tile(cost);
     }
     lds_barrier();
+  } else {
+  lds_barrier();
+  if (fallback.offset >= 0 && flags[0] != 0u) {  // (workgroup-uniform: every vote is in)
+    // ---- a failed vote: the tile again, on the exact pipelined schedule (scan_exact_reexecute above)
+    if (c == 1 && lane == 0 && Q.spec_failures) atomicAdd_system(Q.spec_failures, 1u);  // (the host decides whether this map pays)
+    const float cost = scan_exact_reexecute<POW2RES>(Q, cells16, base + fallback.offset, fallback.map_bytes, e2,
+                                                     folded ? u_sh : uq, T, c, lane, (const float2*)nullptr, fallback.rot_ok != 0, []() {});
+    if (c == 1) {
+      __builtin_amdgcn_s_setprio(3);
+      finish_tile(cost);
+    }
+    lds_barrier();
+  }
   }
 
   // ---------------------------------------------------------------- F: the tile's share of the update

@@ -115,6 +115,13 @@ struct PendingApply {
   int reduce_n_tiles;
   unsigned long long* published;    // [2][T][kPublishedStride] words, one used per step
   int flag_set;
+  // the hand-over is bounded and fails soft (round 5): a workgroup that has polled `max_polls` times for a step --
+  // its publisher is not running: fewer workgroups resident than the launch has, a second tenant or a CU mask --
+  // raises this host-mapped word, takes what memory holds for the missing steps (garbage: the call is lost) and goes
+  // on, so the launch ends, the host sees the word at its next synchronisation, returns MPPI_ERR_BUSY and stops
+  // folding updates into rollout launches on this handle.  No trap on any default path.
+  unsigned int* fault;
+  int max_polls;
   // Several GPUs in that mode (round 4, the peer exchange): the workgroup that has combined the LOCAL tiles for
   // step t writes this rank's four numbers for that step -- beta_g, den_g, num_g[t] -- straight into every rank's
   // inbox (peer access / IPC-mapped fine-grained memory: xGMI on a multi-GPU node) and waits for the other ranks'
@@ -332,15 +339,15 @@ __device__ __forceinline__ void publish_step(const PendingApply& A, StepSums S, 
 
 // every workgroup, one wave: the published sequence -> u_sh[0 .. Tp) (LDS); steps past the horizon are zero.
 // A lane polls the steps lane, lane + 64, ... and stops asking for a step once it has it.
-// Bounded: the publishers are the first workgroups of the grid, dispatched before any workgroup that waits for them,
-// so this cannot deadlock; should it ever poll for about a second (without a peer exchange), something else is broken:
-// trap rather than hang.
+// The publishers are the first workgroups of the grid, dispatched before any workgroup that waits for them, so with
+// the whole grid resident (one workgroup per CU: what the launch plan provides on a device of its own) this cannot
+// deadlock.  It is bounded all the same: see PendingApply::fault.
 __device__ __forceinline__ void collect_published(const PendingApply& A, int n_steps, int padded_steps, int lane,
                                                   float2* u_sh) {
   unsigned long long* words = A.published + (size_t)A.flag_set * n_steps * kPublishedStride;
   // (with a peer exchange the publishers may themselves be waiting for another rank, up to peers.max_polls of THEIR
-  // polls, and then publish what they have and raise the fault word: the collectors must outlast that, not trap first)
-  const int limit = A.peers.world > 0 ? 8 * min(max(A.peers.max_polls, 1 << 17), 1 << 27) : (1 << 20);
+  // polls, and then publish what they have and raise the peers' fault word: the collectors must outlast that)
+  const int limit = A.peers.world > 0 ? 8 * min(max(A.peers.max_polls, 1 << 17), 1 << 27) : max(A.max_polls, 1);
   for (int base = 0; base < padded_steps; base += 128) {  // (one round for T <= 128)
     unsigned long long w[2] = {kNotPublished, kNotPublished};
     for (int polls = 0;; ++polls) {
@@ -354,7 +361,18 @@ __device__ __forceinline__ void collect_published(const PendingApply& A, int n_s
         }
       }
       if (__all(all_there)) break;
-      if (polls > limit) __builtin_trap();
+      // give up: after `limit` polls, or as soon as another workgroup of this or an earlier launch has
+      if (polls > limit || ((polls & 255) == 255 && A.fault &&
+                            __hip_atomic_load(A.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)) {
+        if (!A.fault) __builtin_trap();  // (no word to raise: a handle built without one -- not the library's)
+        if (lane == 0) __hip_atomic_store(A.fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {  // (whatever the other control buffer holds: the call is lost, the launch ends)
+          const int t = base + lane + 64 * q;
+          if (t < n_steps && w[q] == kNotPublished) w[q] = published_word(A.u_out[t]);
+        }
+        break;
+      }
       __builtin_amdgcn_s_sleep(1);
     }
 #pragma unroll

@@ -447,6 +447,18 @@ class MPPI_Numba(object):
         tiles, 32 or 64 rollouts); math="fast": variants agree to float32 tolerance (include/mppi_hip.h)."""
         _lib.call("mppi_planner_set_debug_flags", self._handle, int(flags))
 
+    def set_fold_poll_limit(self, polls):
+        """Test hook: how long a workgroup of a rollout launch waits for the controls its siblings publish inside the
+        launch before it gives the launch up (include/mppi_hip.h, MPPI_ERR_BUSY)."""
+        _lib.call("mppi_planner_set_fold_poll_limit", self._handle, int(polls))
+
+    def fold_state(self):
+        """(folding, faults): whether this handle still folds its updates into the next rollout launch, and how many
+        launches have given that hand-over up so far."""
+        folding, faults = C.c_int(0), C.c_long(0)
+        _lib.call("mppi_planner_fold_state", self._handle, C.byref(folding), C.byref(faults))
+        return bool(folding.value), int(faults.value)
+
     def set_graph_replay(self, enabled=True, iterations_per_graph=2):
         """hipGraph replay of the iteration loop (include/mppi_hip.h); same results."""
         _lib.call("mppi_planner_set_graph_replay", self._handle, int(iterations_per_graph) if enabled else 0)

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import bench
+from mppi_numba_amd import _lib
 from helpers import ulp_diff_f32
 from oracle import oracle as O
 
@@ -517,11 +518,11 @@ def test_planner_stops_speculating_on_a_map_where_it_does_not_pay():
     params = bench.make_params("c2")
     params.update(x0=np.array([25.1, 24.9, 0.7]), xgoal=np.array([40.0, 38.0]), lambda_weight=5.0)
 
-    def check(planner, lin, ang, expect):
+    def check(planner, lin, ang, expect, mode=""):
         planner.sample_noise()
         noise, u_in = planner.noise_samples_d.copy_to_host(), planner.u_cur_d.copy_to_host()
         planner.rollout()
-        assert planner.last_rollout_kernel().startswith(expect), planner.last_rollout_kernel()
+        assert planner.last_rollout_kernel().startswith(expect) and mode in planner.last_rollout_kernel(), planner.last_rollout_kernel()
         ulps = ulp_diff_f32(planner.costs_d.copy_to_host(), oracle_costs(dict(m=1), params, lin, ang, noise, u_in))
         assert (ulps == 0).mean() >= 0.999
 
@@ -535,10 +536,15 @@ def test_planner_stops_speculating_on_a_map_where_it_does_not_pay():
     ang.sample_grids()
     check(planner, lin, ang, "k_rollout_scan_exact")  # nothing known about this map yet
     planner.solve()                             # ... the host synchronises, sees the failed tiles ...
-    check(planner, lin, ang, "k_rollout_pipe")  # ... and stops speculating
+    # ... and stops speculating: every tile on the exact three-wave schedule at once (round 5: inside the same kernel,
+    # so the iteration stays one launch; round 4 launched k_rollout_pipe + k_update_rows here)
+    check(planner, lin, ang, "k_rollout_scan_exact", "direct=1")
     planner.iterate_async(3)
     planner.synchronize()
+    check(planner, lin, ang, "k_rollout_scan_exact", "direct=1")
+    planner.set_debug_flags(_lib.DEBUG_NO_SCAN_DIRECT)
     check(planner, lin, ang, "k_rollout_pipe")
+    planner.set_debug_flags(0)
     # a map of one traction value: speculation pays again
     pmf, ang_pmf, obstacle, unknown, td = patch_world(rows, cols, res, "uniform", seed=11)
     lin.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)

@@ -7,7 +7,9 @@ changes from cell to cell, as C4).
 A tile whose vote fails is re-executed inside the same launch on the exact three-wave pipelined
 schedule (rollout_scan_exact_kernel.h: scan_exact_reexecute -- round 3 rolled it out with one wave,
 ~300 us per launch); the planner counts failed tiles per LAUNCH and, at its next synchronisation,
-takes k_rollout_pipe on such a map.  Costs are the oracle's bits either way (mppi.py:916-1009)."""
+stops speculating on such a map: round 5 keeps the kernel and launches it `direct` (every tile on the
+exact schedule at once: one launch per iteration), round 4 took k_rollout_pipe + k_update_rows (still
+there behind MPPI_DEBUG_NO_SCAN_DIRECT).  Costs are the oracle's bits either way (mppi.py:916-1009)."""
 import numpy as np
 import pytest
 
@@ -42,11 +44,18 @@ def test_failed_votes_are_reexecuted_pipelined_and_the_planner_then_takes_the_ex
     name = stage_level_iteration(planner, w, params, lin, ang)
     assert name.startswith("k_rollout_scan_exact") and "failed_tiles=pipelined" in name, name
     planner.solve()  # the host synchronises and sees the failed tiles
+    # round 5: the same kernel without the time-parallel attempt -- every tile on the exact three-wave schedule at
+    # once, noise from the counters, previous update folded in, tile packets out: one launch per iteration
     name = stage_level_iteration(planner, w, params, lin, ang)
-    assert name.startswith("k_rollout_pipe"), name
+    assert name.startswith("k_rollout_scan_exact") and "direct=1" in name, name
     planner.iterate_async(4)
     planner.synchronize()
-    assert planner.last_rollout_kernel().startswith("k_rollout_pipe")
+    name = planner.last_rollout_kernel()
+    assert name.startswith("k_rollout_scan_exact") and "direct=1" in name and "reduces_tiles=1" in name, name
+    # ... and round 4's choice behind a developer switch: the bits of the oracle as well
+    planner.set_debug_flags(_lib.DEBUG_NO_SCAN_DIRECT)
+    name = stage_level_iteration(planner, w, params, lin, ang)
+    assert name.startswith("k_rollout_pipe"), name
 
 
 @pytest.mark.parametrize("workload", ["c2s", "c2c"])
@@ -67,3 +76,21 @@ def test_loop_that_keeps_speculating_has_the_bits_of_the_exact_kernel(workload):
     span = np.array([params["vrange"][1] - params["vrange"][0], params["wrange"][1] - params["wrange"][0]])
     du = float((np.abs(spec.u_cur_d.copy_to_host() - exact.u_cur_d.copy_to_host()) / span).max())
     assert du <= 2e-6, du
+
+
+@pytest.mark.parametrize("workload", ["c2s", "c2c"])
+def test_direct_exact_schedule_has_the_bits_of_the_loop_that_keeps_speculating(workload):
+    """Round 5: once the planner has stopped speculating the kernel runs `direct`.  Same noise counters, same
+    arithmetic per rollout, same tiles of 32 rollouts, same packets, same fold: the control sequence of a loop that
+    switches (default) and of one that never does (MPPI_DEBUG_KEEP_SPECULATING) is the same BITS after every call."""
+    _, _, _, _, spec, _ = bench.build_planner(workload)
+    _, _, _, _, auto, _ = bench.build_planner(workload)
+    spec.set_debug_flags(_lib.DEBUG_KEEP_SPECULATING)
+    for call in range(3):
+        for planner in (spec, auto):
+            planner.solve()
+            planner.iterate_async(5)
+            planner.synchronize()
+        assert np.array_equal(spec.u_cur_d.copy_to_host().view(np.uint32), auto.u_cur_d.copy_to_host().view(np.uint32)), call
+        assert np.array_equal(spec.costs_d.copy_to_host().view(np.uint32), auto.costs_d.copy_to_host().view(np.uint32)), call
+    assert "direct=1" in auto.last_rollout_kernel() and "direct=1" not in spec.last_rollout_kernel()

@@ -34,12 +34,13 @@ def main():
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--math", default="fast", choices=["fast", "exact"])
+    ap.add_argument("--workload", default="c2", help="c2s / c2c: the exact three-wave schedule inside the kernel (direct mode; slots 11 .. 15 of waves 0 state, 1 cost, 2 producer: entered, first barrier passed, chunk 0 done, chunk 6 done, loop end)")
     ap.add_argument("--iterations", type=int, default=1, help="iterations per call (>1: the last launch folds the previous update)")
     args = ap.parse_args()
     from mppi_numba_amd import _lib
     with contextlib.redirect_stdout(io.StringIO()):
         from bench import build_planner as build
-        w, cfg, lin, ang, planner, params = build("c2", args.n, math=args.math)
+        w, cfg, lin, ang, planner, params = build(args.workload, args.n, math=args.math)
         planner.set_debug_flags(args.flags)
         planner.solve()
         planner.iterate_async(20)
