@@ -128,6 +128,9 @@ SIGNATURES = {
     "mppi_planner_time_kernels": [_vp, _vp, _vp, C.c_int, _f32p, _f32p],
     "mppi_planner_describe_last_rollout": [_vp, C.c_char_p, C.c_int],
     "mppi_planner_set_debug_flags": [_vp, C.c_int],
+    "mppi_planner_set_fold_poll_limit": [_vp, C.c_int],
+    "mppi_planner_fold_state": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_long)],
+    "mppi_debug_occupy_cus": [C.c_int, C.c_int, C.c_int],
     "mppi_selftest_philox": [C.c_int, C.POINTER(C.c_int)],
     "mppi_debug_read_stamps": [C.POINTER(C.c_ulonglong), C.c_int, C.c_int],
     "mppi_planner_graph_probe": [_vp, _vp, _vp, C.c_int, C.c_int, _f32p, _f32p],
