@@ -280,6 +280,15 @@ __device__ __forceinline__ void copy_window_to_lds_direct(const DevParams& P, co
   const float inv_vpr = 1.0f / (float)vec_per_row;
   const int lane = tid & 63;
   const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+  if (vec_per_row == src_pitch) {  // full-width window (the whole map at long horizons): one contiguous run
+    for (int base = wave_base; base < total; base += n_threads) {
+      const int v = base + lane;
+      if (v < total)
+        __builtin_amdgcn_global_load_lds(src + v, (__attribute__((address_space(3))) void*)(reinterpret_cast<uint4*>(lds_map) + base),
+                                         16, 0, 0);
+    }
+    return;
+  }
   for (int base = wave_base; base < total; base += n_threads) {
     const int v = base + lane;
     const int r = (int)(((float)v + 0.5f) * inv_vpr);
@@ -703,7 +712,15 @@ __device__ __forceinline__ void pipe_tile_body(DevParams P, const uint16_t* __re
   // them stages the arrays itself (the same values to the same addresses when there are several)
   // and goes on without a workgroup barrier -- a wave's LDS operations complete in order --
   // while the state and cost waves are already copying the map window.
+  // (round 5: its first two chunks of noise are requested BEFORE the controls -- two round trips to memory one after
+  //  the other put the producer's first chunk, and with it the first barrier, ~2k cycles behind the window copy)
+  constexpr int kFirstNoise = 2 * C;
+  float2 e_first[kFirstNoise];
   if (role == 2) {
+    const int tile0 = blockIdx.x * W + triple;
+    const float2* col0 = noise + (tile0 * 64 < N ? (size_t)tile0 * T * 64 + lane : (size_t)0);
+#pragma unroll
+    for (int j = 0; j < kFirstNoise; ++j) e_first[j] = col0[(size_t)min(j, T - 1) * 64];
     for (int t = lane; t < T; t += 64) {
       const float2 ut = u[t];
       us[t] = ut;
@@ -779,9 +796,9 @@ __device__ __forceinline__ void pipe_tile_body(DevParams P, const uint16_t* __re
       }
     };
 #pragma unroll
-    for (int j = 0; j < C; ++j) e_cur[j] = col[(size_t)min(j, T - 1) * 64];
+    for (int j = 0; j < C; ++j) e_cur[j] = e_first[j];
 #pragma unroll
-    for (int j = 0; j < C; ++j) e_nxt[j] = col[(size_t)min(C + j, T - 1) * 64];
+    for (int j = 0; j < C; ++j) e_nxt[j] = e_first[C + j];
     produce(0, e_cur);
     MPPI_STAMP(stamp_wg && triple == 0, stamp_base + 2);
     __syncthreads();
@@ -847,9 +864,17 @@ __device__ __forceinline__ void pipe_tile_body(DevParams P, const uint16_t* __re
     // loop made the compiler keep the batch registers live across it and cost 7 us; wider single batches were no better.
     constexpr int kTailBatch = 24;
     double ca[kTailBatch], cb[kTailBatch];
+    // (a whole batch inside the horizon: one base address and immediate offsets; the clamped form of the last batch
+    //  costs ~6 address instructions per load -- as many as the three-instruction addition it feeds, twice over)
     auto tail_load = [&](double (&dst)[kTailBatch], int t0) {
+      if (t0 + kTailBatch <= T) {
+        const double* at = my_cc + (size_t)t0 * 64;
 #pragma unroll
-      for (int j = 0; j < kTailBatch; ++j) dst[j] = my_cc[(size_t)min(t0 + j, T - 1) * 64];
+        for (int j = 0; j < kTailBatch; ++j) dst[j] = at[j * 64];
+      } else {
+#pragma unroll
+        for (int j = 0; j < kTailBatch; ++j) dst[j] = my_cc[(size_t)min(t0 + j, T - 1) * 64];
+      }
     };
     auto tail_add = [&](const double (&src)[kTailBatch], int t0) {
       if (t0 + kTailBatch <= T) {
@@ -861,6 +886,9 @@ __device__ __forceinline__ void pipe_tile_body(DevParams P, const uint16_t* __re
           if (t0 + j < T) cost = (float)((double)cost + src[j]);
       }
     };
+    // (three register sets, two batches ahead -- enough to cover the L2 latency of the global scratch at T = 200,
+    //  where this walk runs at 57 cycles per addition -- made the LAUNCH 21 us slower: the kernel's register allocation
+    //  is one for all roles, and 144 batch registers moved the state role's; measured, round 5)
     tail_load(ca, 0);
     for (int t0 = 0; t0 < T; t0 += 2 * kTailBatch) {
       tail_load(cb, t0 + kTailBatch);
