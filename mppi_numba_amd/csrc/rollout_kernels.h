@@ -1100,6 +1100,13 @@ __global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cel
   [[maybe_unused]] const float dwf = (float)P.dist_weight, gt2f = P.gt2;
   const double gt2 = (double)P.gt2;
   const float last_col = (float)(P.cols - 1), last_row = (float)(P.rows - 1);
+  // Round 5 (instruction budget per (n, m, t), profiles/r05_c3_isa.md): the additive traction constants pinned in
+  // vector registers (a v_fma_f64 takes ONE scalar operand: with ratio and lo both scalar the compiler copied lo into
+  // a register pair again every step, two v_mov_b64 per step), both cell coordinates in one packed subtract and one
+  // packed multiply, the square root without the select of an exact zero (sqrt_newton_nz_f64: added to >= dt).
+  double lin_lo_v = P.lin_lo, ang_lo_v = P.ang_lo;
+  asm volatile("" : "+v"(lin_lo_v), "+v"(ang_lo_v));
+  const pipe_f2 map_lo = {P.xlo, P.ylo}, map_inv = {P.inv_res, P.inv_res};
   for (int m = threadIdx.x; m < m_pow2; m += blockDim.x) {
     if (m >= M) {
       sc[m] = -__builtin_inff();  // padding sorts to the tail
@@ -1114,16 +1121,17 @@ __global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cel
     auto step = [&](int t) {
       double2 qd = qd_sh[t];
       int xi, yi;
-      if (POW2RES) {  // see cell_coord_pow2 (window = the whole map)
-        xi = cell_coord_pow2(x, P.xlo, P.inv_res, 0.0f, last_col);
-        yi = cell_coord_pow2(y, P.ylo, P.inv_res, 0.0f, last_row);
+      if (POW2RES) {  // see cell_coord_pow2 (window = the whole map; fl(pos - lo) * inv_res is exact)
+        const pipe_f2 q = (pipe_f2{x, y} - map_lo) * map_inv;
+        xi = (int)__builtin_amdgcn_fmed3f(q.x, 0.0f, last_col);
+        yi = (int)__builtin_amdgcn_fmed3f(q.y, 0.0f, last_row);
       } else {
         xi = clamp_index(floordiv_to_int(x - P.xlo, P.res, P.inv_res), P.cols);
         yi = clamp_index(floordiv_to_int(y - P.ylo, P.res, P.inv_res), P.rows);
       }
       uint32_t cell = cellsM[(size_t)(yi * P.cols + xi) * M + m];
-      double vtr = fma(P.lin_ratio, (double)(int)(int8_t)(cell & 0xff), P.lin_lo);
-      double wtr = fma(P.ang_ratio, (double)(int)(int8_t)((cell >> 8) & 0xff), P.ang_lo);
+      double vtr = fma(P.lin_ratio, (double)(int)(int8_t)(cell & 0xff), lin_lo_v);
+      double wtr = fma(P.ang_ratio, (double)(int)(int8_t)((cell >> 8) & 0xff), ang_lo_v);
       float nx = (float)fma(vtr, qd.x * c, x64);
       float ny = (float)fma(vtr, qd.x * s, y64);
       float nth = (float)fma(wtr, qd.y, th64);
@@ -1139,7 +1147,7 @@ __global__ void k_rollout_tdm_fast(DevParams P, const uint32_t* __restrict__ cel
       } else {
         double dx = (double)(P.xg - nx), dy = (double)(P.yg - ny);
         nd2 = fma(dx, dx, dy * dy);
-        c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(nd2), dt64));
+        c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_nz_f64(nd2), dt64));
         hit = nd2 <= gt2;
       }
       c1 = c1 + (float)(int8_t)((cell >> 16) & 0xff) * P.obs_cost;
