@@ -363,7 +363,12 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   // packets (reducing) every wave takes it where it would otherwise wait for the updated controls -- the chunk waves
   // behind their Philox blocks, wave 0 when it has collected the sequence -- so that nobody stands at a barrier while
   // the packets are on their way, and the barrier's release is the hand-over of u_sh.
-  if (!reducing || c == 1 || (walker < 0 && g < 0)) lds_barrier();  // (every wave has only just started; the cost walker and a wave without a group have nothing else to do)
+  // (direct mode, reducing: this barrier is also the one in front of the exact schedule -- a wave that requested a
+  //  share of the map window waits for it here, where it waits anyway)
+  if (!reducing || c == 1 || (walker < 0 && g < 0)) {  // (every wave has only just started; the cost walker and a wave without a group have nothing else to do)
+    if (direct && reducing && c >= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+  }
   MPPI_STAMP(stamp_wg && c < 16, stamp_base + 9);
   // Everything a flag guards is in LDS, and the LDS executes one wave's instructions in the order they
   // were issued: a flag written after the data IS after the data for every other wave.  No s_waitcnt
@@ -728,8 +733,12 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
       e2[t * R + (r ^ (t & (R - 1)))] = e[j];
     }
     if (folded) {  // (wave-uniform) the sequence this launch's update leaves: formed by wave 0 meanwhile
-      if (reducing) lds_barrier();
-      else (void)wait_for(&u_ready[0]);
+      if (reducing) {
+        if (direct && c >= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's share of the map window)
+        lds_barrier();
+      } else {
+        (void)wait_for(&u_ready[0]);
+      }
 #pragma unroll
       for (int j = 0; j < CHL; ++j) ut[j] = u_sh[t0 + j];
     }
@@ -920,8 +929,10 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
   if (direct) {
     // ---- no time-parallel attempt (ScanFallback::direct): the noise is in e2, the controls in u_sh (a folded launch) or
     //      in memory, the window's vectors were requested at entry
-    if (c >= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the map window has landed in LDS
-    lds_barrier();
+    if (!reducing) {  // (reducing: the workgroup's first barrier was the hand-over of all three)
+      if (c >= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the map window has landed in LDS
+      lds_barrier();
+    }
     const float cost = scan_exact_reexecute<POW2RES>(Q, cells16, base + fallback.offset, fallback.map_bytes, e2, uq, T, c, lane,
                                                      folded ? u_sh : (const float2*)nullptr, fallback.rot_ok != 0,
                                                      [&]() { if (g >= 0) chunk_ccr(); });
