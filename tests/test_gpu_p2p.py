@@ -34,6 +34,19 @@ def test_ranks_sharing_the_device_through_ipc_have_the_bits_of_the_k_apply_loop(
     assert "max|du|=0.000e+00" in line, line
 
 
+@pytest.mark.parametrize("workload", ["c2s", "c2c"])
+def test_ranks_on_a_map_they_stop_speculating_on_keep_the_exchange(workload):
+    """which tiles fail their traction vote differs from rank to rank (own noise), so the ranks
+    stop speculating at their own synchronisations; round 4 then left k_rollout_scan_exact for k_rollout_pipe -- and
+    with it the peer exchange, which its peers kept waiting in.  Round 5: the kernel stays (direct: its exact
+    three-wave schedule), the packets and the exchange with it; the bits are those of the host-staged k_apply loop."""
+    line = run_ranks("--ranks", "2", "--n", "2048", "--t", "100", "--iterations", "6", "--calls", "4", "--workload", workload)
+    print("\n" + line)
+    assert line.startswith("P2P_OK") and "world=2" in line, line
+    assert "k_rollout_scan_exact+direct+reduces_tiles" in line, line
+    assert "max|du|=0.000e+00" in line, line
+
+
 @pytest.mark.parametrize("ranks,n,t,iterations", [(2, 2048, 100, 6), (3, 1024, 64, 5)])
 def test_ranks_in_the_tolerance_mode_have_the_bits_of_the_k_apply_loop(ranks, n, t, iterations):
     """math="fast": k_rollout_scan carries the same exchange (publish_step is shared)."""

@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--calls", type=int, default=3)
     ap.add_argument("--time", type=int, default=0, help="also time this many iterations of each exchange")
     ap.add_argument("--math", default="exact", choices=["exact", "fast"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c2s", "c2c"],
+                    help="c2s / c2c: maps on which tiles fail their traction vote and the planners stop speculating -- every "
+                         "rank at its own synchronisation: the kernel family (and with it the exchange) must survive that")
     args = ap.parse_args()
     from mppi_numba_amd import launch
     if not launch.launched_by_a_launcher():
@@ -39,11 +42,11 @@ def main():
     hub = launch.Hub(rank, world)
     import bench
     from mppi_numba_amd import _lib
-    saved = dict(bench.WORKLOADS["c2"])
-    bench.WORKLOADS["c2"] = dict(saved, t=args.t)
+    saved = dict(bench.WORKLOADS[args.workload])
+    bench.WORKLOADS[args.workload] = dict(saved, t=args.t)
     with contextlib.redirect_stdout(io.StringIO()):
-        _, _, lin, ang, peer, params = bench.build_planner("c2", args.n, rank=rank, world=world, math=args.math)
-        _, _, lin2, ang2, staged, _ = bench.build_planner("c2", args.n, rank=rank, world=world, math=args.math)
+        _, _, lin, ang, peer, params = bench.build_planner(args.workload, args.n, rank=rank, world=world, math=args.math)
+        _, _, lin2, ang2, staged, _ = bench.build_planner(args.workload, args.n, rank=rank, world=world, math=args.math)
     handles = hub.all_gather(peer.p2p_export())
     peer.p2p_connect(handles)
     hub.barrier()
@@ -91,7 +94,7 @@ def main():
     if rank == 0:
         print("%s world=%d n_per_rank=%d T=%d exchanges=%d inbox=%s kernel=%s max|du|=%.3e%s" % (
             "P2P_OK" if all(oks) else "P2P_MISMATCH", world, args.n, args.t, stats["exchanges"], stats["inbox"],
-            name.split(" ")[0] + ("+reduces_tiles" if "reduces_tiles=1" in name else ""), max(worsts), timing))
+            name.split(" ")[0] + ("+direct" if "direct=1" in name else "") + ("+reduces_tiles" if "reduces_tiles=1" in name else ""), max(worsts), timing))
         sys.stdout.flush()
     hub.barrier()
     hub.close()
