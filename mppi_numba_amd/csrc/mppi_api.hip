@@ -1649,7 +1649,15 @@ extern "C" int mppi_group_iterate_async(mppi_planner** ps, mppi_tdm** lins, mppi
     // nothing to coordinate on the host -- each device's loop is enqueued as if it were alone, the launches wait for
     // each other's numbers on the devices.  (Decided alike for all: they share sizes, mode and maps.)
     bool all_p2p = count > 1;
-    for (int g = 0; g < count && all_p2p; ++g) all_p2p = ps[g] && ps[g]->params_set && p2p_usable(ps[g]);
+    for (int g = 0; g < count && all_p2p; ++g) all_p2p = ps[g] && ps[g]->params_set && ps[g]->p2p_on && lins[g] && angs[g];
+    // (which kernels will run is decided from the packed maps: pack them first -- a group's very first call would
+    //  otherwise take the RCCL path, or fail for want of a communicator it does not need)
+    for (int g = 0; g < count && all_p2p; ++g) {
+      HIP_TRY(hipSetDevice(ps[g]->cfg.device));
+      TRY(check_tdms(ps[g], lins[g], angs[g]));
+      TRY(ensure_packed(ps[g], lins[g], angs[g]));
+      all_p2p = p2p_usable(ps[g]);
+    }
     if (all_p2p) {
       // Every launch of device g spins inside the kernel until the other devices' numbers for the same iteration have
       // arrived, so no device may be handed more launches than its queue takes before the others have theirs: a few

@@ -47,6 +47,25 @@ def test_ranks_on_a_map_they_stop_speculating_on_keep_the_exchange(workload):
     assert "max|du|=0.000e+00" in line, line
 
 
+@pytest.mark.parametrize("ranks,workload", [(2, "c2"), (2, "c2s")])
+def test_device_group_in_one_process_uses_the_peer_exchange(ranks, workload):
+    """mppi_group_p2p_connect (peer access before the inboxes are allocated, a ping of all ranks at once) and
+    mppi_group_iterate_async's enqueue -- a few iterations per device in turn: every launch of one device waits inside
+    the kernel for the other devices' numbers -- with the shard planners of one process.
+    (Two planners: on ONE device the runtime maps a process's streams onto four hardware queues, and launches that
+    share a queue run one after the other -- with three planners the connect's own ping reports "heard 2 of 3" and
+    refuses, as it should; devices of their own have queues of their own.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MPPI_RDZV_FILE")}
+    env["MPPI_P2P_MAX_POLLS"] = str(1 << 21)  # (a second, not five, should the launches ever fail to run side by side)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "p2p_group.py"), "--ranks", str(ranks), "--workload", workload],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("GROUP_P2P_")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-1500:], out.stderr[-1500:])
+    print("\n" + lines[0])
+    assert lines[0].startswith("GROUP_P2P_OK") and "max|du|=0.000e+00" in lines[0], lines[0]
+    assert "kernel=k_rollout_scan_exact" in lines[0] and "exchanges=0" not in lines[0], lines[0]
+
+
 @pytest.mark.parametrize("ranks,n,t,iterations", [(2, 2048, 100, 6), (3, 1024, 64, 5)])
 def test_ranks_in_the_tolerance_mode_have_the_bits_of_the_k_apply_loop(ranks, n, t, iterations):
     """math="fast": k_rollout_scan carries the same exchange (publish_step is shared)."""
