@@ -94,3 +94,23 @@ def test_direct_exact_schedule_has_the_bits_of_the_loop_that_keeps_speculating(w
         assert np.array_equal(spec.u_cur_d.copy_to_host().view(np.uint32), auto.u_cur_d.copy_to_host().view(np.uint32)), call
         assert np.array_equal(spec.costs_d.copy_to_host().view(np.uint32), auto.costs_d.copy_to_host().view(np.uint32)), call
     assert "direct=1" in auto.last_rollout_kernel() and "direct=1" not in spec.last_rollout_kernel()
+
+
+@pytest.mark.parametrize("workload", ["c2s"])
+def test_graph_replay_of_the_direct_loop_has_the_bits_of_the_direct_launches(workload):
+    """hipGraph replay (opt-in) over a map the planner has stopped speculating on: the captured launches are the
+    direct ones (fold, buffer parities and all); the same bits as the loop launched directly."""
+    _, _, _, _, plain, _ = bench.build_planner(workload, 4096)
+    _, _, _, _, graph, _ = bench.build_planner(workload, 4096)
+    graph.set_graph_replay(True, 4)
+    for planner in (plain, graph):
+        planner.solve()          # (speculative launch, failed tiles; the host sees them)
+        planner.iterate_async(3)
+        planner.synchronize()
+    for call in range(3):
+        for planner in (plain, graph):
+            planner.iterate_async(9)   # warm-up iteration + two graphs of four
+            planner.synchronize()
+        assert "direct=1" in graph.last_rollout_kernel(), graph.last_rollout_kernel()
+        assert np.array_equal(plain.u_cur_d.copy_to_host().view(np.uint32), graph.u_cur_d.copy_to_host().view(np.uint32)), call
+        assert np.array_equal(plain.costs_d.copy_to_host().view(np.uint32), graph.costs_d.copy_to_host().view(np.uint32)), call
