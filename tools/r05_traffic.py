@@ -17,8 +17,8 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 PROF = os.path.join(ROOT, "profiles")
 # key in traffic.json -> (tag, label)
 SOURCES = {
-    "c2": ("r05n", "c2"), "c2_fast": ("r05n", "c2fast"), "c2s": ("r05n", "c2s"), "c2c": ("r05n", "c2c"),
-    "c4shard": ("r05n", "c4shard"), "ns": ("r05a", "ns"), "c3": ("r05a", "c3"), "c4": ("r05a", "c4"), "c5": ("r05a", "c5"),
+    "c2": ("r05p", "c2"), "c2_fast": ("r05p", "c2fast"), "c2s": ("r05p", "c2s"), "c2c": ("r05p", "c2c"),
+    "c4shard": ("r05p", "c4shard"), "ns": ("r05p", "ns"), "c3": ("r05p", "c3"), "c4": ("r05p", "c4"), "c5": ("r05p", "c5"),
 }
 NOTES = {
     "c2": "the launch is the whole iteration: Philox in registers, the previous update combined by 100 of its workgroups, tile packets out; bound by instruction issue, the three float32-rounded walks and the in-launch hand-off of u, not by HBM",
