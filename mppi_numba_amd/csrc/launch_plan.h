@@ -386,7 +386,7 @@ static bool scan_plan(const mppi_planner* p, ScanPlan* out) {
   if (!p->cells16_valid || p->cells16_with_risk) return false;
   const bool direct = p->speculation_off && !(p->debug_flags & MPPI_DEBUG_KEEP_SPECULATING);
   static const bool no_direct = getenv("MPPI_NO_SCAN_DIRECT") != nullptr;  // developer switch (ablation): k_rollout_pipe as in round 4
-  if (direct && (no_direct || (p->debug_flags & MPPI_DEBUG_NO_SCAN_DIRECT) || p->cfg.math != MPPI_MATH_EXACT || p->inst_set ||
+  if (direct && (no_direct || (p->debug_flags & MPPI_DEBUG_NO_SCAN_DIRECT) || p->cfg.math != MPPI_MATH_EXACT ||
                  !p->packed_lin || !p->packed_ang))
     return false;
   const int T = p->cfg.num_steps;
@@ -414,7 +414,9 @@ static bool scan_plan(const mppi_planner* p, ScanPlan* out) {
     // and the exact-increment rotation (|dt * w * traction| <= 0.36 rad): else k_rollout_pipe / the general kernels
     DevParams d = make_dev_params(p, p->packed_lin, p->packed_ang);
     size_t lds_win = 0;
-    if (!plan_lds_window(const_cast<mppi_planner*>(p), d, &lds_win)) return false;  // (single problem: nothing of p changes)
+    // (a batched handle's per-problem window origins are recomputed into its host mirror: the values launch_rollout_det
+    //  computes from the same start states -- idempotent)
+    if (!plan_lds_window(const_cast<mppi_planner*>(p), d, &lds_win)) return false;
     // LDS of a direct launch: noise | control-cost terms | {controls, window, ring} | small arrays (the walks' groups
     // and positions do not exist)
     const int W = plan.chunk_waves;
