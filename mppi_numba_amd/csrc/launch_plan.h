@@ -384,7 +384,10 @@ static bool scan_plan(const mppi_planner* p, ScanPlan* out) {
   if (disabled || (p->debug_flags & MPPI_DEBUG_NO_SCAN_KERNEL)) return false;
   if (p->cfg.mode != MPPI_MODE_DET) return false;
   if (!p->cells16_valid || p->cells16_with_risk) return false;
-  const bool direct = p->speculation_off && !(p->debug_flags & MPPI_DEBUG_KEEP_SPECULATING);
+  // (MPPI_DEBUG_NO_SPECULATION: "the speculative kernels on their exact schedule from the first step" -- for this kernel
+  //  that is the direct launch, whatever the map has shown so far: how the tests reach it on any map)
+  const bool direct = ((p->speculation_off && !(p->debug_flags & MPPI_DEBUG_KEEP_SPECULATING)) ||
+                       (p->debug_flags & MPPI_DEBUG_NO_SPECULATION)) && p->cfg.math == MPPI_MATH_EXACT;
   static const bool no_direct = getenv("MPPI_NO_SCAN_DIRECT") != nullptr;  // developer switch (ablation): k_rollout_pipe as in round 4
   if (direct && (no_direct || (p->debug_flags & MPPI_DEBUG_NO_SCAN_DIRECT) || p->cfg.math != MPPI_MATH_EXACT ||
                  !p->packed_lin || !p->packed_ang))

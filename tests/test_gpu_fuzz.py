@@ -122,7 +122,17 @@ def _patch_seeds():
 
 
 @pytest.mark.parametrize("seed", _patch_seeds())
-def test_random_configuration_on_patchwise_constant_traction(seed):
+def test_random_configuration_on_the_exact_schedule_inside_the_time_parallel_kernel(seed):
+    """Round 5: the same random cases with MPPI_DEBUG_NO_SPECULATION -- k_rollout_scan_exact `direct` (what the planner
+    launches on a map it has stopped speculating on) from the first launch: horizons of 1..104 steps (every count of
+    chunk waves, every length of the last chunk), 1..700 rollouts (ragged tiles), resolutions that are not powers of
+    two, frozen rollouts, goal breaks.  Bits of the oracle."""
+    from mppi_numba_amd import _lib
+    test_random_configuration_on_patchwise_constant_traction(seed, debug_flags=_lib.DEBUG_NO_SPECULATION)
+
+
+@pytest.mark.parametrize("seed", _patch_seeds())
+def test_random_configuration_on_patchwise_constant_traction(seed, debug_flags=0):
     """The speculation of the time-parallel kernels HOLDS on these maps (one traction value, or two in
     large patches: tiles that stay inside a patch keep their assumption, tiles that cross fail their
     vote and are re-run step by step), with everything else random: resolution (powers of two and
@@ -162,6 +172,8 @@ def test_random_configuration_on_patchwise_constant_traction(seed):
     ang.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)
     planner = MPPI_Numba(cfg)
     planner.setup(params, lin, ang)
+    if debug_flags:
+        planner.set_debug_flags(debug_flags)
     useq = planner.solve()
     assert useq is not None and useq.shape == (t_steps, 2) and np.isfinite(useq).all()
     planner.set_u((useq + rng.normal(0, 0.3, useq.shape)).astype(np.float32))
@@ -171,6 +183,9 @@ def test_random_configuration_on_patchwise_constant_traction(seed):
     kernel = planner.last_rollout_kernel()
     if t_steps <= 104 and seed % 3 != 0:  # (on a two-patch map the planner may have stopped speculating: review_speculation)
         assert kernel.startswith("k_rollout_scan_exact"), kernel
+    if debug_flags and t_steps <= 104:
+        # (direct whenever the map window fits beside the noise; else the kernels of its own)
+        assert "direct=1" in kernel or not kernel.startswith("k_rollout_scan"), kernel
     got = planner.costs_d.copy_to_host()
     p = O.make_params(params, lin.res, lin.padded_xlimits, lin.padded_ylimits,
                       lin.bin_values_bounds_d.copy_to_host(), ang.bin_values_bounds_d.copy_to_host())
