@@ -386,8 +386,9 @@ static bool scan_plan(const mppi_planner* p, ScanPlan* out) {
   if (!p->cells16_valid || p->cells16_with_risk) return false;
   // (MPPI_DEBUG_NO_SPECULATION: "the speculative kernels on their exact schedule from the first step" -- for this kernel
   //  that is the direct launch, whatever the map has shown so far: how the tests reach it on any map)
-  const bool direct = ((p->speculation_off && !(p->debug_flags & MPPI_DEBUG_KEEP_SPECULATING)) ||
-                       (p->debug_flags & MPPI_DEBUG_NO_SPECULATION)) && p->cfg.math == MPPI_MATH_EXACT;
+  const bool stopped = p->speculation_off && !(p->debug_flags & MPPI_DEBUG_KEEP_SPECULATING);
+  if (stopped && p->cfg.math != MPPI_MATH_EXACT) return false;  // (the tolerance kernel has no exact schedule inside)
+  const bool direct = (stopped || (p->debug_flags & MPPI_DEBUG_NO_SPECULATION)) && p->cfg.math == MPPI_MATH_EXACT;
   static const bool no_direct = getenv("MPPI_NO_SCAN_DIRECT") != nullptr;  // developer switch (ablation): k_rollout_pipe as in round 4
   if (direct && (no_direct || (p->debug_flags & MPPI_DEBUG_NO_SCAN_DIRECT) || p->cfg.math != MPPI_MATH_EXACT ||
                  !p->packed_lin || !p->packed_ang))
