@@ -848,7 +848,9 @@ static int try_launch_pipe(mppi_planner* p, DevParams& d, const DetRegime& r, bo
     };
     int chunk = 0;
     for (;;) {  // fewer triples per workgroup (more workgroups than CUs) before giving the kernel up
-      for (int cnd : {8, 4, 2})
+      // (6: the whole-map window of the long horizons -- 135 KiB at T = 200 -- leaves room for chunks of six steps but
+      //  not of eight; every chunk costs ~340 cycles beside its steps, so six instead of four is 28 cycles per step)
+      for (int cnd : {8, 6, 4, 2})
         if (lds_win + ring_bytes(cnd) <= budget) { chunk = cnd; break; }
       if (chunk > 0 || pairs == 1) break;
       --pairs;
@@ -890,6 +892,7 @@ MPPI_KLAUNCH(kern, dim3(grid + extra), dim3(block), lds_total, p->stream, d, p->
 #define MPPI_LAUNCH_PIPE_C(P2, CL)            \
   do {                                        \
 if (chunk == 8) MPPI_LAUNCH_PIPE(8, P2, CL);      \
+else if (chunk == 6) MPPI_LAUNCH_PIPE(6, P2, CL); \
 else if (chunk == 4) MPPI_LAUNCH_PIPE(4, P2, CL); \
 else MPPI_LAUNCH_PIPE(2, P2, CL);                 \
   } while (0)
