@@ -568,7 +568,12 @@ struct PipeWindow {
   float inv_res, res;
   int pitch_bytes, c0, r0, cols, rows;
   uint32_t base;          // LDS byte address of the window
+  // the additive traction constants in VECTOR registers: v_fma_f64 takes one scalar operand, and with ratio and lo both
+  // scalar the compiler copies lo into a register pair again in every step (two v_mov_b64 per step; profiles/r05_c3_isa.md)
+  double lin_lo, ang_lo;
   __device__ __forceinline__ PipeWindow(const DevParams& P, const uint16_t* lds_map) {
+    lin_lo = P.lin_lo; ang_lo = P.ang_lo;
+    asm volatile("" : "+v"(lin_lo), "+v"(ang_lo));
     lo = pipe_f2{P.xlo, P.ylo};
     origin = pipe_f2{(float)P.win_c0, (float)P.win_r0};
     inv_res = P.inv_res; res = P.res;
@@ -627,8 +632,8 @@ template <bool POW2RES, bool CHECK_ROTATION>
 __device__ __forceinline__ void pipe_state_step(const DevParams& P, const PipeWindow<POW2RES>& win, PipeState& st,
                                                 const double2 qd, float2* out_xy, uint16_t* out_cell) {
   const uint32_t c16 = pipe_cell_arrived(st.cell);
-  const double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), P.lin_lo);
-  const double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), P.ang_lo);
+  const double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), win.lin_lo);
+  const double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), win.ang_lo);
   const float x = (float)fma(vtr, qd.x * st.c, st.x64);
   const float y = (float)fma(vtr, qd.x * st.s, st.y64);
   const float th = (float)fma(wtr, qd.y, st.th64);
