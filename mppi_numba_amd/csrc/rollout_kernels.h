@@ -605,9 +605,15 @@ struct PipeWindow {
     return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t*>(address(x, y));
   }
 };
-__device__ __forceinline__ uint32_t pipe_cell_arrived(uint16_t raw) {
-  asm volatile("" : "+v"(raw));  // (the compiler's s_waitcnt for the lookup lands here)
-  return (uint32_t)raw;
+// The two 7-bit traction codes straight from the 16-bit load result (the compiler's s_waitcnt for the lookup lands
+// here).  Through a uint32 the compiler puts a zero extension -- v_and_b32 0xffff -- in front of the masks: one more
+// instruction on the position loop's dependent chain (cell -> code -> traction -> x -> coordinates -> address -> cell,
+// ~10 cycles per dependent instruction: profiles/r04_chain_latency.txt).
+__device__ __forceinline__ void pipe_cell_arrived(uint16_t raw, uint32_t& lin, uint32_t& ang) {
+  // (handed over as a 16-bit FLOAT: an integer of 16 bits is zero-extended for the register operand -- the very
+  //  instruction this is about --, a half is just its bits in the low half of the register)
+  const _Float16 bits = __builtin_bit_cast(_Float16, raw);
+  asm volatile("v_and_b32 %0, 0x7f, %2\n\tv_bfe_u32 %1, %2, 7, 7" : "=&v"(lin), "=v"(ang) : "v"(bits));
 }
 
 struct PipeState {
@@ -631,9 +637,11 @@ __device__ __forceinline__ PipeState pipe_state_init(const DevParams& P) {
 template <bool POW2RES, bool CHECK_ROTATION>
 __device__ __forceinline__ void pipe_state_step(const DevParams& P, const PipeWindow<POW2RES>& win, PipeState& st,
                                                 const double2 qd, float2* out_xy, uint16_t* out_cell) {
-  const uint32_t c16 = pipe_cell_arrived(st.cell);
-  const double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), win.lin_lo);
-  const double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), win.ang_lo);
+  const uint16_t c16 = st.cell;
+  uint32_t lin, ang;
+  pipe_cell_arrived(c16, lin, ang);
+  const double vtr = fma(P.lin_ratio, (double)(int)lin, win.lin_lo);
+  const double wtr = fma(P.ang_ratio, (double)(int)ang, win.ang_lo);
   const float x = (float)fma(vtr, qd.x * st.c, st.x64);
   const float y = (float)fma(vtr, qd.x * st.s, st.y64);
   const float th = (float)fma(wtr, qd.y, st.th64);
@@ -649,7 +657,7 @@ __device__ __forceinline__ void pipe_state_step(const DevParams& P, const PipeWi
   else sincos_f64<false>(th_new, st.s, st.c);
   st.th64 = th_new;
   *out_xy = make_float2(x, y);
-  *out_cell = (uint16_t)c16;
+  *out_cell = c16;
   __builtin_amdgcn_sched_barrier(0);
 }
 

@@ -135,7 +135,7 @@ template <bool POW2RES, typename Background>
 __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const uint16_t* __restrict__ cells16, char* fb,
                                                       int map_bytes, const float2* e2, const float2* u_src, int T,
                                                       int c, int lane, const float2* us_ready, bool rot_ok,
-                                                      Background&& background) {
+                                                      Background&& background, bool leave_when_idle = false) {
   constexpr int C = 8, R = ScanExactLds::R;
   using Ring = PipeRing<C>;
   const int Tp = (T + 7) & ~7;
@@ -179,9 +179,10 @@ __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const 
     //  cost terms of its group, which the cost wave waits for in front of its last walk -- fits into one of those gaps)
     const int bg_at = min(2, K);
     for (int k = 0; k <= K; ++k) {
+      MPPI_STAMP(stamp_wg && k == 5, stamp_base + 13);  // (stamps build: chunk 5 -- released, work done)
       if (k + 1 < K) produce(k + 1);
       if (k == bg_at) background();
-      MPPI_STAMP(stamp_wg && (k == 0 || k == 6), stamp_base + (k == 0 ? 13 : 14));
+      MPPI_STAMP(stamp_wg && k == 5, stamp_base + 14);
       __syncthreads();
     }
     MPPI_STAMP(stamp_wg, stamp_base + 15);
@@ -194,6 +195,7 @@ __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const 
     MPPI_STAMP(stamp_wg, stamp_base + 12);
     auto run = [&](auto check) {
       for (int k = 0; k <= K; ++k) {
+        MPPI_STAMP(stamp_wg && k == 5, stamp_base + 13);
         if (k < K) {
           constexpr bool CHK = decltype(check)::value != 0;
           const double2* in_qd = ring_qd + (size_t)(k & 1) * Ring::kHalf;
@@ -202,7 +204,7 @@ __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const 
           if (T - k * C >= C) pipe_state_chunk<C, POW2RES, CHK>(P, win, st, in_qd, out_xy, out_cell, lane);
           else pipe_state_tail<POW2RES, CHK>(P, win, st, in_qd, out_xy, out_cell, lane, T - k * C);
         }
-        MPPI_STAMP(stamp_wg && (k == 0 || k == 6), stamp_base + (k == 0 ? 13 : 14));
+        MPPI_STAMP(stamp_wg && k == 5, stamp_base + 14);
         __syncthreads();
       }
     };
@@ -217,7 +219,7 @@ __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const 
     __syncthreads();
     MPPI_STAMP(stamp_wg, stamp_base + 12);
     for (int k = 0; k <= K; ++k) {
-      MPPI_STAMP(stamp_wg && (k == 1 || k == 7), stamp_base + (k == 1 ? 13 : 14));
+      MPPI_STAMP(stamp_wg && k == 5, stamp_base + 13);
       if (k >= 1) {
         const int t0 = (k - 1) * C;
         const float2* in_xy = ring_xy + (size_t)((k - 1) & 1) * Ring::kHalf;
@@ -238,6 +240,7 @@ __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const 
           done = done || hit;
         }
       }
+      MPPI_STAMP(stamp_wg && k == 5, stamp_base + 14);
       __syncthreads();
     }
     MPPI_STAMP(stamp_wg, stamp_base + 15);
@@ -245,6 +248,11 @@ __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const 
   } else {
     __syncthreads();
     background();
+    // (direct mode: a wave with nothing left to do in this launch -- waves 4.. : phase F belongs to waves 2 and 3 --
+    //  leaves the kernel here instead of keeping the schedule's barrier count: a barrier waits for the waves that are
+    //  still alive, and with 16 of them a release took ~280 cycles after the last arrival against ~80 with 4: 200 cycles
+    //  in every chunk of the state wave's critical path)
+    if (leave_when_idle && c >= 4) __builtin_amdgcn_endpgm();
     for (int k = 0; k <= K; ++k) __syncthreads();
   }
   return cost;
@@ -935,7 +943,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     }
     const float cost = scan_exact_reexecute<POW2RES>(Q, cells16, base + fallback.offset, fallback.map_bytes, e2, uq, T, c, lane,
                                                      folded ? u_sh : (const float2*)nullptr, fallback.rot_ok != 0,
-                                                     [&]() { if (g >= 0) chunk_ccr(); });
+                                                     [&]() { if (g >= 0) chunk_ccr(); }, /*leave_when_idle=*/true);
     if (c == 1) {
       __builtin_amdgcn_s_setprio(3);
       finish_tile(cost);
