@@ -30,6 +30,7 @@
 
 using namespace mppi;
 
+#include <chrono>
 #include "host_common.h"
 #include "handles.h"
 
@@ -779,6 +780,26 @@ extern "C" int mppi_planner_iterate_async(mppi_planner* p, mppi_tdm* lin, mppi_t
   return run_iterations(p, lin, ang, iterations);
 }
 
+// Waiting for the planner's stream where a control loop waits for it (solve, synchronize): the first few hundred
+// microseconds by polling -- hipStreamSynchronize parks the thread, and being woken costs more than a 15 us iteration
+// (measured, tools/call_overhead.py: profiles/r05_call_overhead.txt) -- then the blocking call.
+// MPPI_SYNC_SPIN_US=0 switches the polling off.
+static int wait_for_stream(mppi_planner* p) {
+  static const long spin_us = getenv("MPPI_SYNC_SPIN_US") ? atol(getenv("MPPI_SYNC_SPIN_US")) : 400;
+  if (spin_us > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t e = hipStreamQuery(p->stream);
+      if (e == hipSuccess) return MPPI_OK;
+      if (e != hipErrorNotReady) HIP_TRY(e);
+      (void)hipGetLastError();  // (hipErrorNotReady is sticky in hipGetLastError)
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  return MPPI_OK;
+}
+
 // after the stream has drained: did a peer fail to deliver (update_kernels.h, exchange_step)?
 static int check_peer_fault(mppi_planner* p) {
   if (p->p2p_fault_host && *p->p2p_fault_host != 0u) {
@@ -812,7 +833,7 @@ static int check_fold_fault(mppi_planner* p) {
 extern "C" int mppi_planner_synchronize(mppi_planner* p) {
   REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
   HIP_TRY(hipSetDevice(p->cfg.device));
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  TRY(wait_for_stream(p));
   review_speculation(p);
   TRY(check_peer_fault(p));
   TRY(check_fold_fault(p));
@@ -878,7 +899,7 @@ extern "C" int mppi_planner_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang,
   // replayed graph has not: its launches are the loop's ordinary ones)
   if (p->params.num_opt < 1 || !p->mirror_done)
     HIP_TRY(hipMemcpyAsync(p->u_host, p->u, u_bytes, hipMemcpyDeviceToHost, p->stream));
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  TRY(wait_for_stream(p));
   review_speculation(p);
   TRY(check_peer_fault(p));
   TRY(check_fold_fault(p));
