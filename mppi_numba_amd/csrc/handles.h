@@ -131,6 +131,7 @@ struct mppi_planner {
   unsigned int* fold_fault_host = nullptr;  // pinned, device-mapped: a workgroup gave up waiting for a published step
   unsigned int* fold_fault_dev = nullptr;
   int fold_max_polls = 1 << 20;             // ... after this many polls (~a second)
+  long iterations_since_wait = 0;           // enqueued since the host last waited for the stream (wait_for_stream)
   bool fold_off = false;                    // ... after which this handle updates through launches of their own
   uint64_t fold_faults = 0;
   bool reduce_pending = false;  // the last launch's tile packets hold an update that the next rollout launch applies

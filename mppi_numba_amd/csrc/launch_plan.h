@@ -1521,6 +1521,7 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
   TRY(check_tdms(p, lin, ang));
   TRY(ensure_packed(p, lin, ang));
   DevParams d = make_dev_params(p, lin, ang);
+  p->iterations_since_wait += iterations;
   timed = timed || p->profile_stages;
   if (timed) HIP_TRY(hipEventRecord(p->ev_begin, p->stream));
   // The noise of iteration k+1 does not depend on iteration k.  When the pipelined rollout

@@ -780,13 +780,19 @@ extern "C" int mppi_planner_iterate_async(mppi_planner* p, mppi_tdm* lin, mppi_t
   return run_iterations(p, lin, ang, iterations);
 }
 
-// Waiting for the planner's stream where a control loop waits for it (solve, synchronize): the first few hundred
-// microseconds by polling -- hipStreamSynchronize parks the thread, and being woken costs more than a 15 us iteration
-// (measured, tools/call_overhead.py: profiles/r05_call_overhead.txt) -- then the blocking call.
-// MPPI_SYNC_SPIN_US=0 switches the polling off.
+// Waiting for the planner's stream where a control loop waits for it (solve, synchronize).  hipStreamSynchronize
+// waits actively for a short while and then parks the thread; being woken costs ~4 us (tools/call_overhead.py,
+// profiles/r05_call_overhead.txt: a call of 20 iterations 324 -> 315 us when the stream is polled instead).  Polling is
+// not free either: after a hipStreamQuery loop the next enqueue of this thread is ~2 us slower, and a wait as short as
+// one iteration never reaches the parking phase (tools/control_step_latency.py, control step blocking / polling:
+// num_opt = 1 40.6 / 43.7 us, 2: 57.3 / 61.6, 4: 97.1 / 97.3, 8: 162.7 / 161.5).  So: poll when four or more iterations
+// have been enqueued since the last wait (MPPI_SYNC_POLL_FROM), block otherwise.  MPPI_SYNC_SPIN_US=0: never poll.
 static int wait_for_stream(mppi_planner* p) {
   static const long spin_us = getenv("MPPI_SYNC_SPIN_US") ? atol(getenv("MPPI_SYNC_SPIN_US")) : 400;
-  if (spin_us > 0) {
+  static const long kPollFromIterations = getenv("MPPI_SYNC_POLL_FROM") ? atol(getenv("MPPI_SYNC_POLL_FROM")) : 4;
+  const bool long_wait = p->iterations_since_wait >= kPollFromIterations;
+  p->iterations_since_wait = 0;
+  if (spin_us > 0 && long_wait) {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
       const hipError_t e = hipStreamQuery(p->stream);
