@@ -160,8 +160,18 @@ __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const 
   }
   if (c < 3) __builtin_amdgcn_s_setprio(3);  // (the waves without a role may share a SIMD with one that has)
   float cost = 0.0f;
+  const double dt64 = (double)P.dt;
+  // Direct mode with enough waves: the FIRST chunk's controls come from eight of the waves without a role, one step
+  // each, side by side -- the producer alone needs ~1.3k cycles for a chunk (a cold loop body, eight 16-byte stores),
+  // and the state wave cannot take its first step before that chunk is there.
+  const bool first_chunk_by_helpers = us_ready != nullptr && (int)(blockDim.x >> 6) >= 3 + C;
+  if (first_chunk_by_helpers && c >= 3 && c < 3 + C) {
+    const int t = c - 3;  // (< Tp; past a very short horizon the noise rows hold zeros)
+    const float2 ut = us[t], e = e2[t * R + (r ^ (t & (R - 1)))];
+    ring_qd[t * 64 + lane] = make_double2(dt64 * (double)clip_f32(ut.x + e.x, P.v_lo, P.v_hi),
+                                          dt64 * (double)clip_f32(ut.y + e.y, P.w_lo, P.w_hi));
+  }
   if (c == 2) {  // ---- producer: {dt * v, dt * w} of chunk k + 1 while the state wave integrates chunk k
-    const double dt64 = (double)P.dt;
     auto produce = [&](int chunk) {
       double2* out_qd = ring_qd + (size_t)(chunk & 1) * Ring::kHalf;
 #pragma unroll
@@ -173,7 +183,7 @@ __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const 
       }
     };
     MPPI_STAMP(stamp_wg, stamp_base + 12);
-    produce(0);
+    if (!first_chunk_by_helpers) produce(0);
     __syncthreads();
     // (this wave reaches every barrier ~1k cycles before the state wave: what it still owes -- direct mode: the control-
     //  cost terms of its group, which the cost wave waits for in front of its last walk -- fits into one of those gaps)
@@ -213,7 +223,7 @@ __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const 
     MPPI_STAMP(stamp_wg, stamp_base + 15);
     __builtin_amdgcn_s_setprio(0);
   } else if (c == 1) {  // ---- cost: pipe_tile_body's role 1
-    const double dt64 = (double)P.dt, gt2 = (double)P.gt2;
+    const double gt2 = (double)P.gt2;
     double d2 = 1e9;
     bool done = false, reached = false;
     __syncthreads();
