@@ -872,10 +872,13 @@ __global__ __launch_bounds__(64) void k_debug_occupy(unsigned long long ticks, i
 extern "C" int mppi_debug_occupy_cus(int device, int workgroups, int milliseconds) {
   REQUIRE(workgroups >= 1 && workgroups <= 4096 && milliseconds >= 1 && milliseconds <= 2000, MPPI_ERR_INVALID, "bad argument");
   HIP_TRY(hipSetDevice(device));
-  static hipStream_t side = nullptr;  // (a test hook: one stream, never destroyed)
+  // a stream of another priority: the runtime maps streams of one priority onto a small pool of hardware queues,
+  // and two streams that share a queue run one after the other (measured: the planner's loop simply waited)
+  // (a test hook: one stream per device, never destroyed -- hipStreamDestroy waits for the stream's work)
+  static hipStream_t sides[64] = {};
+  REQUIRE(device >= 0 && device < 64, MPPI_ERR_INVALID, "device %d", device);
+  hipStream_t& side = sides[device];
   if (!side) {
-    // a stream of another priority: the runtime maps streams of one priority onto a small pool of hardware queues,
-    // and two streams that share a queue run one after the other (measured: the planner's loop simply waited)
     int least = 0, greatest = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
     HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, greatest));
