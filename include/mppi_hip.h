@@ -306,8 +306,11 @@ int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity)
 int mppi_planner_set_debug_flags(mppi_planner* p, int flags);
 /* How long a workgroup of a rollout launch polls for the controls its sibling workgroups publish inside the launch
  * (update folded into the next rollout launch: rollout_scan*_kernel.h) before it gives the launch up: `polls` of
- * ~0.3-1 us each (default 2^20, about a second; test hook).  After a give-up the next synchronising call returns
- * MPPI_ERR_BUSY and the handle stops folding (mppi_planner_fold_state: folding, faults so far). */
+ * ~0.3-1 us each (default 2^20, about a second; test hook).  After a give-up the next call that waits for the handle's
+ * stream -- synchronize, solve, and every stage-level call that returns data (get_u, get_costs, rollout, update ...) --
+ * returns MPPI_ERR_BUSY and the handle stops folding (mppi_planner_fold_state: folding, faults so far).  Calling
+ * mppi_planner_set_fold_poll_limit again re-arms the handle: it folds again (and gives up again if the device is still
+ * shared). */
 int mppi_planner_set_fold_poll_limit(mppi_planner* p, int polls);
 int mppi_planner_fold_state(mppi_planner* p, int* folding, long* faults);
 /* developer / test hook: occupy `workgroups` compute units of `device` (one workgroup each: 100 KiB of LDS) for

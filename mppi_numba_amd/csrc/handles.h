@@ -41,9 +41,30 @@ struct mppi_tdm {
   uint64_t sampled_epoch = 0;   // Philox epoch of the current draws
   bool injected = false;  // grids came from mppi_tdm_set_sampled_grids
   int8_t injected_max = 0, injected_min = 0;
+  // How many concentric rings of border cells carry ZERO traction in every grid a sampler can write (the padding ring of
+  // terrain.py:511-583: a rollout that enters it never moves again, so none leaves the map as long as a step is no longer
+  // than the ring is wide).  The exact schedule's state role computes its LDS address without a clamp only on maps where
+  // that -- or the reach bound -- proves the clamp idle (launch_plan.h: unclamped_lookup_ok); capped at kSinkRingCap.
+  static constexpr int kSinkRingCap = 16;
+  int maps_sink_ring = 0, injected_sink_ring = 0;
   // samples sharded over GPUs (mppi_tdm_set_sample_shard): this handle's G grids are samples
   // [first_sample, first_sample + G) of the unsharded set; even, a Philox block serves a pair
   int first_sample = 0;
+};
+
+// ---- k_rollout_scan / k_rollout_scan_exact: the launch geometry (launch_plan.h: scan_plan) --------
+struct ScanPlan {
+  int waves = 0;       // waves per workgroup: one per 8 steps (+ the three walkers of the exact kernel)
+  int chunk_waves = 0; // ... of which work on 8 steps each
+  int tile = 32;       // rollouts per workgroup: 32 (two lanes per rollout) or 64
+  size_t lds = 0;
+  bool pow2res = false;
+  bool exact = false;  // k_rollout_scan_exact: the three running sums walked with the reference's roundings
+  // k_rollout_scan_exact on a map the planner has stopped speculating on (round 5): every tile runs the exact
+  // three-wave schedule at once (ScanFallback::direct) -- noise, folded update and tile packets as ever, so the
+  // iteration stays one launch and the kernel family does not depend on the map
+  bool direct = false;
+  int fallback_offset = -1, fallback_map_bytes = 0, small_offset = 0;  // where the exact schedule's controls | window | ring and the small arrays live (direct)
 };
 
 // ---------------------------------------------------------------------------
@@ -164,6 +185,7 @@ struct mppi_planner {
   float2* obs_pos = nullptr;
   float* obs_r = nullptr;
   int n_obstacles = 0;
+  std::vector<float> obs_pos_host, obs_r_host;  // what the device arrays hold (mppi_planner_set_disc_obstacles)
   float* state_rollout = nullptr;  // [V][T+1][3]
   // host state
   mppi_params params;
@@ -187,6 +209,10 @@ struct mppi_planner {
   // synchronised anyway it compares that with the LAUNCHES it made (a launch lasts as long as its slowest
   // tile: one failing tile stalls it) and, from one failed tile per two launches on, stops speculating
   // until the packed map changes.
+  // scan_plan()'s answer for the state it was derived from (launch_plan.h)
+  std::vector<unsigned char> scan_key;
+  ScanPlan scan_cached;
+  bool scan_cached_ok = false;
   unsigned int* spec_fail_host = nullptr;  // pinned, device-mapped
   unsigned int* spec_fail_dev = nullptr;   // device view of the same word
   uint64_t spec_launches = 0;
@@ -230,6 +256,20 @@ struct mppi_planner {
   int* loop_done_count_dev = nullptr;  // device view of the same int
   int loop_capacity = 0;
 };
+
+// rings of cells, from the border inwards, for which sink(row, col) holds (see mppi_tdm::maps_sink_ring)
+template <typename F>
+static int count_sink_rings(int rows, int cols, F&& sink) {
+  int rings = 0;
+  for (; rings < mppi_tdm::kSinkRingCap && 2 * rings < rows && 2 * rings < cols; ++rings) {
+    const int r0 = rings, r1 = rows - 1 - rings, c0 = rings, c1 = cols - 1 - rings;
+    bool all = true;
+    for (int c = c0; c <= c1 && all; ++c) all = sink(r0, c) && sink(r1, c);
+    for (int r = r0; r <= r1 && all; ++r) all = sink(r, c0) && sink(r, c1);
+    if (!all) break;
+  }
+  return rings;
+}
 
 static void drop_graphs(mppi_planner* p) {
   for (int i = 0; i < mppi_planner::kGraphSlots; ++i) {

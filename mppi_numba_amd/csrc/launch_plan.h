@@ -302,6 +302,30 @@ static bool plan_lds_window(mppi_planner* p, DevParams& d, size_t* lds_bytes) {
   return true;
 }
 
+// The exact schedule's state role (rollout_kernels.h, PipeWindow<POW2RES = true>) forms its LDS address without the
+// [0, last] clamp -- one instruction per coordinate on the horizon's only dependent chain.  That is sound on a map no
+// rollout can leave: the reference's padded maps (a ring of zero-traction cells at least as wide as one step is long:
+// terrain.py:511-583 -- whoever enters it stays), or a reach square that lies strictly inside the map.  Anything else
+// (an mppi_tdm filled through the C API without such a ring, a window clipped by the border) takes the variant with the
+// exact floor division and the clamp, i.e. the border cell, like k_rollout_map and k_rollout_fused.
+static bool unclamped_lookup_ok(const mppi_planner* p, const DevParams& d) {
+  const mppi_params& a = p->params;
+  const mppi_tdm* lin = p->packed_lin;
+  const double vmax = std::fmax(std::fabs((double)a.vrange[0]), std::fabs((double)a.vrange[1]));
+  const double trmax = std::fmax(std::fabs(d.lin_lo), std::fabs(d.lin_lo + (double)d.lin_max_byte * d.lin_ratio));
+  const double step_cells = (double)a.dt * vmax * trmax / (double)a.res;
+  if (!std::isfinite(step_cells)) return false;
+  if (lin) {
+    const int ring = lin->injected ? lin->injected_sink_ring : lin->maps_sink_ring;
+    if ((double)ring >= std::ceil(step_cells + 1e-3)) return true;
+  }
+  if (p->inst_set) return false;  // (per-problem windows are shifted inwards at the border)
+  const double reach = std::ceil((double)p->cfg.num_steps * step_cells) + 2.0;
+  const double xi0 = std::floor(((double)a.x0[0] - (double)a.xlo) / (double)a.res);
+  const double yi0 = std::floor(((double)a.x0[1] - (double)a.ylo) / (double)a.res);
+  return yi0 - reach > 0.0 && yi0 + reach + 1.0 < (double)d.rows && xi0 - reach > 0.0 && xi0 + reach + 1.0 < (double)d.cols;
+}
+
 // Waves (tiles of 64 rollouts) per workgroup of the one-wave-per-tile kernels that keep the map
 // window in LDS.  The window makes it one workgroup per CU, so the workgroup is sized to cover
 // the problem in one round: at least 4 waves (one per SIMD, and enough lanes to copy the
@@ -345,19 +369,7 @@ static int upload_instances(mppi_planner* p) {
 // ---- k_rollout_scan (rollout_scan_kernel.h): the time-parallel rollout of MPPI_MATH_FAST --------
 // Eligible: deterministic-dynamics mode, 16-bit cells (the reference's own maps always are), a horizon
 // of at most 16 waves of 8 steps, LDS for the per-step records, and a map the speculation pays on.
-struct ScanPlan {
-  int waves = 0;       // waves per workgroup: one per 8 steps (+ the three walkers of the exact kernel)
-  int chunk_waves = 0; // ... of which work on 8 steps each
-  int tile = 32;       // rollouts per workgroup: 32 (two lanes per rollout) or 64
-  size_t lds = 0;
-  bool pow2res = false;
-  bool exact = false;  // k_rollout_scan_exact: the three running sums walked with the reference's roundings
-  // k_rollout_scan_exact on a map the planner has stopped speculating on (round 5): every tile runs the exact
-  // three-wave schedule at once (ScanFallback::direct) -- noise, folded update and tile packets as ever, so the
-  // iteration stays one launch and the kernel family does not depend on the map
-  bool direct = false;
-  int fallback_offset = -1, fallback_map_bytes = 0, small_offset = 0;  // where the exact schedule's controls | window | ring and the small arrays live (direct)
-};
+// (struct ScanPlan: handles.h -- the planner caches one)
 
 // Where k_rollout_scan_exact re-executes a tile on the exact schedule: in the LDS of the walks' groups and positions
 // (dead by then; unused in direct mode), or behind everything.  Returns the total LDS of the launch, 0: no room.
@@ -379,11 +391,43 @@ static size_t scan_fallback_place(const mppi_planner* p, const DevParams& d, int
   return 0;
 }
 
+static bool scan_plan_compute(const mppi_planner* p, ScanPlan* out);
+
+// scan_plan() is asked several times per iteration (which kernel runs, whether it generates its noise, whether the next
+// launch can take this one's update, whether the peer exchange is usable): the answer is cached on everything it is
+// derived from.  (Batched handles are planned afresh every time: their plan also rewrites the per-problem window origins.)
 static bool scan_plan(const mppi_planner* p, ScanPlan* out) {
+  struct Key {
+    mppi_params params;
+    const void *lin, *ang;
+    uint64_t lin_grid, ang_grid, lin_maps;
+    int debug_flags, speculation_off, cells16_valid, cells16_with_risk, params_set, pad;
+  } key;
+  if (p->inst_set) return scan_plan_compute(p, out);
+  memset(&key, 0, sizeof(key));
+  key.params = p->params;
+  key.lin = p->packed_lin; key.ang = p->packed_ang;
+  key.lin_grid = p->packed_lin_grid; key.ang_grid = p->packed_ang_grid; key.lin_maps = p->packed_lin_maps;
+  key.debug_flags = p->debug_flags; key.speculation_off = p->speculation_off; key.cells16_valid = p->cells16_valid;
+  key.cells16_with_risk = p->cells16_with_risk; key.params_set = p->params_set;
+  mppi_planner* q = const_cast<mppi_planner*>(p);  // (the cache only)
+  if (q->scan_key.size() != sizeof(key) || memcmp(q->scan_key.data(), &key, sizeof(key)) != 0) {
+    q->scan_cached_ok = scan_plan_compute(p, &q->scan_cached);
+    q->scan_key.assign(reinterpret_cast<const unsigned char*>(&key), reinterpret_cast<const unsigned char*>(&key) + sizeof(key));
+  }
+  if (q->scan_cached_ok && out) *out = q->scan_cached;
+  return q->scan_cached_ok;
+}
+
+static bool scan_plan_compute(const mppi_planner* p, ScanPlan* out) {
   static const bool disabled = getenv("MPPI_NO_SCAN") != nullptr;  // developer switch (ablation)
   if (disabled || (p->debug_flags & MPPI_DEBUG_NO_SCAN_KERNEL)) return false;
-  if (p->cfg.mode != MPPI_MODE_DET) return false;
-  if (!p->cells16_valid || p->cells16_with_risk) return false;
+  // (round 6) the speed-map mode too: its dynamics run on nominal traction -- the walks' assumption by construction --
+  // and the risk byte comes with the (32-bit) cell; exact arithmetic only, no direct form (rollout_scan_exact_kernel.h)
+  const bool speed = p->cfg.mode == MPPI_MODE_SPEED_MAP;
+  if (p->cfg.mode != MPPI_MODE_DET && !speed) return false;
+  if (!p->cells16_valid || p->cells16_with_risk != speed) return false;
+  if (speed && p->cfg.math != MPPI_MATH_EXACT) return false;
   // (MPPI_DEBUG_NO_SPECULATION: "the speculative kernels on their exact schedule from the first step" -- for this kernel
   //  that is the direct launch, whatever the map has shown so far: how the tests reach it on any map)
   const bool stopped = p->speculation_off && !(p->debug_flags & MPPI_DEBUG_KEEP_SPECULATING);
@@ -391,7 +435,7 @@ static bool scan_plan(const mppi_planner* p, ScanPlan* out) {
   const bool direct = (stopped || (p->debug_flags & MPPI_DEBUG_NO_SPECULATION)) && p->cfg.math == MPPI_MATH_EXACT;
   static const bool no_direct = getenv("MPPI_NO_SCAN_DIRECT") != nullptr;  // developer switch (ablation): k_rollout_pipe as in round 4
   if (direct && (no_direct || (p->debug_flags & MPPI_DEBUG_NO_SCAN_DIRECT) || p->cfg.math != MPPI_MATH_EXACT ||
-                 !p->packed_lin || !p->packed_ang))
+                 !p->packed_lin || !p->packed_ang || speed))
     return false;
   const int T = p->cfg.num_steps;
   ScanPlan plan;
@@ -413,10 +457,15 @@ static bool scan_plan(const mppi_planner* p, ScanPlan* out) {
   if (plan.lds > (size_t)p->lds_per_cu - 1024) return false;
   int res_exp = 0;
   plan.pow2res = std::frexp((double)p->params.res, &res_exp) == 0.5;  // res == 2^k exactly
+  // (the template flag also selects the unclamped address of the exact schedule inside the kernel -- direct launches
+  //  and re-executed tiles: only where no rollout can leave the map)
+  const DevParams d0 = make_dev_params(p, p->packed_lin, p->packed_ang);
+  // (the speed-map form has no exact schedule inside: its lookups all clamp)
+  plan.pow2res = plan.pow2res && (speed || (p->packed_lin && unclamped_lookup_ok(p, d0)));
   if (plan.direct) {
     // the exact schedule needs the 16-bit window of the cells reachable within the horizon in LDS, next to the noise,
     // and the exact-increment rotation (|dt * w * traction| <= 0.36 rad): else k_rollout_pipe / the general kernels
-    DevParams d = make_dev_params(p, p->packed_lin, p->packed_ang);
+    DevParams d = d0;
     size_t lds_win = 0;
     // (a batched handle's per-problem window origins are recomputed into its host mirror: the values launch_rollout_det
     //  computes from the same start states -- idempotent)
@@ -488,6 +537,8 @@ static bool tiles_can_reduce(int tiles, int n_steps) { return 4 * tiles >= n_ste
 static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan_in, bool have_window) {
   ScanPlan plan = plan_in;
   const int N = p->n_local, T = p->cfg.num_steps;
+  const bool speed = p->cfg.mode == MPPI_MODE_SPEED_MAP;
+  REQUIRE(!speed || (plan.exact && !plan.direct), MPPI_ERR_STATE, "internal: speed-map mode on a kernel that does not serve it");
   const int tiles = ceil_div(N, plan.tile);
   REQUIRE(p->tile_packets[0] && p->tile_packets[1], MPPI_ERR_STATE, "internal: no tile packet buffers on this handle");
   const bool gen = p->scan_gen_now;
@@ -561,18 +612,20 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
     fallback.map_bytes = plan.fallback_map_bytes;
     fallback.small_offset = plan.small_offset;
     fallback.direct = 1;
-  } else if (plan.exact && have_window && !no_fast_fallback) {
+  } else if (plan.exact && have_window && !no_fast_fallback && !speed) {  // (speed-map: 32-bit cells, no exact schedule inside)
     const size_t lds = scan_fallback_place(p, d, plan.chunk_waves, plan.lds, &fallback.offset, &fallback.map_bytes);
     if (lds) plan.lds = lds;
   }
 #define MPPI_LAUNCH_SCAN_EXACT(P2, GEN)                                                                    \
   do {                                                                                                    \
-    auto kern = plan.direct ? k_rollout_scan_exact<P2, GEN, true> : k_rollout_scan_exact<P2, GEN, false>; \
+    auto kern = speed ? k_rollout_scan_exact<P2, GEN, false, true>                                        \
+                      : (plan.direct ? k_rollout_scan_exact<P2, GEN, true> : k_rollout_scan_exact<P2, GEN, false>); \
     if (plan.lds > 64 * 1024)                                                                             \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));            \
     MPPI_KLAUNCH(kern, dim3(tiles), dim3(64 * plan.waves), plan.lds, p->stream, d, p->cells16, p->cells,  \
-                 p->noise, gen_job, p->u, p->costs, p->w_rel, pk, pend, fallback);                         \
+                 p->noise, gen_job, p->u, p->costs, p->w_rel, pk, pend, fallback,                          \
+                 (const int8_t*)(speed ? p->risk_ref : nullptr));                                          \
   } while (0)
 #define MPPI_LAUNCH_SCAN(RR, P2, GEN)                                                                      \
   do {                                                                                                    \
@@ -617,7 +670,7 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
   char buf[384];
   snprintf(buf, sizeof(buf),
            "k_rollout_scan%s tile=%d waves=%d pow2res=%d noise=%s lds=%zu noise_blocks=%d problems=%d%s%s",
-           plan.exact ? "_exact" : "", plan.tile, plan.waves, (int)plan.pow2res, gen ? "in-kernel" : "read", plan.lds, extra,
+           plan.exact ? (speed ? "_exact speed_map" : "_exact") : "", plan.tile, plan.waves, (int)plan.pow2res, gen ? "in-kernel" : "read", plan.lds, extra,
            p->inst_set ? p->B : 0, !plan.exact ? "" : (plan.direct ? " direct=1 (exact three-wave schedule, no speculation)" : (fallback.offset >= 0 ? " failed_tiles=pipelined" : " failed_tiles=one_wave")), applied_here ? (pend.reduce_tiles ? " applies_update=1 reduces_tiles=1" : " applies_update=1") : "");
   p->last_rollout = buf;
   p->tile_packets_fresh = false;  // (w_rel is relative to this kernel's own tiles: tbeta, not tile_beta)
@@ -642,6 +695,7 @@ struct DetRegime {
   size_t lds_win;         // ... bytes of {staged controls, window}
   bool rot_ok;            // incremental trig applies (|dt*w*traction| <= 0.36 rad, T <= 2000, exact math)
   bool pow2res;           // resolution is a power of two: four-instruction cell coordinates
+  bool pow2res_unclamped; // ... and no rollout can leave the map: the exact schedule's address without a clamp (unclamped_lookup_ok)
   bool rot_ok_fast;       // ... the same bound under MPPI_MATH_FAST (k_rollout_fused<one pass>)
   bool fast_deep_ok;      // MPPI_MATH_FAST: |theta| stays inside v_sin_f32's range
   bool keep_speculating;  // the map has not (yet) proved the traction assumption a loss
@@ -651,7 +705,7 @@ template <bool EXACT>
 static int try_launch_deep(mppi_planner* p, DevParams& d, const DetRegime& r, bool* launched) {
   *launched = false;
   const int N = p->n_local, T = p->cfg.num_steps;
-  [[maybe_unused]] const bool have_window = r.have_window, rot_ok = r.rot_ok, pow2res = r.pow2res,
+  [[maybe_unused]] const bool have_window = r.have_window, rot_ok = r.rot_ok, pow2res = r.pow2res_unclamped,
                               fast_deep_ok = r.fast_deep_ok, keep_speculating = r.keep_speculating;
   [[maybe_unused]] const size_t lds_win = r.lds_win;
   static const bool no_pipe = getenv("MPPI_NO_PIPE") != nullptr;  // developer switch (ablation)
@@ -739,7 +793,7 @@ template <bool EXACT>
 static int try_launch_spec(mppi_planner* p, DevParams& d, const DetRegime& r, bool* launched) {
   *launched = false;
   const int N = p->n_local, T = p->cfg.num_steps;
-  [[maybe_unused]] const bool have_window = r.have_window, rot_ok = r.rot_ok, pow2res = r.pow2res,
+  [[maybe_unused]] const bool have_window = r.have_window, rot_ok = r.rot_ok, pow2res = r.pow2res_unclamped,
                               fast_deep_ok = r.fast_deep_ok, keep_speculating = r.keep_speculating;
   [[maybe_unused]] const size_t lds_win = r.lds_win;
   static const bool no_pipe = getenv("MPPI_NO_PIPE") != nullptr;  // developer switch (ablation)
@@ -830,7 +884,7 @@ template <bool EXACT>
 static int try_launch_pipe(mppi_planner* p, DevParams& d, const DetRegime& r, bool* launched) {
   *launched = false;
   const int N = p->n_local, T = p->cfg.num_steps;
-  [[maybe_unused]] const bool have_window = r.have_window, rot_ok = r.rot_ok, pow2res = r.pow2res,
+  [[maybe_unused]] const bool have_window = r.have_window, rot_ok = r.rot_ok, pow2res = r.pow2res_unclamped,
                               fast_deep_ok = r.fast_deep_ok, keep_speculating = r.keep_speculating;
   [[maybe_unused]] const size_t lds_win = r.lds_win;
   static const bool no_pipe = getenv("MPPI_NO_PIPE") != nullptr;  // developer switch (ablation)
@@ -1009,6 +1063,7 @@ static int launch_rollout_det(mppi_planner* p, DevParams d) {
   const bool keep_speculating = !p->speculation_off || (p->debug_flags & MPPI_DEBUG_KEEP_SPECULATING);
   DetRegime r;
   r.have_window = have_window; r.lds_win = lds_win; r.rot_ok = rot_ok; r.rot_ok_fast = rot_ok_fast; r.pow2res = pow2res;
+  r.pow2res_unclamped = pow2res && unclamped_lookup_ok(p, d);
   r.fast_deep_ok = fast_deep_ok; r.keep_speculating = keep_speculating;
   bool launched = false;
   TRY(try_launch_deep<EXACT>(p, d, r, &launched));
@@ -1029,6 +1084,14 @@ static int launch_rollout_speed_map(mppi_planner* p, DevParams d) {
   size_t lds_win = 0;
   const bool have_window = plan_lds_window(p, d, &lds_win);  // 32-bit cells: 16 bits + risk byte
   TRY(upload_instances(p));
+  {
+    // latency regime (every tile of 32 rollouts a CU, T <= 104): the time-parallel kernel, one launch per iteration
+    ScanPlan plan;
+    if (scan_plan(p, &plan)) {
+      d.pitch16 = p->pitch16;
+      return launch_scan(p, d, plan, have_window);
+    }
+  }
   const mppi_params& a = p->params;
   double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
   double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
@@ -1158,7 +1221,7 @@ static int launch_rollout(mppi_planner* p, const DevParams& d) {
   REQUIRE((size_t)p->cfg.num_steps * sizeof(double2) <= 64 * 1024, MPPI_ERR_INVALID, "num_steps %d too large",
           p->cfg.num_steps);
   // an update left to its consumer (launch_update) and a rollout kernel that will not take it
-  if (p->apply_pending && !(p->cfg.mode == MPPI_MODE_DET && scan_plan(p, nullptr))) TRY(launch_apply(p));
+  if (p->apply_pending && !(p->cfg.mode == MPPI_MODE_DET && scan_plan(p, nullptr))) TRY(launch_apply(p));  // (sharded updates fold in deterministic-dynamics mode only)
   if (p->reduce_pending && !next_rollout_reduces_tiles(p)) TRY(settle_reduce_pending(p));
   // |theta| can never exceed |theta0| + T*dt*max|w|*max(traction): when that is far
   // inside the range of the two-term pi/2 reduction, the kernels drop the libm branch
@@ -1315,7 +1378,8 @@ static bool next_rollout_reduces_tiles(const mppi_planner* p) {
   static const bool disabled = getenv("MPPI_NO_REDUCE_FOLD") != nullptr;  // developer switch (ablation)
   ScanPlan plan;
   return !disabled && !p->fold_off && !(p->debug_flags & (MPPI_DEBUG_NO_FOLDED_APPLY | MPPI_DEBUG_NO_REDUCE_FOLD)) && p->B == 1 && !p->inst_set &&
-         p->m_count == 1 && ((p->cfg.world_size == 1 && !p->comm) || p2p_usable(p)) && p->cfg.mode == MPPI_MODE_DET && !p->mirror_now &&
+         p->m_count == 1 && ((p->cfg.world_size == 1 && !p->comm) || p2p_usable(p)) &&
+         (p->cfg.mode == MPPI_MODE_DET || p->cfg.mode == MPPI_MODE_SPEED_MAP) && !p->mirror_now &&
          scan_plan(p, &plan) && plan.tile == p->scan_tile &&
          tiles_can_reduce(ceil_div(p->n_local, plan.tile), p->cfg.num_steps);
 }
@@ -1391,7 +1455,13 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
     want_next = false;
   } else if (have_noise) {
     p->noise_cur ^= 1;
-    if (p->noise_on_side_stream) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_noise_ready, 0));
+    if (p->noise_on_side_stream) {
+      HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_noise_ready, 0));
+      if (p->ktime_index >= 0) {  // (see k_absorb_wait: the timed launch must not be the first dispatch behind the wait)
+        hipLaunchKernelGGL(k_absorb_wait, dim3(1), dim3(64), 0, p->stream);
+        HIP_TRY(hipGetLastError());
+      }
+    }
     p->noise_on_side_stream = false;
     p->noise_virtual = false;
   } else {
@@ -1515,14 +1585,17 @@ static void review_speculation(mppi_planner* p) {
   p->spec_launches = 0;
 }
 
+// `part_of_group_loop` (mppi_group_iterate_async's round robin over devices): this call is one turn of a longer loop
+// on this handle -- `more_follow`: further turns come, so the last iteration of this one may leave its update to the
+// next turn's first rollout launch like any other iteration -- and the loop's events belong to the caller.
 static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int iterations, bool timed = true,
-                          bool mirror_last = false) {
+                          bool mirror_last = false, bool part_of_group_loop = false, bool more_follow = false) {
   REQUIRE(p->params_set, MPPI_ERR_STATE, "params not set");
   TRY(check_tdms(p, lin, ang));
   TRY(ensure_packed(p, lin, ang));
   DevParams d = make_dev_params(p, lin, ang);
   p->iterations_since_wait += iterations;
-  timed = timed || p->profile_stages;
+  timed = (timed || p->profile_stages) && !part_of_group_loop;
   if (timed) HIP_TRY(hipEventRecord(p->ev_begin, p->stream));
   // The noise of iteration k+1 does not depend on iteration k.  When the pipelined rollout
   // kernel runs, its spare workgroups generate it into the other half of the double buffer
@@ -1537,9 +1610,9 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
     bool have_noise = p->primed;
     for (int k = 0; k < iterations; ++k) {
       // profiled iteration: a steady-state one when there is one, else the last
-      bool prof = p->profile_stages && k == (iterations >= 3 ? iterations - 2 : iterations - 1);
+      bool prof = p->profile_stages && !part_of_group_loop && k == (iterations >= 3 ? iterations - 2 : iterations - 1);
       p->mirror_now = mirror_last && k == iterations - 1;
-      const int rc = launch_iteration(p, d, have_noise, true, prof, false, k + 1 < iterations);
+      const int rc = launch_iteration(p, d, have_noise, true, prof, false, k + 1 < iterations || more_follow);
       p->mirror_now = false;
       TRY(rc);
     }

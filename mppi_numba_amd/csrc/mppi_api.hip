@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -72,8 +73,22 @@ extern "C" int mppi_device_props_get(int device, mppi_device_props* out) {
 }
 
 
+// live planners of this process: a planner remembers which TDMs its cell words were packed from (packed_lin / packed_ang,
+// dereferenced again by scan_plan); a TDM that goes away takes those notes with it
+static std::vector<mppi_planner*> g_planners;
+static std::mutex g_planners_mutex;  // (handles are single-threaded each; the registry is shared)
+
 extern "C" int mppi_tdm_destroy(mppi_tdm* t) {
   if (!t) return MPPI_OK;
+  {
+    std::lock_guard<std::mutex> lock(g_planners_mutex);
+    for (mppi_planner* p : g_planners) {
+      if (p->packed_lin == t || p->packed_ang == t) {
+        p->packed_lin = p->packed_ang = nullptr;
+        p->packed_lin_grid = p->packed_ang_grid = p->packed_lin_maps = ~0ULL;
+      }
+    }
+  }
   (void)hipSetDevice(t->cfg.device);
   dev_free(t->grid);
   dev_free(t->pmf);
@@ -176,6 +191,13 @@ extern "C" int mppi_tdm_set_maps(mppi_tdm* t, const int8_t* pmf, int bins, int r
   t->compact_ok = compact;
   t->table_max = -128;
   for (int b = 0; b < bins; ++b) t->table_max = std::max(t->table_max, (int)bin_to_int8[b]);
+  // border cells whose whole mass sits in a bin of zero traction: every sample of them is a sink
+  t->maps_sink_ring = count_sink_rings(rows, cols, [&](int r, int c) {
+    const size_t cell = (size_t)r * cols + c;
+    for (int b = 0; b < bins; ++b)
+      if (pmf[(size_t)b * plane + cell] == 100) return std::fma(traction_ratio, (double)bin_to_int8[b], traction_lo) == 0.0;
+    return false;
+  });
   t->one_hot = one_hot;
   t->bins = bins;
   t->rows = rows;
@@ -184,6 +206,7 @@ extern "C" int mppi_tdm_set_maps(mppi_tdm* t, const int8_t* pmf, int bins, int r
   t->lo = traction_lo;
   t->ratio = traction_ratio;
   t->maps_set = true;
+  t->injected_sink_ring = 0;  // (judged with the old traction bounds)
   ++t->maps_version;
   return MPPI_OK;
 }
@@ -284,6 +307,9 @@ extern "C" int mppi_tdm_set_maps_from_pmf(mppi_tdm* t, int kind, const int8_t* p
     t->table_max = std::max(t->table_max, (int)bin_to_int8[b]);
   }
   t->compact_ok = compact;
+  // (the ring k_prepare_maps writes: all mass in bin 0)
+  t->maps_sink_ring = std::fma(traction_ratio, (double)bin_to_int8[0], traction_lo) == 0.0
+                          ? std::min(pad_cells, (int)mppi_tdm::kSinkRingCap) : 0;
   t->one_hot = (kind != PREP_TDM) || flags[1] == 0;
   t->bins = bins;
   t->rows = rows;
@@ -292,6 +318,7 @@ extern "C" int mppi_tdm_set_maps_from_pmf(mppi_tdm* t, int kind, const int8_t* p
   t->lo = traction_lo;
   t->ratio = traction_ratio;
   t->maps_set = true;
+  t->injected_sink_ring = 0;  // (judged with the old traction bounds)
   ++t->maps_version;
   return MPPI_OK;
 }
@@ -414,6 +441,11 @@ extern "C" int mppi_tdm_set_sampled_grids(mppi_tdm* t, const int8_t* grids, int 
     if (grids[i] < t->injected_min) t->injected_min = grids[i];
     if (grids[i] > t->injected_max) t->injected_max = grids[i];
   }
+  t->injected_sink_ring = (!t->maps_set || rows != t->rows || cols != t->cols) ? 0 : count_sink_rings(rows, cols, [&](int r, int c) {
+    for (int g = 0; g < t->cfg.num_grids; ++g)
+      if (std::fma(t->ratio, (double)grids[((size_t)g * rows + r) * cols + c], t->lo) != 0.0) return false;
+    return true;
+  });
   ++t->grid_version;
   t->sampled_maps_version = ~0ULL;  // injected grids are not a cached sample
   t->grid_stale = false;             // (a lazy sample, if any, is superseded)
@@ -459,6 +491,10 @@ extern "C" int mppi_comm_unique_id(char id[MPPI_COMM_ID_BYTES]) {
 
 extern "C" int mppi_planner_destroy(mppi_planner* p) {
   if (!p) return MPPI_OK;
+  {
+    std::lock_guard<std::mutex> lock(g_planners_mutex);
+    g_planners.erase(std::remove(g_planners.begin(), g_planners.end(), p), g_planners.end());
+  }
   (void)hipSetDevice(p->cfg.device);
   if (p->stream) (void)hipStreamSynchronize(p->stream);
   if (p->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(p->comm);
@@ -562,7 +598,7 @@ static int planner_alloc(mppi_planner* p) {
   TRY(dev_alloc(&p->w_rel, N));
   TRY(dev_alloc(&p->tile_beta, (size_t)p->n_tiles));
   TRY(dev_alloc(&p->packets, (size_t)c.world_size * B * packet_len((int)T)));
-  if (c.mode == MPPI_MODE_DET) {  // the time-parallel kernels' tile packets (handles.h)
+  if (c.mode == MPPI_MODE_DET || c.mode == MPPI_MODE_SPEED_MAP) {  // the time-parallel kernels' tile packets (handles.h)
     const size_t tiles = (size_t)ceil_div((long)N, 32);
     for (int b = 0; b < 2; ++b) {
       TRY(dev_alloc(&p->tile_packets[b], tiles * (size_t)tile_packet_floats((int)T)));
@@ -652,6 +688,10 @@ extern "C" int mppi_planner_create(const mppi_planner_cfg* cfg, mppi_planner** o
     g_last_error = keep;
     return rc;
   }
+  {
+    std::lock_guard<std::mutex> lock(g_planners_mutex);
+    g_planners.push_back(p);
+  }
   *out = p;
   return MPPI_OK;
 }
@@ -689,25 +729,41 @@ extern "C" int mppi_planner_set_disc_obstacles(mppi_planner* p, const float* pos
                                                int count) {
   REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
   REQUIRE(count >= 0 && (count == 0 || (positions && radii)), MPPI_ERR_INVALID, "bad obstacle arrays");
+  // the barebone mirror hands the obstacles over with every solve() (the notebook uploads them per call,
+  // barebone_mppi_numba.ipynb cell 3): unchanged discs cost a comparison, not a synchronisation and two allocations
+  if (count == p->n_obstacles && (size_t)count * 2 == p->obs_pos_host.size() &&
+      (count == 0 || (memcmp(positions, p->obs_pos_host.data(), sizeof(float) * 2 * (size_t)count) == 0 &&
+                      memcmp(radii, p->obs_r_host.data(), sizeof(float) * (size_t)count) == 0)))
+    return MPPI_OK;
   HIP_TRY(hipSetDevice(p->cfg.device));
   HIP_TRY(hipStreamSynchronize(p->stream));
   dev_free(p->obs_pos);
   dev_free(p->obs_r);
-  p->n_obstacles = count;
+  p->n_obstacles = 0;
+  p->obs_pos_host.clear();
+  p->obs_r_host.clear();
   if (count > 0) {
     TRY(dev_alloc(&p->obs_pos, (size_t)count));
     TRY(dev_alloc(&p->obs_r, (size_t)count));
     HIP_TRY(hipMemcpy(p->obs_pos, positions, sizeof(float2) * (size_t)count, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(p->obs_r, radii, sizeof(float) * (size_t)count, hipMemcpyHostToDevice));
+    p->obs_pos_host.assign(positions, positions + 2 * (size_t)count);
+    p->obs_r_host.assign(radii, radii + (size_t)count);
   }
+  p->n_obstacles = count;
+  drop_graphs(p);  // (the count is a by-value argument of the captured launches)
   return MPPI_OK;
 }
+
+// Every entry point that waits for the planner's stream does it through this: the wait itself, then the words the
+// kernels of the drained launches may have raised -- a peer whose numbers did not arrive (MPPI_ERR_COMM), a rollout
+// launch that gave the hand-over of the controls up (MPPI_ERR_BUSY; include/mppi_hip.h: "the next synchronising call").
+static int drain_stream(mppi_planner* p);
 
 static int copy_out(mppi_planner* p, void* dst, const void* src, size_t bytes) {
   HIP_TRY(hipSetDevice(p->cfg.device));
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, p->stream));
-  HIP_TRY(hipStreamSynchronize(p->stream));
-  return MPPI_OK;
+  return drain_stream(p);
 }
 
 extern "C" int mppi_planner_set_u(mppi_planner* p, const float* u) {
@@ -836,13 +892,25 @@ static int check_fold_fault(mppi_planner* p) {
   return MPPI_OK;
 }
 
+// what follows every wait for the stream (the wait itself: wait_for_stream on the control path, else drain_stream)
+static int after_drain(mppi_planner* p, bool review = true) {
+  if (review) review_speculation(p);  // (the control loop's waits: is speculating on this map paying?)
+  TRY(check_peer_fault(p));
+  TRY(check_fold_fault(p));
+  return MPPI_OK;
+}
+
+static int drain_stream(mppi_planner* p) {
+  HIP_TRY(hipStreamSynchronize(p->stream));
+  p->iterations_since_wait = 0;
+  return after_drain(p, /*review=*/false);
+}
+
 extern "C" int mppi_planner_synchronize(mppi_planner* p) {
   REQUIRE(p, MPPI_ERR_INVALID, "NULL planner");
   HIP_TRY(hipSetDevice(p->cfg.device));
   TRY(wait_for_stream(p));
-  review_speculation(p);
-  TRY(check_peer_fault(p));
-  TRY(check_fold_fault(p));
+  TRY(after_drain(p));
   return finish_timing(p);
 }
 
@@ -850,6 +918,9 @@ extern "C" int mppi_planner_set_fold_poll_limit(mppi_planner* p, int polls) {
   REQUIRE(p && polls >= 1, MPPI_ERR_INVALID, "bad argument");
   p->fold_max_polls = polls;
   drop_graphs(p);  // (a by-value argument of the captured launches)
+  // ... and the handle folds its updates into rollout launches again: one co-tenant that held CUs for a moment need not
+  // cost a handle the one-launch iteration for the rest of its life (a device that is still shared raises the fault again)
+  p->fold_off = false;
   return MPPI_OK;
 }
 
@@ -909,9 +980,7 @@ extern "C" int mppi_planner_solve(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang,
   if (p->params.num_opt < 1 || !p->mirror_done)
     HIP_TRY(hipMemcpyAsync(p->u_host, p->u, u_bytes, hipMemcpyDeviceToHost, p->stream));
   TRY(wait_for_stream(p));
-  review_speculation(p);
-  TRY(check_peer_fault(p));
-  TRY(check_fold_fault(p));
+  TRY(after_drain(p));
   memcpy(u_out, p->u_host, u_bytes);
   return finish_timing(p);
 }
@@ -1152,7 +1221,7 @@ extern "C" int mppi_planner_closed_loop(mppi_planner* p, mppi_tdm* lin, mppi_tdm
   HIP_TRY(hipMemcpyAsync(done.data(), p->loop_done, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, p->stream));
   // the per-problem records the step kernel has been writing: bring the host mirror up to date
   HIP_TRY(hipMemcpyAsync(p->inst_host.data(), p->inst_dev, sizeof(BatchInst) * (size_t)B, hipMemcpyDeviceToHost, p->stream));
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  TRY(drain_stream(p));
   p->inst_dirty = false;
   for (int b = 0; b < B; ++b) steps_taken[b] = done[b] ? done[b] : launched;
   return finish_timing(p);
@@ -1172,12 +1241,12 @@ extern "C" int mppi_planner_sample_noise(mppi_planner* p) {
     p->noise = p->noise_buf[p->noise_cur];
     p->primed = false;
     p->noise_virtual = false;
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    TRY(drain_stream(p));
     return MPPI_OK;
   }
   p->noise_virtual = false;
   TRY(launch_noise(p, p->noise));
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  TRY(drain_stream(p));
   return MPPI_OK;
 }
 
@@ -1190,7 +1259,7 @@ extern "C" int mppi_planner_set_noise(mppi_planner* p, const float* noise) {
   hipLaunchKernelGGL(k_noise_to_device_layout, dim3(ceil_div((long)count, 256)), dim3(256), 0, p->stream,
                      p->staging, p->n_local, p->cfg.num_steps, p->noise);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  TRY(drain_stream(p));
   return MPPI_OK;
 }
 
@@ -1203,7 +1272,7 @@ extern "C" int mppi_planner_get_noise(mppi_planner* p, float* noise) {
                      p->n_local, p->cfg.num_steps, p->staging);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(noise, p->staging, count * sizeof(float2), hipMemcpyDeviceToHost, p->stream));
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  TRY(drain_stream(p));
   return MPPI_OK;
 }
 
@@ -1222,7 +1291,7 @@ extern "C" int mppi_planner_rollout(mppi_planner* p, mppi_tdm* lin, mppi_tdm* an
     if (p->comm) TRY(exchange_sample_costs(p));
     else p->sample_costs_local_only = true;
   }
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  TRY(drain_stream(p));
   return MPPI_OK;
 }
 
@@ -1233,7 +1302,7 @@ extern "C" int mppi_planner_set_costs(mppi_planner* p, const float* costs) {
   p->tile_packets_fresh = false;
   p->scan_packets_fresh = false;
   p->sample_costs_local_only = false;
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  TRY(drain_stream(p));
   return MPPI_OK;
 }
 
@@ -1269,7 +1338,7 @@ extern "C" int mppi_planner_set_sample_sharding(mppi_planner* p, int rank, int c
           "the communicator was created for another shard layout");
   HIP_TRY(hipSetDevice(p->cfg.device));
   if (count != p->m_count) {
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    TRY(drain_stream(p));
     dev_free(p->slabs);
     dev_free(p->sample_costs);
     drop_graphs(p);
@@ -1296,7 +1365,7 @@ extern "C" int mppi_planner_sample_costs_apply(mppi_planner* p, const float* sla
   const size_t len = (size_t)p->n_local * p->cfg.num_grid_samples;
   HIP_TRY(hipMemcpyAsync(p->slabs, slabs, sizeof(float) * len * (size_t)count, hipMemcpyHostToDevice, p->stream));
   TRY(launch_cvar_reduce(p));
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  TRY(drain_stream(p));
   return MPPI_OK;
 }
 
@@ -1308,7 +1377,7 @@ extern "C" int mppi_planner_update(mppi_planner* p) {
           "them first (mppi_planner_sample_costs_local / _apply, or a communicator)", p->m_count);
   HIP_TRY(hipSetDevice(p->cfg.device));
   TRY(launch_update(p, false));
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  TRY(drain_stream(p));
   return MPPI_OK;
 }
 
@@ -1327,7 +1396,7 @@ extern "C" int mppi_planner_update_local(mppi_planner* p, double* packet) {
   const int len = p->B * packet_len(p->cfg.num_steps);
   HIP_TRY(hipMemcpyAsync(packet, p->packets + (size_t)p->cfg.rank * len, sizeof(double) * (size_t)len,
                          hipMemcpyDeviceToHost, p->stream));
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  TRY(drain_stream(p));
   return MPPI_OK;
 }
 
@@ -1339,7 +1408,7 @@ extern "C" int mppi_planner_update_apply(mppi_planner* p, const double* packets,
   HIP_TRY(hipMemcpyAsync(p->packets, packets, sizeof(double) * (size_t)len * (size_t)count,
                          hipMemcpyHostToDevice, p->stream));
   TRY(launch_apply(p));
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  TRY(drain_stream(p));
   return MPPI_OK;
 }
 
@@ -1367,7 +1436,7 @@ extern "C" int mppi_planner_update_apply_and_rollout(mppi_planner* p, const doub
     if (rc == MPPI_OK) TRY(ra);
   }
   TRY(rc);
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  TRY(drain_stream(p));
   return MPPI_OK;
 }
 
@@ -1474,7 +1543,7 @@ extern "C" int mppi_planner_time_kernels(mppi_planner* p, mppi_tdm* lin, mppi_td
   p->ktime_index = -1;
   p->kev_start = p->kev_stop = nullptr;
   TRY(rc);
-  HIP_TRY(hipStreamSynchronize(p->stream));
+  TRY(drain_stream(p));
   double sum[2] = {0.0, 0.0};
   for (int r = 0; r < reps; ++r)
     for (int k = 0; k < 2; ++k) {
@@ -1701,7 +1770,8 @@ extern "C" int mppi_group_iterate_async(mppi_planner** ps, mppi_tdm** lins, mppi
       for (int k = 0; k < iterations; k += kTurn)
         for (int g = 0; g < count; ++g) {
           HIP_TRY(hipSetDevice(ps[g]->cfg.device));
-          TRY(run_iterations(ps[g], lins[g], angs[g], std::min(kTurn, iterations - k), /*timed=*/false));
+          TRY(run_iterations(ps[g], lins[g], angs[g], std::min(kTurn, iterations - k), /*timed=*/false, /*mirror_last=*/false,
+                             /*part_of_group_loop=*/true, /*more_follow=*/k + kTurn < iterations));
         }
       for (int g = 0; g < count; ++g) {
         mppi_planner* p = ps[g];
@@ -1906,9 +1976,16 @@ extern "C" int mppi_group_p2p_connect(mppi_planner** ps, int count) {
   }
   // Do the peers' stores reach kernels that are already running?  All ranks ping at once (their kernels wait for each
   // other, so every device gets its launch before any is waited for); a group that cannot hear itself is not connected.
-  {
+  // Ranks that SHARE a device (the one-GPU test set-up) are not pinged: their planners' streams can map onto one hardware
+  // queue and run one after the other (mppi_debug_occupy_cus records exactly that), the first ping would then spin until
+  // its poll limit and report a connection that works as broken; through one device's L2 there is nothing to find out.
+  bool shared_device = false;
+  for (int g = 0; g < count; ++g)
+    for (int q = 0; q < g; ++q) shared_device = shared_device || ps[q]->cfg.device == ps[g]->cfg.device;
+  if (!shared_device) {
     std::vector<int*> results((size_t)count, nullptr);
     int rc = MPPI_OK;
+    int launched = 0;
     for (int g = 0; g < count && rc == MPPI_OK; ++g) {
       mppi_planner* p = ps[g];
       if (hipSetDevice(p->cfg.device) != hipSuccess) { rc = fail(MPPI_ERR_HIP, "hipSetDevice failed"); break; }
@@ -1921,18 +1998,22 @@ extern "C" int mppi_group_p2p_connect(mppi_planner** ps, int count) {
       X.rank = g;
       hipLaunchKernelGGL(k_p2p_ping, dim3(1), dim3(64), 0, p->stream, X, inbox_ping_offset(count, p->cfg.num_steps),
                          0x70696e67ull /* "ping" */, 2000 * 1000, results[(size_t)g]);
+      launched = g + 1;
     }
     for (int g = 0; g < count; ++g) {
       mppi_planner* p = ps[g];
       int heard = 0;
-      if (rc == MPPI_OK && results[(size_t)g]) {
+      // (also on the error path: a ping that was launched still polls -- bounded -- and writes its result buffer)
+      if (g < launched) {
         (void)hipSetDevice(p->cfg.device);
-        if (hipStreamSynchronize(p->stream) != hipSuccess ||
-            hipMemcpy(&heard, results[(size_t)g], sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
-          rc = fail(MPPI_ERR_HIP, "peer exchange ping on device %d failed", p->cfg.device);
-        else if (heard != count)
-          rc = fail(MPPI_ERR_COMM, "peer exchange: device %d heard %d of %d ranks (stores of peers do not reach running kernels)",
-                    p->cfg.device, heard, count);
+        const bool drained = hipStreamSynchronize(p->stream) == hipSuccess;
+        if (rc == MPPI_OK) {
+          if (!drained || hipMemcpy(&heard, results[(size_t)g], sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(MPPI_ERR_HIP, "peer exchange ping on device %d failed", p->cfg.device);
+          else if (heard != count)
+            rc = fail(MPPI_ERR_COMM, "peer exchange: device %d heard %d of %d ranks (stores of peers do not reach running kernels)",
+                      p->cfg.device, heard, count);
+        }
       }
       dev_free(results[(size_t)g]);
     }

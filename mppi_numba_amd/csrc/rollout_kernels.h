@@ -555,10 +555,9 @@ struct PipeRing {
 // the lookup of step t + 1 is issued the moment x_{t+1}, y_{t+1} exist, and the 24 instructions that do not need it
 // (float64 copies of the new state, the rotation of (cos, sin) by the exact heading increment, the ring stores) run in
 // its shadow (sched_barrier keeps the compiler from moving them back in front).  The instruction count per step is
-// cut as well: both cell coordinates in one packed float32 subtract and one packed fma; no clamp (negative
-// coordinates saturate to 0 in v_cvt_u32_f32 and an LDS address beyond the window -- unreachable within the horizon,
-// host-proved; only the ignored steps past the horizon of the last chunk can get there -- reads whatever bytes are
-// there or, past the allocation, zero: nothing faults, nothing is used); the raw 16-bit cell goes to the cost wave
+// cut as well: both cell coordinates in one packed float32 subtract and one packed fma; no clamp where the host has
+// proved it idle (POW2RES variant: a map no rollout can leave -- launch_plan.h, unclamped_lookup_ok; elsewhere the
+// variant with the exact floor division clamps to the border cell); the raw 16-bit cell goes to the cost wave
 // instead of a shifted byte.  Same operations on the same operands as before: the oracle's bits.
 typedef float pipe_f2 __attribute__((ext_vector_type(2)));
 
@@ -588,8 +587,12 @@ struct PipeWindow {
       // d = fl(pos - lo) is the reference's float32 difference; d * inv_res and the subtraction of the integer window
       // origin are exact (device_math.h, cell_coord_pow2); the truncating conversion is the floor for q >= 0
       const pipe_f2 q = __builtin_elementwise_fma(pipe_f2{x, y} - lo, pipe_f2{inv_res, inv_res}, -origin);
-      xi = (uint32_t)q.x;  // v_cvt_u32_f32
-      yi = (uint32_t)q.y;
+      // (the instruction itself, not a C++ conversion -- which is undefined for a negative value: v_cvt_u32_f32 saturates
+      //  at 0.  No upper clamp: the host selects this variant only where no rollout can leave the map, launch_plan.h:
+      //  unclamped_lookup_ok; the steps past the horizon of the last chunk may index beyond the window -- an LDS read of
+      //  bytes nobody uses, or zero past the allocation)
+      asm("v_cvt_u32_f32 %0, %1" : "=v"(xi) : "v"(q.x));
+      asm("v_cvt_u32_f32 %0, %1" : "=v"(yi) : "v"(q.y));
     } else {
       xi = (uint32_t)clamp_index(floordiv_to_int(x - lo.x, res, inv_res) - c0, cols);
       yi = (uint32_t)clamp_index(floordiv_to_int(y - lo.y, res, inv_res) - r0, rows);

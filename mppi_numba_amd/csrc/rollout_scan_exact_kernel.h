@@ -268,13 +268,24 @@ __device__ __forceinline__ float scan_exact_reexecute(const DevParams& P, const 
   return cost;
 }
 
-template <bool POW2RES, bool GEN, bool DIRECT = false>
+// SPEED (round 6): rollout_det_dyn_w_speed_map_numba (mppi.py:1013-1111) on the time-parallel schedule.  That mode's
+// dynamics run on NOMINAL traction (terrain.py:455-463: all mass in the last bin, the padding ring in the first), i.e.
+// the assumption the walks rest on -- every visited cell carries the start cell's traction -- holds by construction;
+// what the map changes from cell to cell is the TIME a step is charged with, dt / (risk speed + 1e-6)
+// (mppi.py:1095-1096), and that is a term of the stage cost the chunk waves form side by side anyway (phase C: the
+// risk byte comes with the cell: 32-bit cells, scan_lookup<.., WIDE>; one float64 division per step and lane, off
+// every chain).  A vote that fails all the same (grids injected through the C API) is re-run by the cost wave alone on
+// the general arithmetic (map_step<MAP_SPEED>: global cells + the risk map), counted, and the planner then leaves for
+// k_rollout_fused<SPEED>; there is no DIRECT form of this mode (a window of 32-bit cells does not fit beside the noise).
+template <bool POW2RES, bool GEN, bool DIRECT = false, bool SPEED = false>
 __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const uint16_t* __restrict__ cells16,
                                                              const uint32_t* __restrict__ cells,
                                                              const float2* __restrict__ noise, NoiseJob gen,
                                                              const float2* __restrict__ u, float* __restrict__ costs,
                                                              float* __restrict__ w_rel, ScanPackets pk,
-                                                             PendingApply pend, ScanFallback fallback) {
+                                                             PendingApply pend, ScanFallback fallback,
+                                                             const int8_t* __restrict__ risk) {
+  static_assert(!(DIRECT && SPEED), "the speed-map mode has no direct (exact-schedule) form of this kernel");
   extern __shared__ double2 scan_lds[];
   using L = ScanExactLds;
   constexpr int R = L::R, CHL = L::CHL;
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
 
   // the start cell (the traction every visited cell is assumed to carry): requested at once -- the theta walk needs
   // it for its very first step
-  const uint32_t ref = scan_lookup<POW2RES>(Q, cells16, Q.x0, Q.y0) & 0x3fffu;
+  const uint32_t ref = scan_lookup<POW2RES, SPEED>(Q, cells16, Q.x0, Q.y0) & 0x3fffu;
 
   char* base = reinterpret_cast<char*>(scan_lds);
   // no time-parallel attempt (see ScanFallback): an instantiation of its own -- the speculative launch must not carry
@@ -704,8 +715,8 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
       }
       RolloutState st = {Q.x0, Q.y0, Q.th0, 0.0f, 1e9, false, false};
       for (int t = 0; t < T; ++t) {
-        map_step<MAP_DET, true, false, false>(Q, cells, nullptr, nullptr, folded ? u_sh[t] : uq[t],
-                                              e2[t * R + (r ^ (t & (R - 1)))], st);
+        map_step<SPEED ? MAP_SPEED : MAP_DET, true, false, false>(Q, cells, risk, nullptr, folded ? u_sh[t] : uq[t],
+                                                                  e2[t * R + (r ^ (t & (R - 1)))], st);
         if (__all(st.done)) break;
       }
       cost = (float)((double)st.cost + (st.reached ? 0.0 : 1.0) * sqrt(st.d2) / Q.v_post_den);
@@ -812,6 +823,7 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
     (void)wait_for(&xy_done[g]);
     MPPI_STAMP(stamp_wg && c < 16, stamp_base + 4);
     double sg[CHL], n2[CHL];
+    [[maybe_unused]] double stt[CHL];  // SPEED: the time each step is charged with
     float xa[CHL + 1], ya[CHL + 1];
     float po[CHL], pu[CHL];
     uint32_t zero_bits = 0, mism_bits = 0, hit_bits = 0;
@@ -825,12 +837,13 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
       }
       uint32_t cell[CHL];
 #pragma unroll
-      for (int j = 0; j < CHL; ++j) cell[j] = scan_lookup<POW2RES>(Q, cells16, xa[j], ya[j]);  // the cell step j STARTS in
+      for (int j = 0; j < CHL; ++j) cell[j] = scan_lookup<POW2RES, SPEED>(Q, cells16, xa[j], ya[j]);  // the cell step j STARTS in
 #pragma unroll
       for (int j = 0; j < CHL; ++j) {
         const double dx = (double)(Q.xg - xa[j + 1]), dy = (double)(Q.yg - ya[j + 1]);
         n2[j] = fma(dx, dx, dy * dy);
-        sg[j] = fma(Q.dist_weight, sqrt_newton_nz_f64(n2[j]), dt64);
+        if constexpr (SPEED) sg[j] = sqrt_newton_f64(n2[j]);  // (the step's time needs the cell: below)
+        else sg[j] = fma(Q.dist_weight, sqrt_newton_nz_f64(n2[j]), dt64);
         hit_bits |= (n2[j] <= gt2 ? 1u : 0u) << j;
       }
       pin_memory_order();
@@ -842,6 +855,12 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
         mism_bits |= (((cl ^ ref) & 0x3fffu) != 0u ? 1u : 0u) << j;
         po[j] = (cl & 0x4000u) ? Q.obs_cost : 0.0f;
         pu[j] = (cl & 0x8000u) ? Q.unk_cost : 0.0f;
+        if constexpr (SPEED) {
+          // dt over the risk-aware effective speed of the cell the step starts in (mppi.py:1095-1096)
+          const double eff = fma(Q.lin_ratio, (double)(int)(int8_t)(cl >> 16), Q.lin_lo);
+          stt[j] = dt64 / (eff + 1e-6);
+          sg[j] = fma(Q.dist_weight, sg[j], stt[j]);
+        }
       }
     }
     MPPI_STAMP(stamp_wg && c < 16, stamp_base + 11);
@@ -859,17 +878,21 @@ __global__ __launch_bounds__(1024) void k_rollout_scan_exact(DevParams P, const 
       float fx = xa[0], fy = ya[0];
       f_po = po[0];
       f_pu = pu[0];
+      [[maybe_unused]] double f_st = dt64;
+      if constexpr (SPEED) f_st = stt[0];
 #pragma unroll
       for (int j = 1; j < CHL; ++j) {
         fx = s == j ? xa[j] : fx;
         fy = s == j ? ya[j] : fy;
         f_po = s == j ? po[j] : f_po;
         f_pu = s == j ? pu[j] : f_pu;
+        if constexpr (SPEED) f_st = s == j ? stt[j] : f_st;
       }
       // a rollout in a cell of zero linear traction stays where it is: x = float32(fma(0, ., x))
       const double dx = (double)(Q.xg - fx), dy = (double)(Q.yg - fy);
       f_d2 = fma(dx, dx, dy * dy);
-      f_k = fma(Q.dist_weight, sqrt_newton_nz_f64(f_d2), dt64);
+      if constexpr (SPEED) f_k = fma(Q.dist_weight, sqrt_newton_f64(f_d2), f_st);  // (it goes on paying that cell's time)
+      else f_k = fma(Q.dist_weight, sqrt_newton_nz_f64(f_d2), dt64);
       f_hit = f_d2 <= gt2;
     }
     // A rollout that stops in a zero-traction cell goes on paying the stage cost and the penalties of the

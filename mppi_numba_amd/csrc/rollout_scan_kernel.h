@@ -91,7 +91,9 @@ __device__ __forceinline__ void scan_noise_pair(const NoiseJob& g, uint64_t epoc
   b = make_float2(g.std0 * zb.x, g.std1 * zb.y);
 }
 
-template <bool POW2RES>
+// (WIDE: the 32-bit cells of the speed-map mode -- the same 16 bits + the risk traction byte in bits 16..23 -- behind
+//  the same pointer, same pitch in cells: k_pack_cells32_risk)
+template <bool POW2RES, bool WIDE = false>
 __device__ __forceinline__ uint32_t scan_lookup(const DevParams& Q, const uint16_t* __restrict__ cells16, float x,
                                                 float y) {
   int xi, yi;
@@ -102,6 +104,7 @@ __device__ __forceinline__ uint32_t scan_lookup(const DevParams& Q, const uint16
     xi = clamp_index(floordiv_to_int(x - Q.xlo, Q.res, Q.inv_res), Q.cols);
     yi = clamp_index(floordiv_to_int(y - Q.ylo, Q.res, Q.inv_res), Q.rows);
   }
+  if (WIDE) return reinterpret_cast<const uint32_t*>(cells16)[__mul24(yi, Q.pitch16) + xi];
   return cells16[__mul24(yi, Q.pitch16) + xi];
 }
 

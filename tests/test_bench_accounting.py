@@ -35,10 +35,39 @@ def test_reference_leg_says_what_is_missing(monkeypatch, tmp_path):
     out = bench.reference_cpu_path()
     assert out["status"].startswith("not measured in this run: missing ")
     assert "MPPI_NUMBA_REFERENCE" in out["status"] and "MPPI_NUMBA_PYTHON" in out["status"]
-    # the figure of the build container is labelled as such, never as a measurement of the run
-    assert "value" not in out
-    if os.path.exists(os.path.join(bench.ROOT, "profiles", "r02_reference_cudasim.json")):
-        assert "stale_build_container_measurement" in out
+    # no figure from another machine on the line: the build container's measurement is named, not quoted
+    assert "value" not in out and "stale_build_container_measurement" not in out
+    assert "profiles/r02_reference_cudasim.json" in out["measured_elsewhere"]
+
+
+def test_traffic_entry_follows_the_effective_configuration():
+    """`--workload c4 --n 8192` is configs[3]'s shard: its own counter passes, never C4's."""
+    assert bench.traffic_key("c2", 8192) == "c2"
+    assert bench.traffic_key("c2", 8192, "fast") == "c2_fast"
+    assert bench.traffic_key("c4", 65536) == "c4"
+    assert bench.traffic_key("c4", 8192) == "c4shard"
+    import json
+    with open(os.path.join(bench.ROOT, "profiles", "traffic.json")) as fh:
+        table = json.load(fh)
+    assert bench.traffic_key("c4", 8192) in table
+    assert bench.traffic_key("c4", 4096) not in table and bench.traffic_key("c2", 1024) not in table
+
+
+def test_algorithmic_bytes_speed_map_counts_the_risk_byte():
+    w, base = bench.WORKLOADS["c2m"], bench.WORKLOADS["c2"]
+    it_m, roll_m = bench.algorithmic_bytes(w, w["n"], 264, 264, fused=True)
+    it_d, roll_d = bench.algorithmic_bytes(base, base["n"], 264, 264, fused=True)
+    steps = w["n"] * w["t"]
+    assert it_m - it_d == steps + 264 * 264 and roll_m - roll_d == steps + 264 * 264  # 29 B per rollout-step (SURVEY.md 8d)
+
+
+def test_the_published_barebone_configuration():
+    """bench.py --workload bb is barebone_mppi_numba.ipynb cell 5, nothing else."""
+    cfg, params = bench.barebone_problem()
+    assert cfg == dict(T=5.0, dt=0.1, num_control_rollouts=1000, num_vis_state_rollouts=20, seed=1)
+    assert params["num_opt"] == 1 and params["obs_penalty"] == 1e6 and params["dist_weight"] == 10
+    assert params["obstacle_positions"].tolist() == [[5, 4.5], [2, 1]] and params["obstacle_radius"].tolist() == [1.5, 1]
+    assert bench.BB_PUBLISHED["value_ms"] == 2.74
 
 
 def test_usable_cores_is_positive():

@@ -85,6 +85,12 @@ def test_speed_map_edge_sizes(n, t_steps):
                          lin.obstacle_map_d.copy_to_host(), lin.unknown_map_d.copy_to_host(), noise, u_in,
                          risk=lin.risk_traction_map_d.copy_to_host())
     assert np.array_equal(got, want)
+    # (round 6: the latency regime of this mode is the time-parallel kernel; the fused kernel behind the developer switch)
+    assert "k_rollout_scan_exact speed_map" in planner.last_rollout_kernel()
+    from mppi_numba_amd import _lib
+    planner.set_debug_flags(_lib.DEBUG_NO_SCAN_KERNEL)
+    planner.rollout()
+    assert np.array_equal(planner.costs_d.copy_to_host(), want)
     assert "k_rollout_fused speed_map" in planner.last_rollout_kernel()
 
 
@@ -105,6 +111,8 @@ def test_speed_map_large_reach_uses_global_cells_and_matches_oracle():
     params = bench.make_params("c2")
     params.update(x0=np.array([32.0, 32.0, 0.5]), xgoal=np.array([50.0, 40.0]))
     planner.setup(params, lin, ang)
+    from mppi_numba_amd import _lib
+    planner.set_debug_flags(_lib.DEBUG_NO_SCAN_KERNEL)  # (the time-parallel kernel needs no window: tests/test_gpu_speedmap_scan.py)
     planner.solve()
     planner.sample_noise()
     noise, u_in = planner.noise_samples_d.copy_to_host(), planner.u_cur_d.copy_to_host()

@@ -59,3 +59,34 @@ def test_handover_gives_up_softly_when_the_device_is_shared_and_the_handle_recov
         assert (ulp_diff_f32(got, want) == 0).mean() >= 0.999
         planner.update()
     assert planner.fold_state() == (False, 1)
+
+
+def test_every_draining_call_reports_the_give_up_and_the_handle_can_be_rearmed():
+    """after iterate_async a caller may fetch the controls with get_u() instead of synchronize() -- that
+    call drains the stream too and must report MPPI_ERR_BUSY instead of handing out whatever the broken hand-over left.
+    And one transient co-tenant need not cost the handle its one-launch iteration for good: set_fold_poll_limit re-arms."""
+    w, cfg, lin, ang, planner, params = bench.build_planner("c2")
+    planner.solve()
+    planner.iterate_async(6)
+    planner.synchronize()
+    u_good = planner.u_cur_d.copy_to_host()
+    planner.set_fold_poll_limit(4000)
+    cus = _lib.device_props(0).compute_units
+    _lib.call("mppi_debug_occupy_cus", 0, cus - 40, 300)
+    time.sleep(0.05)
+    planner.iterate_async(6)
+    with pytest.raises(_lib.MppiError) as err:
+        planner.u_cur_d.copy_to_host()  # (mppi_planner_get_u: a drain like any other)
+    assert err.value.code == ERR_BUSY, err.value
+    assert planner.fold_state() == (False, 1)
+    time.sleep(0.4)  # the co-tenant is gone
+    planner.set_u(u_good)
+    planner.iterate_async(4)
+    planner.synchronize()
+    assert "reduces_tiles" not in planner.last_rollout_kernel()
+    planner.set_fold_poll_limit(1 << 20)  # re-arm: the device is the handle's own again
+    assert planner.fold_state() == (True, 1)
+    planner.iterate_async(6)
+    planner.synchronize()
+    assert "reduces_tiles=1" in planner.last_rollout_kernel(), planner.last_rollout_kernel()
+    assert np.isfinite(planner.u_cur_d.copy_to_host()).all()

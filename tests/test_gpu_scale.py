@@ -25,12 +25,14 @@ def oracle_costs(w, params, lin, ang, noise, u):
     p = oracle_params(params, lin, ang)
     args = (p, lin.sample_grid_batch_d.copy_to_host(), ang.sample_grid_batch_d.copy_to_host(),
             lin.obstacle_map_d.copy_to_host(), lin.unknown_map_d.copy_to_host(), noise, u)
-    return O.rollout_tdm(*args) if w["m"] > 1 else O.rollout_det(*args)
+    if w["m"] > 1:
+        return O.rollout_tdm(*args)
+    return O.rollout_det(*args, risk=lin.risk_traction_map_d.copy_to_host() if w.get("speed_map") else None)
 
 
 # which rollout kernel each BASELINE configuration must take (bench.py runs the same objects)
 EXPECTED_KERNEL = {"c2": "k_rollout_scan_exact", "c3": "k_rollout_tdm_fast", "c4": "k_rollout_fused",
-                   "ns": "k_rollout_fused"}
+                   "ns": "k_rollout_fused", "c2m": "k_rollout_scan_exact speed_map", "c2m1k": "k_rollout_scan_exact speed_map"}
 
 
 def costs_and_update_margin(workload, n):
@@ -65,12 +67,14 @@ def costs_and_update_margin(workload, n):
     return margin
 
 
-@pytest.mark.parametrize("workload,n", [("c2", None), ("c4", None), ("c3", None), ("c4", 16384), ("c3", 192), ("ns", None)])
+@pytest.mark.parametrize("workload,n", [("c2", None), ("c4", None), ("c3", None), ("c4", 16384), ("c3", 192), ("ns", None),
+                                        ("c2m", None), ("c2m1k", None)])
 def test_costs_and_update_vs_oracle_at_scale(workload, n):
     """BASELINE configs[1..3] at FULL size -- C2 N=8192, T=100; C4 N=65536, T=200 (the fused
     throughput kernel); C3 N=4096 x M=128 -- the very objects bench.py times, against the C
     restatement; `ns` = north_star's target shape on one GPU (N=65536, T=100, nominal map); plus two reduced cases that take other kernels (C4 at N=16384: pipelined kernel
-    at T=200)."""
+    at T=200); `c2m` / `c2m1k`: the speed-map mode (mppi.py:1013-1111) at C2's shape and at the reference's own
+    N=1024 on the time-parallel kernel (round 6)."""
     costs_and_update_margin(workload, n)
 
 
