@@ -455,6 +455,10 @@ def main():
                     help="multi-GPU c3: what the ranks split -- the N control samples (default; every rank holds all "
                          "M traction maps) or the M traction samples (every rank rolls all N controls over its own "
                          "M maps of a global M*gpus; one all-gather of the (N, M) per-sample costs per step)")
+    ap.add_argument("--no-kernel-timing", action="store_true", dest="no_kernel_timing",
+                    help="skip the event-bracketed stages and the per-launch timing that follow the timed regions: under "
+                         "rocprofv3 the trace then holds the plain loop's launches only (launches that carry events, or that are "
+                         "bracketed by them, run differently where a second stream is involved and would pull the averages)")
     ap.add_argument("--single-process", action="store_true",
                     help="--gpus N from ONE process driving N devices (mppi_group_*) instead of one process per GPU")
     args = ap.parse_args()
@@ -750,7 +754,7 @@ def main():
     # ---- per-kernel durations with HIP events on the planner's stream ---------------
     planner.set_profiling(True)
     stage = dict(noise=0.0, rollout=0.0, update=0.0, collective=0.0)
-    reps = 0 if ((world > 1 and args.exchange == "host" and not problems) or group_size > 1) else 50
+    reps = 0 if ((world > 1 and args.exchange == "host" and not problems) or group_size > 1 or args.no_kernel_timing) else 50
     for _ in range(reps):
         planner.iterate_async(3)  # the middle iteration is profiled: steady state
         planner.synchronize()
@@ -762,8 +766,10 @@ def main():
     # --kernel-trace reports); nothing is inserted between the kernels
     # (every rank runs it: with RCCL the iterations it times contain the all-gather, a collective)
     kernel_us = None
-    if group_size == 1 and not args.graph and not (world > 1 and args.exchange == "host" and not problems):
+    if group_size == 1 and not args.graph and not (world > 1 and args.exchange == "host" and not problems) and not args.no_kernel_timing:
         kernel_us = planner.time_kernels(200)
+        if kernel_us[0] <= 0.0:  # (a loop on two streams whose rollout kernel does not stamp its launch: not timed in the loop)
+            kernel_us = None
 
     if rank != 0:
         barrier()
@@ -834,7 +840,10 @@ def main():
             {"rollout": kernel_us[0], "update": kernel_us[1],
              "how": "200 ordinary iterations of one call; every rollout / update launch carries its own start / stop HIP "
                     "events (hipExtLaunchKernelGGL: the dispatch's begin / end timestamps, as rocprofv3 --kernel-trace "
-                    "reports them; averages agree with profiles/).  `update` is the update launches' time per ITERATION: "
+                    "reports them; averages agree with profiles/).  A loop that runs the next iteration's noise on a second "
+                    "stream (N*T >= 4M: ns, c4) is timed WITHOUT events -- they shift such a loop (mppi_api.hip, "
+                    "mppi_planner_time_kernels) -- by its kernels themselves: first wave in to last wave out on the device's "
+                    "100 MHz clock.  `update` is the update launches' time per ITERATION: "
                     "when the next rollout launch applies the update itself (rollout_kernel says applies_update=1) only "
                     "the last iteration of a call has an update launch and its time is spread over all of them"},
         # the line must follow from its parts: the dominant launches of an iteration cannot last longer than the iteration

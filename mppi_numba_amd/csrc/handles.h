@@ -223,6 +223,14 @@ struct mppi_planner {
   std::vector<hipEvent_t> ktime_events;
   std::vector<char> ktime_update_ran;  // per timed iteration: its update was a launch of its own
   int ktime_index = -1;
+  bool ktime_markers = false;  // a timed rollout launch followed a cross-stream wait / an event record on the stream
+  unsigned long long* ktime_dev = nullptr;  // [reps][4][ktime_waves] when the waves of the timed rollout | update launches entered, left (DevParams::ktime)
+  size_t ktime_dev_capacity = 0;            // ... in words
+  int ktime_waves = 0;
+  bool used_side_stream = false;   // an iteration put the next one's noise on noise_stream (since the flag was last cleared)
+  bool ktime_use_stamps = false;   // this timing run is a plain loop whose kernels stamp themselves
+  unsigned long long* ktime_rollout_slot = nullptr;  // this iteration's slots, while its launches are made
+  unsigned long long* ktime_update_slot = nullptr;
   // comm
   ncclComm_t comm = nullptr;
   // The peer exchange (mppi_planner_p2p_*; update_kernels.h, PeerExchange): this rank's inbox -- fine-grained device

@@ -914,7 +914,8 @@ static int try_launch_pipe(mppi_planner* p, DevParams& d, const DetRegime& r, bo
     // the problem with at most three triples (measured, profiles/r01_ablation.md: 1 triple
     // 53 vs 79 us, 2 triples 76 vs 83 us, 4 triples a tie, two rounds 162 vs 88 us at T=200).
     // Beyond that the fused kernel below, 4..16 waves per CU, has the better throughput.
-    const bool latency_regime = pairs <= 3 && ceil_div(ceil_div(N, 64), pairs) <= p->num_cus;
+    static const int max_triples = getenv("MPPI_PIPE_MAX_TRIPLES") ? atoi(getenv("MPPI_PIPE_MAX_TRIPLES")) : 3;  // developer switch (experiments)
+    const bool latency_regime = pairs <= max_triples && ceil_div(ceil_div(N, 64), pairs) <= p->num_cus;
     if (chunk > 0 && latency_regime) {
       // control-cost products in LDS when there is room, else in a global scratch array
       const size_t cc_bytes = (size_t)pairs * T * 64 * sizeof(double);
@@ -1237,8 +1238,12 @@ static int launch_rollout(mppi_planner* p, const DevParams& d) {
   double theta_bound = th0_max + (double)p->cfg.num_steps * (double)a.dt * wmax * trmax;
   bool bounded = std::isfinite(theta_bound) && theta_bound < 5.0e4;
   p->theta_bounded = bounded;
-  if (p->cfg.math != MPPI_MATH_EXACT) return launch_rollout_t<false, false>(p, d);
-  return bounded ? launch_rollout_t<true, true>(p, d) : launch_rollout_t<true, false>(p, d);
+  // mppi_planner_time_kernels on a two-stream loop: the kernels of the throughput regime stamp their own begin / end
+  DevParams dk = d;
+  dk.ktime = p->ktime_rollout_slot;
+  dk.ktime_waves = p->ktime_waves;
+  if (p->cfg.math != MPPI_MATH_EXACT) return launch_rollout_t<false, false>(p, dk);
+  return bounded ? launch_rollout_t<true, true>(p, dk) : launch_rollout_t<true, false>(p, dk);
 }
 
 // tile-relative weights (unless the rollout kernel just emitted them) + the row kernel:
@@ -1326,7 +1331,8 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
   MPPI_KLAUNCH((k_update_rows<APPLY, TC, FC>), grid, dim3(kRowThreads), lds, p->stream,                   \
                      FC ? p->costs : p->w_rel, p->tile_beta, p->n_inst, p->inst_tiles, p->noise, T,             \
                      a.lambda_weight, my_packet, p->u, p->u_prev, (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0], a.vrange[1],      \
-                     a.wrange[0], a.wrange[1], p->stats, p->graph_on ? p->gen_dev : (unsigned long long*)nullptr)
+                     a.wrange[0], a.wrange[1], p->stats, p->graph_on ? p->gen_dev : (unsigned long long*)nullptr,              \
+                     p->ktime_update_slot, p->ktime_waves)
 #define MPPI_LAUNCH_ROWS_TC(APPLY, FC)        \
   do {                                        \
     if (many_rows) MPPI_LAUNCH_ROWS(APPLY, 4, FC); \
@@ -1444,6 +1450,7 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
   // then runs in the rollout's tail and collides with the update (measured, profiles/r01_ablation.md)
   const bool side_stream_pays = (long)p->n_local * p->cfg.num_steps >= 4L * 1000 * 1000 &&
                                 ceil_div(ceil_div(p->n_local, 64), p->num_cus) <= 8 && !no_side_stream;
+  const bool ktime_stamps = p->ktime_index >= 0 && p->ktime_dev && p->ktime_use_stamps;  // (mppi_planner_time_kernels)
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[0], p->stream));
   // MPPI_MATH_FAST over a map the time-parallel kernel takes: the rollout launch computes its noise
   // from the Philox counters itself; nothing is generated ahead, nothing is stored
@@ -1455,13 +1462,7 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
     want_next = false;
   } else if (have_noise) {
     p->noise_cur ^= 1;
-    if (p->noise_on_side_stream) {
-      HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_noise_ready, 0));
-      if (p->ktime_index >= 0) {  // (see k_absorb_wait: the timed launch must not be the first dispatch behind the wait)
-        hipLaunchKernelGGL(k_absorb_wait, dim3(1), dim3(64), 0, p->stream);
-        HIP_TRY(hipGetLastError());
-      }
-    }
+    if (p->noise_on_side_stream) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_noise_ready, 0));
     p->noise_on_side_stream = false;
     p->noise_virtual = false;
   } else {
@@ -1477,12 +1478,18 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
   if (want_next && side_stream_pays) HIP_TRY(hipEventRecord(p->ev_buf_free, p->stream));
   {
     TraceRange tr("mppi:rollout");
-    if (p->ktime_index >= 0) {
+    // mppi_planner_time_kernels.  A loop with the second stream in it is timed by the kernels themselves (device
+    // stamps, no event anywhere near the launches -- see there); every other loop by start / stop events on the launches.
+    if (ktime_stamps) {
+      p->ktime_markers = true;
+      p->ktime_rollout_slot = p->ktime_dev + 4 * (size_t)p->ktime_waves * (size_t)p->ktime_index;
+    } else if (p->ktime_index >= 0) {
       p->kev_start = p->ktime_events[4 * (size_t)p->ktime_index];
       p->kev_stop = p->ktime_events[4 * (size_t)p->ktime_index + 1];
     }
     const int rc = launch_rollout(p, d);
     p->kev_start = p->kev_stop = nullptr;
+    p->ktime_rollout_slot = nullptr;
     TRY(rc);
   }
   if (p->m_count > 1) {
@@ -1494,6 +1501,7 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
     HIP_TRY(hipStreamWaitEvent(p->noise_stream, p->ev_buf_free, 0));
     TraceRange tr("mppi:noise_ahead");
     TRY(launch_noise(p, p->noise_buf[p->noise_cur ^ 1], p->noise_stream));
+    p->used_side_stream = true;
     HIP_TRY(hipEventRecord(p->ev_noise_ready, p->noise_stream));
     have_noise = p->noise_on_side_stream = true;
     if (p->graph_on) {
@@ -1509,13 +1517,18 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
   TraceRange tr_update("mppi:update");
   const int ktime_slot = p->ktime_index;
   if (p->ktime_index >= 0) {
-    p->kev_start = p->ktime_events[4 * (size_t)p->ktime_index + 2];
-    p->kev_stop = p->ktime_events[4 * (size_t)p->ktime_index + 3];
+    if (ktime_stamps) {
+      p->ktime_update_slot = p->ktime_dev + 4 * (size_t)p->ktime_waves * (size_t)p->ktime_index + 2 * (size_t)p->ktime_waves;
+    } else {
+      p->kev_start = p->ktime_events[4 * (size_t)p->ktime_index + 2];
+      p->kev_stop = p->ktime_events[4 * (size_t)p->ktime_index + 3];
+    }
     ++p->ktime_index;
   }
   {
     const int rc = launch_update(p, prof, defer_exchange, may_leave_apply);
     p->kev_start = p->kev_stop = nullptr;
+    p->ktime_update_slot = nullptr;
     TRY(rc);
     // (an update left to the next rollout launch has no launch of its own to time)
     if (ktime_slot >= 0 && (size_t)ktime_slot < p->ktime_update_ran.size()) p->ktime_update_ran[(size_t)ktime_slot] = !p->reduce_pending;

@@ -78,6 +78,11 @@ struct DevParams {
   float cc_k0, cc_k1;              // lambda / u_std^2
   double inv_v_post_den;           // 1 / (v_post_rollout + 1e-6)
   double neg_log2e_over_lambda;    // -log2(e) / lambda
+  // mppi_planner_time_kernels only (else nullptr): when every wave of this launch entered ([0, ktime_waves)) and left
+  // ([ktime_waves, 2 ktime_waves)) on the device's constant 100 MHz clock -- for the kernels of the throughput regime,
+  // whose loop runs on two streams and cannot be timed with events (see there)
+  unsigned long long* ktime;
+  int ktime_waves;
 };
 
 // What differs between the problems of a batched handle (mppi_planner_set_instances).
@@ -87,6 +92,16 @@ struct BatchInst {
   int win_r0, win_c0;  // the LDS window is planned around each start state
   int pad;
 };
+
+// (one slot per wave, plain stores: atomics of a few thousand waves on one address took longer than the kernel)
+__device__ __forceinline__ void ktime_begin(const DevParams& P) {
+  if (P.ktime && (threadIdx.x & 63) == 0)
+    P.ktime[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = (unsigned long long)wall_clock64();
+}
+__device__ __forceinline__ void ktime_end(const DevParams& P) {
+  if (P.ktime && (threadIdx.x & 63) == 0)
+    P.ktime[P.ktime_waves + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = (unsigned long long)wall_clock64();
+}
 
 // Problem b of a batched handle: patch the by-value parameters and return its control
 // sequence.  b is uniform over the workgroup, so these are scalar loads; a single-problem
@@ -306,6 +321,7 @@ __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
                               const float2* __restrict__ noise, const float2* __restrict__ u,
                               float* __restrict__ costs) {
   extern __shared__ double2 uos[];
+  ktime_begin(P);
   // batched handle: the waves of a workgroup belong to one problem (host: blockDim/64 divides inst_tiles)
   u = select_instance(P, u, P.inst ? (int)(blockIdx.x * (blockDim.x >> 6)) / P.inst_tiles : 0);
   float2* us = reinterpret_cast<float2*>(uos + P.n_steps);  // u[t] staged next to the ratios
@@ -360,6 +376,7 @@ __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
     cost = EXACT ? (float)((double)cost + c1) : cost + (float)c1;
   }
   if (live) costs[n] = cost;
+  ktime_end(P);
 }
 
 // -------------------------------------------------------------------------
@@ -396,6 +413,7 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
                                 float* __restrict__ costs, float* __restrict__ w_rel,
                                 float* __restrict__ tile_beta) {
   extern __shared__ double2 uos[];
+  ktime_begin(P);
   // batched handle: the waves of a workgroup belong to one problem (host: blockDim/64 divides inst_tiles)
   u = select_instance(P, u, P.inst ? (int)(blockIdx.x * (blockDim.x >> 6)) / P.inst_tiles : 0);
   const int T = P.n_steps, N = P.n_local;
@@ -503,6 +521,7 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
     cost = (float)fma((double)P.lambda, (double)cc32, (double)cost);
     if (live) costs[n] = cost;
     if ((n & ~63) < N) emit_tile_weights(cost, live, P.lambda, n, n >> 6, w_rel, tile_beta);
+    ktime_end(P);
     return;
   }
   for (t0 = 0; t0 + kNoiseBatch <= T; t0 += kNoiseBatch) {
@@ -516,6 +535,7 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
   if (live) costs[n] = cost;
   // first half of the control update (update_kernels.h): weights relative to the tile's minimum
   if ((n & ~63) < N) emit_tile_weights(cost, live, P.lambda, n, n >> 6, w_rel, tile_beta);
+  ktime_end(P);
 }
 
 // -------------------------------------------------------------------------
@@ -1258,6 +1278,7 @@ __global__ __launch_bounds__(64) void k_rollout_barebone(DevParams P, const floa
                                                          const float2* __restrict__ u,
                                                          float* __restrict__ costs) {
   extern __shared__ double2 uos[];
+  ktime_begin(P);
   stage_control_ratios(P, u, uos);
   const int n = blockIdx.x * 64 + threadIdx.x;
   const bool live = n < P.n_local;
@@ -1310,6 +1331,7 @@ __global__ __launch_bounds__(64) void k_rollout_barebone(DevParams P, const floa
     cost = (float)((double)cost + cc);
   }
   if (live) costs[n] = cost;
+  ktime_end(P);
 }
 
 // -------------------------------------------------------------------------

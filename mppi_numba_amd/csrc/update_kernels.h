@@ -433,8 +433,12 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
                                                              float2* __restrict__ u, float2* __restrict__ u_prev,
                                                              float2* __restrict__ u_mirror, float v_lo, float v_hi,
                                                              float w_lo, float w_hi, double* __restrict__ stats,
-                                                             unsigned long long* __restrict__ gen_counter) {
+                                                             unsigned long long* __restrict__ gen_counter,
+                                                             unsigned long long* __restrict__ ktime, int ktime_waves) {
   extern __shared__ float scale_sh[];  // [n_tiles]
+  // mppi_planner_time_kernels (else nullptr): when every wave of this launch entered / left (as DevParams::ktime)
+  const int ktime_slot = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * (kRowThreads / 64) + (int)(threadIdx.x >> 6);
+  if (ktime && (threadIdx.x & 63) == 0) ktime[ktime_slot] = (unsigned long long)wall_clock64();
   // graph replay: one more generation of noise has been consumed (rng_kernels.h NoiseJob); no
   // generator runs while an update does
   if (gen_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *gen_counter += 1ull;
@@ -590,6 +594,7 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
     }
   }
   MPPI_STAMP(stamp_wg, 517);
+  if (ktime && (threadIdx.x & 63) == 0) ktime[ktime_waves + ktime_slot] = (unsigned long long)wall_clock64();
 }
 
 // ---- stage 2 after the time-parallel kernels (rollout_scan*.h): the rollout launch has already reduced
@@ -726,13 +731,5 @@ __global__ void k_noise_to_host_layout(const float2* __restrict__ dev_layout, in
   int r = (int)(i / t_steps), t = (int)(i % t_steps);
   host_layout[i] = dev_layout[tile_index(t, r, t_steps)];
 }
-
-// mppi_planner_time_kernels: a launch that follows a cross-stream wait (hipStreamWaitEvent on the noise stream) gets its
-// start event stamped when the queue REACHES the wait -- right after the previous dispatch was issued, a whole iteration
-// early (round 5: 70.98 us "in loop" against 48.92 us traced at N = 65536) -- because the wait is a barrier packet that
-// does not order itself behind the dispatch in front of it.  This empty dispatch does (kernels carry the barrier bit):
-// placed between the wait and the timed launch it takes the wait upon itself, and the timed launch's events bracket
-// the kernel alone again.  Timing runs only.
-__global__ void k_absorb_wait() {}
 
 }  // namespace mppi

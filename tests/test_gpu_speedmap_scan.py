@@ -20,22 +20,24 @@ from test_gpu_scale import oracle_costs, oracle_params
 
 pytestmark = pytest.mark.gpu
 
+# (the seventh, semantic_speedmap, is an end-to-end fixture -- seed -> sampled grids -> u through set_TDM_from_semantic_grid:
+#  tests/test_gpu_parity.py::test_semantic_grid_end_to_end_xoroshiro runs it on this kernel; asserted below by name)
 SPEEDMAP_FIXTURES = ["speedmap_cvar", "speedmap_mean", "speedmap_mean_bounds", "speedmap_odd_units",
-                     "speedmap_odd_units_w101", "speedmap_odd_units_w202", "semantic_speedmap"]
+                     "speedmap_odd_units_w101", "speedmap_odd_units_w202"]
 KERNEL = "k_rollout_scan_exact speed_map"
 
 
 @pytest.mark.parametrize("name", SPEEDMAP_FIXTURES)
 def test_reference_fixtures_on_the_time_parallel_kernel(name):
+    from gpu_helpers import solve_of_iteration
     g = golden(name)
-    if "solve0_lin_sample_grid" not in g:
-        pytest.skip("fixture holds no kernel-level inputs")
     _, lin, ang, planner, P = build_from_golden(name, g)
-    lin.set_sampled_grids(g["solve0_lin_sample_grid"])
-    ang.set_sampled_grids(g["solve0_ang_sample_grid"])
+    span = np.array([P["vrange"][1] - P["vrange"][0], P["wrange"][1] - P["wrange"][0]])
     for k, it in enumerate(iterations(g)):
-        if "solve%d_x0" % k in g:
-            planner.params["x0"] = g["solve%d_x0" % k]
+        sol = solve_of_iteration(g, k)
+        lin.set_sampled_grids(g["solve%d_lin_sample_grid" % sol])
+        ang.set_sampled_grids(g["solve%d_ang_sample_grid" % sol])
+        planner.params["x0"] = g["solve%d_x0" % sol]
         planner.set_noise(it["noise"])
         planner.set_u(it["u_in"])
         planner.rollout()
@@ -43,8 +45,36 @@ def test_reference_fixtures_on_the_time_parallel_kernel(name):
         got = planner.costs_d.copy_to_host()
         assert ulp_diff_f32(got, it["costs"]).max() == 0, (name, k, int(ulp_diff_f32(got, it["costs"]).max()))
         planner.update()
-        span = np.array([P["vrange"][1] - P["vrange"][0], P["wrange"][1] - P["wrange"][0]])
         assert (np.abs(planner.u_cur_d.copy_to_host().astype(np.float64) - it["u_out"]) / span).max() <= 1e-5
+
+
+def test_semantic_grid_entry_point_runs_the_time_parallel_kernel():
+    """set_TDM_from_semantic_grid in speed-map mode, from the seed (the reference's streams): the end-to-end fixture's u,
+    computed by this kernel."""
+    from test_host_and_abi import semantic_inputs
+    from gpu_helpers import config_from_golden
+    from mppi_numba_amd.mppi import MPPI_Numba
+    from mppi_numba_amd.terrain import TDM_Numba
+    from helpers import params_from_golden
+    g = golden("semantic_speedmap")
+    values, id2name, name2terrain, terrain2pmf, alpha = semantic_inputs(g)
+    cfg = config_from_golden("speedmap", g, rng="xoroshiro")
+    res = float(g["in_res"])
+    rows, cols = g["in_semantic_grid"].shape
+    lin, ang = TDM_Numba(cfg), TDM_Numba(cfg)
+    for tdm in (lin, ang):
+        tdm.set_TDM_from_semantic_grid(g["in_semantic_grid"], res, len(values), values, np.array([0.0, 1.0]),
+                                       (0.0, cols * res), (0.0, rows * res), id2name, name2terrain, terrain2pmf,
+                                       det_dynamics_cvar_alpha=alpha, obstacle_map=g["in_obstacle_map"],
+                                       unknown_map=g["in_unknown_map"])
+    planner = MPPI_Numba(cfg)
+    P = params_from_golden(g)
+    planner.setup(P, lin, ang)
+    useq = planner.solve()
+    assert planner.last_rollout_kernel().startswith(KERNEL), planner.last_rollout_kernel()
+    span = np.array([P["vrange"][1] - P["vrange"][0], P["wrange"][1] - P["wrange"][0]])
+    assert ulp_diff_f32(planner.costs_d.copy_to_host(), iterations(g)[0]["costs"]).max() == 0
+    assert (np.abs(useq.astype(np.float64) - g["solve0_useq"]) / span).max() <= 1e-5
 
 
 def test_loop_is_one_launch_per_iteration_and_matches_the_stage_level_path():
@@ -117,6 +147,8 @@ def test_a_failed_vote_is_reexecuted_exactly_and_the_planner_leaves_for_the_fuse
     planner.update()
     planner.iterate_async(2)  # (no TDM sampling: the injected grids stay)
     planner.synchronize()     # the host looks at the failure count here
+    planner.set_noise(noise)
+    planner.set_u(u_in)
     planner.rollout()
     assert planner.last_rollout_kernel().startswith("k_rollout_fused speed_map"), planner.last_rollout_kernel()
     assert (ulp_diff_f32(planner.costs_d.copy_to_host(), want) == 0).mean() >= 0.999
