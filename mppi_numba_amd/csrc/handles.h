@@ -100,6 +100,19 @@ struct mppi_planner {
   // rollout k on a second stream while the rollout leaves wave slots free (run_iterations)
   hipStream_t noise_stream = nullptr;
   hipEvent_t ev_buf_free = nullptr, ev_noise_ready = nullptr;
+  // ... and how the consumer of that noise is ordered behind it (DevParams::noise_flag): a sequence number stored by a
+  // one-thread kernel behind every generator on noise_stream; a rollout kernel that looks at it itself takes the place of
+  // the cross-stream wait, every other launch gets the wait (launch_plan.h: settle_noise_wait)
+  unsigned long long* noise_flag_dev = nullptr;
+  unsigned long long noise_flag_seq = 0;     // generators launched on noise_stream so far
+  unsigned long long noise_flag_expect = 0;  // ... the one whose noise the next rollout launch reads
+  bool noise_wait_pending = false;           // that launch has not been ordered behind its noise yet
+  // ... and how the generator is held back until the buffer it overwrites is free (DevParams::progress): launches that
+  // signal their start let a one-wave gate kernel on noise_stream take the place of ev_buf_free
+  unsigned long long* progress_dev = nullptr;
+  unsigned long long progress_seq = 0;       // launches that signal, so far
+  bool progress_signalled = false;           // the rollout launch of this iteration does
+  bool progress_capable_last = false;        // ... the previous one did: no event is recorded in front of the next
   // hipGraph replay of the iteration loop (mppi_planner_set_graph_replay): two iterations
   // (one round of the noise double buffer) captured once, replayed while nothing a kernel
   // argument carries has changed.  See run_iterations.

@@ -362,8 +362,34 @@ static int upload_instances(mppi_planner* p) {
 // Rollout and update launches go through the extended launch call: with p->kev_start / kev_stop
 // set (mppi_planner_time_kernels) the runtime stamps the dispatch's own begin / end -- what
 // rocprofv3 reads -- into those events; with both null it is an ordinary launch.
+// (A launch whose noise came from the second stream and that does not look at the generator's flag itself is ordered
+//  behind it by the event, here, at the last moment: which kernel runs is decided deep inside the launch paths.)
+static void settle_noise_wait(mppi_planner* p) {
+  if (!p->noise_wait_pending) return;
+  p->noise_wait_pending = false;
+  (void)hipStreamWaitEvent(p->stream, p->ev_noise_ready, 0);
+}
 #define MPPI_KLAUNCH(kernel, grid, block, lds, stream, ...) \
+  (settle_noise_wait(p), hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, p->kev_start, p->kev_stop, 0, __VA_ARGS__))
+// ... the kernels that do (DevParams::noise_flag; their DevParams through noise_flag_params)
+#define MPPI_KLAUNCH_WAITS_ITSELF(kernel, grid, block, lds, stream, ...) \
   hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, p->kev_start, p->kev_stop, 0, __VA_ARGS__)
+static DevParams noise_flag_params(mppi_planner* p, DevParams d) {
+  static const bool no_flag = getenv("MPPI_NO_NOISE_FLAG") != nullptr;  // developer switch (ablation): the event wait of rounds 1-5
+  if (p->noise_wait_pending && p->noise_flag_dev && !no_flag) {
+    d.noise_flag = p->noise_flag_dev;
+    d.noise_flag_expect = p->noise_flag_expect;
+    p->noise_wait_pending = false;
+  } else {
+    settle_noise_wait(p);
+  }
+  if (p->progress_dev && !no_flag && !p->graph_on) {  // (a captured launch would signal a stale number)
+    d.progress = p->progress_dev;
+    d.progress_value = ++p->progress_seq;
+    p->progress_signalled = true;
+  }
+  return d;
+}
 
 
 // ---- k_rollout_scan (rollout_scan_kernel.h): the time-parallel rollout of MPPI_MATH_FAST --------
@@ -996,8 +1022,8 @@ static int launch_windowed_or_general(mppi_planner* p, DevParams& d, const DetRe
       if (lds_win > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fused),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
-      MPPI_KLAUNCH(fused, dim3(ceil_div(N, block)), dim3(block), lds_win, p->stream, d, p->cells16,
-                         p->noise, p->u, p->costs, p->w_rel, p->tile_beta);
+      MPPI_KLAUNCH_WAITS_ITSELF(fused, dim3(ceil_div(N, block)), dim3(block), lds_win, p->stream, noise_flag_params(p, d), p->cells16,
+                                p->noise, p->u, p->costs, p->w_rel, p->tile_beta);
       char buf[200];
       snprintf(buf, sizeof(buf), "k_rollout_fused%s pow2res=%d waves_per_wg=%d window=%dx%d problems=%d",
                EXACT ? "" : "<one pass>", (int)pow2res, waves, d.win_rows, d.win_cols, p->inst_set ? p->B : 0);
@@ -1107,8 +1133,8 @@ static int launch_rollout_speed_map(mppi_planner* p, DevParams d) {
     if (lds_win > 64 * 1024)
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fused),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
-    MPPI_KLAUNCH(fused, dim3(ceil_div(N, 64 * waves)), dim3(64 * waves), lds_win, p->stream, d, p->cells16,
-                       p->noise, p->u, p->costs, p->w_rel, p->tile_beta);
+    MPPI_KLAUNCH_WAITS_ITSELF(fused, dim3(ceil_div(N, 64 * waves)), dim3(64 * waves), lds_win, p->stream, noise_flag_params(p, d), p->cells16,
+                              p->noise, p->u, p->costs, p->w_rel, p->tile_beta);
     char buf[200];
     snprintf(buf, sizeof(buf), "k_rollout_fused%s speed_map pow2res=%d waves_per_wg=%d window=%dx%d problems=%d",
              EXACT ? "" : "<one pass>", (int)pow2res, waves, d.win_rows, d.win_cols, p->inst_set ? p->B : 0);
@@ -1462,7 +1488,8 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
     want_next = false;
   } else if (have_noise) {
     p->noise_cur ^= 1;
-    if (p->noise_on_side_stream) HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_noise_ready, 0));
+    // (ordered behind the generator by the rollout launch itself: its flag, or the event -- settle_noise_wait)
+    if (p->noise_on_side_stream) p->noise_wait_pending = true;
     p->noise_on_side_stream = false;
     p->noise_virtual = false;
   } else {
@@ -1475,7 +1502,18 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
   p->next_noise_done = false;
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[1], p->stream));
   // the other noise buffer was last read by the previous update, which is behind us on this stream
-  if (want_next && side_stream_pays) HIP_TRY(hipEventRecord(p->ev_buf_free, p->stream));
+  // The generator of the next iteration's noise (second stream, below) must not start before the previous update -- the
+  // last reader of the buffer it overwrites -- is complete.  A rollout launch that signals its own start (DevParams::
+  // progress) provides that without anything in front of it on this stream; the event recorded here held the launch back
+  // by ~6 us.  Whether the coming launch signals is known once it has been made (the kernel is chosen deep inside the
+  // launch paths): the event is left out when the previous iteration's launch did, and made up for behind the launch
+  // (one iteration without overlap) should this one not.
+  p->progress_signalled = false;
+  bool buf_free_recorded = false;
+  if (want_next && side_stream_pays && (!p->progress_capable_last || p->graph_on)) {
+    HIP_TRY(hipEventRecord(p->ev_buf_free, p->stream));
+    buf_free_recorded = true;
+  }
   {
     TraceRange tr("mppi:rollout");
     // mppi_planner_time_kernels.  A loop with the second stream in it is timed by the kernels themselves (device
@@ -1490,6 +1528,7 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
     const int rc = launch_rollout(p, d);
     p->kev_start = p->kev_stop = nullptr;
     p->ktime_rollout_slot = nullptr;
+    settle_noise_wait(p);  // (a path that launched nothing: whatever follows on the stream still needs the noise)
     TRY(rc);
   }
   if (p->m_count > 1) {
@@ -1498,10 +1537,23 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
   }
   have_noise = p->next_noise_done;
   if (want_next && !have_noise && side_stream_pays) {
-    HIP_TRY(hipStreamWaitEvent(p->noise_stream, p->ev_buf_free, 0));
+    if (buf_free_recorded) {
+      HIP_TRY(hipStreamWaitEvent(p->noise_stream, p->ev_buf_free, 0));
+    } else if (p->progress_signalled) {
+      hipLaunchKernelGGL(k_wait_progress, dim3(1), dim3(64), 0, p->noise_stream, p->progress_dev, p->progress_seq);
+      HIP_TRY(hipGetLastError());
+    } else {  // (neither: ordered behind the rollout launch itself)
+      HIP_TRY(hipEventRecord(p->ev_buf_free, p->stream));
+      HIP_TRY(hipStreamWaitEvent(p->noise_stream, p->ev_buf_free, 0));
+    }
     TraceRange tr("mppi:noise_ahead");
     TRY(launch_noise(p, p->noise_buf[p->noise_cur ^ 1], p->noise_stream));
     p->used_side_stream = true;
+    if (p->noise_flag_dev && !p->graph_on) {
+      p->noise_flag_expect = ++p->noise_flag_seq;
+      hipLaunchKernelGGL(k_set_noise_flag, dim3(1), dim3(1), 0, p->noise_stream, p->noise_flag_dev, p->noise_flag_expect);
+      HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(p->ev_noise_ready, p->noise_stream));
     have_noise = p->noise_on_side_stream = true;
     if (p->graph_on) {
@@ -1511,6 +1563,7 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
       p->noise_on_side_stream = false;
     }
   }
+  p->progress_capable_last = p->progress_signalled;
   p->next_noise_wanted = false;
   p->scan_gen_now = false;
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[2], p->stream));

@@ -534,6 +534,8 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   for (hipEvent_t e : p->ktime_events)
     if (e) (void)hipEventDestroy(e);
   dev_free(p->ktime_dev);
+  dev_free(p->noise_flag_dev);
+  dev_free(p->progress_dev);
   if (p->spec_fail_host) (void)hipHostFree(p->spec_fail_host);
   dev_free(p->loop_state);
   dev_free(p->loop_xhist);
@@ -570,6 +572,10 @@ static int planner_alloc(mppi_planner* p) {
   HIP_TRY(hipStreamCreateWithFlags(&p->noise_stream, hipStreamNonBlocking));
   HIP_TRY(hipEventCreateWithFlags(&p->ev_buf_free, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&p->ev_noise_ready, hipEventDisableTiming));
+  TRY(dev_alloc(&p->noise_flag_dev, (size_t)1));
+  HIP_TRY(hipMemset(p->noise_flag_dev, 0, sizeof(unsigned long long)));
+  TRY(dev_alloc(&p->progress_dev, (size_t)1));
+  HIP_TRY(hipMemset(p->progress_dev, 0, sizeof(unsigned long long)));
   HIP_TRY(hipEventCreate(&p->ev_begin));
   HIP_TRY(hipEventCreate(&p->ev_end));
   for (auto& e : p->ev_stage) HIP_TRY(hipEventCreate(&e));

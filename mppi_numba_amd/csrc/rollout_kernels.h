@@ -83,6 +83,20 @@ struct DevParams {
   // whose loop runs on two streams and cannot be timed with events (see there)
   unsigned long long* ktime;
   int ktime_waves;
+  // Round 6: this launch's noise was generated on the planner's second stream.  Rounds 1-5 ordered the two with a
+  // cross-stream wait in front of the launch -- a barrier packet that cost the loop ~6 us per iteration at N = 65536
+  // although the generator had finished long before (profiles/r06_ns_notes.md).  Instead a one-thread kernel behind
+  // the generator stores its sequence number here, and the rollout's waves look at it before their first noise load:
+  // in the steady state one load.  nullptr: ordered by the stream (or by the event wait, launch_plan.h: settle_noise_wait).
+  const unsigned long long* noise_flag;
+  unsigned long long noise_flag_expect;
+  // ... and the other direction: the generator of the NEXT iteration's noise may start once this launch has (everything
+  // in front of it on the stream -- the previous update, the last reader of the buffer the generator overwrites -- is
+  // complete then).  The first wave of the launch stores `progress_value` here; a one-wave gate kernel in front of the
+  // generator on the second stream waits for it (k_wait_progress).  Rounds 1-5: an event recorded in front of this
+  // launch -- a marker that held the launch back by ~6 us (profiles/r06_ns_notes.md: timeline).
+  unsigned long long* progress;
+  unsigned long long progress_value;
 };
 
 // What differs between the problems of a batched handle (mppi_planner_set_instances).
@@ -92,6 +106,44 @@ struct BatchInst {
   int win_r0, win_c0;  // the LDS window is planned around each start state
   int pad;
 };
+
+// every wave, before its first load of the noise (see DevParams::noise_flag)
+__device__ __forceinline__ void wait_for_noise(const DevParams& P) {
+  if (P.noise_flag == nullptr) return;
+  // (wave-uniform: lane 0's look, broadcast)
+  if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(P.noise_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.noise_flag_expect)))
+    return;  // the generator had finished before this kernel started: the kernel's own start made its stores visible
+  for (unsigned int polls = 0;; ++polls) {
+    __builtin_amdgcn_s_sleep(16);
+    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(P.noise_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.noise_flag_expect)))
+      break;
+    // (the generator was enqueued before this launch and needs no resource this launch holds: seconds of waiting mean
+    //  a broken device, not a slow one)
+    if (polls > (1u << 26)) __builtin_trap();
+  }
+  // the generator finished while this kernel was running: nothing of its output may be served from this kernel's caches
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+__global__ void k_set_noise_flag(unsigned long long* flag, unsigned long long value) {
+  __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// first thing in a launch that carries DevParams::progress
+__device__ __forceinline__ void signal_progress(const DevParams& P) {
+  if (P.progress && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(P.progress, P.progress_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wave on the second stream, in front of the generator: returns when the main stream's launch number `value` has
+// started.  Bounded (a main stream that never gets there is an error the host reports elsewhere; the generator then
+// simply runs).
+__global__ __launch_bounds__(64) void k_wait_progress(const unsigned long long* progress, unsigned long long value) {
+  for (unsigned int polls = 0; polls < (1u << 24); ++polls) {
+    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= value))) return;
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
 
 // (one slot per wave, plain stores: atomics of a few thousand waves on one address took longer than the kernel)
 __device__ __forceinline__ void ktime_begin(const DevParams& P) {
@@ -413,6 +465,7 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
                                 float* __restrict__ costs, float* __restrict__ w_rel,
                                 float* __restrict__ tile_beta) {
   extern __shared__ double2 uos[];
+  signal_progress(P);
   ktime_begin(P);
   // batched handle: the waves of a workgroup belong to one problem (host: blockDim/64 divides inst_tiles)
   u = select_instance(P, u, P.inst ? (int)(blockIdx.x * (blockDim.x >> 6)) / P.inst_tiles : 0);
@@ -435,6 +488,7 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
   const bool live = n < N;
   const int nn = live ? n : N - 1;
   const float2* col = noise + tile_index(0, nn, T);  // this lane's column; rows are 64 apart
+  wait_for_noise(P);
 
   float x = P.x0, y = P.y0, th = P.th0, cost = 0.0f;
   [[maybe_unused]] float cc32 = 0.0f;
