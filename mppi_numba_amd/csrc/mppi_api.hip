@@ -1550,14 +1550,15 @@ extern "C" int mppi_planner_time_kernels(mppi_planner* p, mppi_tdm* lin, mppi_td
   // (the one-wave-per-tile rollout kernels: at most a whole workgroup of 16 waves beyond the tiles; k_update_rows:
   //  16 waves per row and problem)
   p->ktime_waves = std::max(ceil_div(p->n_local, 64) + 16, p->cfg.num_steps * p->B * (kRowThreads / 64) + 16);
-  const size_t stamp_words = 4 * (size_t)p->ktime_waves * (size_t)reps;
+  if (p->ktime_use_stamps) reps = std::min(reps, 64);  // (32 bytes per wave and launch)
+  const size_t stamp_words = p->ktime_use_stamps ? 4 * (size_t)p->ktime_waves * (size_t)reps : 0;  // (a loop timed by events needs none)
   if (stamp_words > p->ktime_dev_capacity) {
     dev_free(p->ktime_dev);
     p->ktime_dev_capacity = 0;
     TRY(dev_alloc(&p->ktime_dev, stamp_words));
     p->ktime_dev_capacity = stamp_words;
   }
-  HIP_TRY(hipMemsetAsync(p->ktime_dev, 0, sizeof(unsigned long long) * stamp_words, p->stream));  // (0: this wave did not stamp)
+  if (stamp_words) HIP_TRY(hipMemsetAsync(p->ktime_dev, 0, sizeof(unsigned long long) * stamp_words, p->stream));  // (0: this wave did not stamp)
   p->ktime_index = 0;
   p->ktime_markers = false;
   const int rc = run_iterations(p, lin, ang, reps, /*timed=*/false);

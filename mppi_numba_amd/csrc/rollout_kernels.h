@@ -407,8 +407,11 @@ __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
     if (__all(st.done)) break;
   }
   if (!__all(st.done))
-    for (int t = t0; t < T; ++t)
-      map_step<KIND, EXACT, BOUNDED, LDSMAP>(P, cells, risk, lds_map, us[t], e_cur[t - t0], st);
+    for (int t = t0; t < T; ++t) {  // (batch registers shifted down, not indexed: see k_rollout_fused)
+      map_step<KIND, EXACT, BOUNDED, LDSMAP>(P, cells, risk, lds_map, us[t], e_cur[0], st);
+#pragma unroll
+      for (int j = 0; j + 1 < kNoiseBatch; ++j) e_cur[j] = e_cur[j + 1];
+    }
 
   float cost = st.cost;
   // terminal cost (mppi.py:26-28, 1005)
@@ -565,8 +568,14 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
     for (int j = 0; j < kNoiseBatch; ++j) e_cur[j] = e_nxt[j];
     if (!ONEPASS && __all(done)) break;  // (ONEPASS: the control cost needs every step's noise)
   }
+  // (the horizon's last, shorter batch: the batch registers shifted down one per step -- indexing them with t - t0
+  //  put both batches into scratch memory, seven scratch accesses per batch in the loop above as well: round 6)
   if (ONEPASS || !__all(done))
-    for (int t = t0; t < T; ++t) step(us[t], e_cur[t - t0], t);
+    for (int t = t0; t < T; ++t) {
+      step(us[t], e_cur[0], t);
+#pragma unroll
+      for (int j = 0; j + 1 < kNoiseBatch; ++j) e_cur[j] = e_cur[j + 1];
+    }
 
   // terminal cost, then the control cost of all T steps (mppi.py:1005-1009): the float32-rounded
   // accumulation is sequential, loads and products are batched
