@@ -505,25 +505,32 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
   const int win_pitch_bytes = (SPEED ? 4 : 2) * P.win_cols;
   const char* lds_bytes = reinterpret_cast<const char*>(lds_map);
 
-  auto step = [&](float2 ut, float2 e, [[maybe_unused]] int t) {
+  // the cell of (px, py) in the LDS window: the request only -- the value is looked at one step later
+  auto lookup = [&](float px, float py) -> uint32_t {
     int xi, yi;
     if (POW2RES) {  // res is a power of two: see cell_coord_pow2
-      xi = cell_coord_pow2(x, P.xlo, P.inv_res, win_c0f, win_last_col);
-      yi = cell_coord_pow2(y, P.ylo, P.inv_res, win_r0f, win_last_row);
+      xi = cell_coord_pow2(px, P.xlo, P.inv_res, win_c0f, win_last_col);
+      yi = cell_coord_pow2(py, P.ylo, P.inv_res, win_r0f, win_last_row);
     } else {
-      xi = clamp_index(floordiv_to_int(x - P.xlo, P.res, P.inv_res) - P.win_c0, P.win_cols);
-      yi = clamp_index(floordiv_to_int(y - P.ylo, P.res, P.inv_res) - P.win_r0, P.win_rows);
+      xi = clamp_index(floordiv_to_int(px - P.xlo, P.res, P.inv_res) - P.win_c0, P.win_cols);
+      yi = clamp_index(floordiv_to_int(py - P.ylo, P.res, P.inv_res) - P.win_r0, P.win_rows);
     }
-    uint32_t c16;
+    // 32-bit cell (speed-map mode): the 16 bits below + the risk traction byte
+    if (SPEED) return *reinterpret_cast<const uint32_t*>(lds_bytes + (__mul24(yi, win_pitch_bytes) + (xi << 2)));
+    return *reinterpret_cast<const uint16_t*>(lds_bytes + (__mul24(yi, win_pitch_bytes) + (xi << 1)));
+  };
+  // Round 6: the chain of a step is  cell -> traction -> x, y -> next cell, and its LDS gather (64 lanes, bank conflicts:
+  // ~100+ cycles) was waited for a handful of instructions after it was issued -- with ONE wave per SIMD at N = 65536
+  // nothing else covers it.  As in the pipelined kernels' state role the lookup of step t + 1 is requested the moment
+  // x, y of step t exist, and the rotation and the whole cost side of step t run in its shadow.
+  uint32_t cell_now = lookup(x, y);
+  auto step = [&](float2 ut, float2 e, [[maybe_unused]] int t) {
+    const uint32_t c16 = cell_now;  // the cell this step STARTS in
     double step_time = dt64;
     if (SPEED) {
-      // 32-bit cell: the 16 bits below + the risk traction byte; time per step = dt over the
-      // risk-aware effective speed (mppi.py:1095-1096)
-      c16 = *reinterpret_cast<const uint32_t*>(lds_bytes + (__mul24(yi, win_pitch_bytes) + (xi << 2)));
+      // time per step = dt over the risk-aware effective speed (mppi.py:1095-1096)
       const double eff = fma(P.lin_ratio, (double)(int)(int8_t)(c16 >> 16), P.lin_lo);
       step_time = dt64 / (eff + 1e-6);
-    } else {
-      c16 = *reinterpret_cast<const uint16_t*>(lds_bytes + (__mul24(yi, win_pitch_bytes) + (xi << 1)));
     }
     const double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), P.lin_lo);
     const double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), P.ang_lo);
@@ -532,6 +539,8 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
     x = (float)fma(vtr, qv * c, x64);
     y = (float)fma(vtr, qv * s, y64);
     th = (float)fma(wtr, qw, th64);
+    cell_now = lookup(x, y);
+    __builtin_amdgcn_sched_barrier(0);  // ---- everything below runs while the lookup is in flight
     x64 = (double)x;
     y64 = (double)y;
     const double th_new = (double)th;
@@ -553,6 +562,7 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
       reached = reached || (act && hit);
       done = done || hit;
     }
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   float2 e_cur[kNoiseBatch], e_nxt[kNoiseBatch];
