@@ -1550,7 +1550,8 @@ extern "C" int mppi_planner_time_kernels(mppi_planner* p, mppi_tdm* lin, mppi_td
   // (the one-wave-per-tile rollout kernels: at most a whole workgroup of 16 waves beyond the tiles; k_update_rows:
   //  16 waves per row and problem)
   p->ktime_waves = std::max(ceil_div(p->n_local, 64) + 16, p->cfg.num_steps * p->B * (kRowThreads / 64) + 16);
-  if (p->ktime_use_stamps) reps = std::min(reps, 64);  // (32 bytes per wave and launch)
+  if (p->ktime_use_stamps)  // (32 bytes per wave and launch: at most ~64 MB of stamps)
+    reps = std::max(8, std::min(reps, (int)std::min<size_t>(64, ((size_t)64 << 20) / (32 * (size_t)p->ktime_waves))));
   const size_t stamp_words = p->ktime_use_stamps ? 4 * (size_t)p->ktime_waves * (size_t)reps : 0;  // (a loop timed by events needs none)
   if (stamp_words > p->ktime_dev_capacity) {
     dev_free(p->ktime_dev);

@@ -107,22 +107,27 @@ struct BatchInst {
   int pad;
 };
 
-// every wave, before its first load of the noise (see DevParams::noise_flag)
+// every wave of a workgroup, before its first load of the noise (see DevParams::noise_flag).  Every wave looks once; when
+// the generator has not finished yet ONE wave per workgroup polls -- thousands of waves on one word would be a hot spot of
+// their own -- and the others wait at the barrier.
 __device__ __forceinline__ void wait_for_noise(const DevParams& P) {
-  if (P.noise_flag == nullptr) return;
-  // (wave-uniform: lane 0's look, broadcast)
-  if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(P.noise_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.noise_flag_expect)))
-    return;  // the generator had finished before this kernel started: the kernel's own start made its stores visible
-  for (unsigned int polls = 0;; ++polls) {
-    __builtin_amdgcn_s_sleep(16);
-    if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(P.noise_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.noise_flag_expect)))
-      break;
-    // (the generator was enqueued before this launch and needs no resource this launch holds: seconds of waiting mean
-    //  a broken device, not a slow one)
-    if (polls > (1u << 26)) __builtin_trap();
+  if (P.noise_flag == nullptr) return;  // (uniform over the launch)
+  const bool ready = __builtin_amdgcn_readfirstlane(
+      (int)(__hip_atomic_load(P.noise_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.noise_flag_expect)) != 0;
+  if (!ready && threadIdx.x < 64) {
+    for (unsigned int polls = 0;; ++polls) {
+      __builtin_amdgcn_s_sleep(32);
+      if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(P.noise_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.noise_flag_expect)))
+        break;
+      // (the generator was enqueued before this launch and needs no resource this launch holds: seconds of waiting mean
+      //  a broken device, not a slow one)
+      if (polls > (1u << 25)) __builtin_trap();
+    }
   }
+  __syncthreads();
   // the generator finished while this kernel was running: nothing of its output may be served from this kernel's caches
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // (a wave that saw the flag at its first look needs nothing: the kernel's own start made those stores visible)
+  if (!ready) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 __global__ void k_set_noise_flag(unsigned long long* flag, unsigned long long value) {
