@@ -63,7 +63,7 @@ def synthetic_world(workload, rng):
     for m in (obstacle, unknown):
         m[12:20, 12:20] = 0
         m[236:244, 236:244] = 0
-    if workload in ("c2", "ns"):
+    if workload in ("c2", "ns", "c2l"):
         bins = 2
         pmf = np.zeros((bins, rows, cols), dtype=np.int8)
         pmf[-1] = 100  # nominal traction (README.md:136-151 recipe)
@@ -118,6 +118,9 @@ WORKLOADS = {
     # north_star's own target shape on ONE GPU: the denominator of "scaling 1 -> 8 GPUs at N=65536, T=100" 
     "ns": dict(n=65536, t=100, m=1, mode=dict(use_det_dynamics=True),
                label="Unicycle MPPI det-dyn, N=65536/GPU, T=100, 256x256 nominal traction grid (north_star's shape on one GPU)"),
+    # C2's map at twice the horizon (no BASELINE configuration: the study of the kernel families, profiles/r06_families.md)
+    "c2l": dict(n=8192, t=200, m=1, mode=dict(use_det_dynamics=True),
+                label="Unicycle MPPI det-dyn, N=8192/GPU, T=200, 256x256 nominal traction grid (kernel-family study)"),
     # the C2 shape on maps the time-parallel kernel's assumption does not hold on
     "c2s": dict(n=8192, t=100, m=1, mode=dict(use_det_dynamics=True),
                 label="Unicycle MPPI det-dyn, N=8192/GPU, T=100, 256x256 SEMANTIC map: 4 terrain types in patches of 4-16 m"),
@@ -779,7 +782,7 @@ def main():
     kernel_name = planner.last_rollout_kernel().split(" ")[0]
     fused = kernel_name.startswith("k_rollout_scan") and "noise=in-kernel" in planner.last_rollout_kernel()
     bytes_iter, bytes_roll = algorithmic_bytes(w, n_local * max(1, problems), rp, cp,
-                                               rollout_writes_noise=(kernel_name in ("k_rollout_pipe", "k_rollout_spec", "k_rollout_deep")),
+                                               rollout_writes_noise=(kernel_name in ("k_rollout_pipe",)),
                                                fused=fused)
     traffic = None
     try:  # HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
@@ -851,7 +854,7 @@ def main():
             {"rollout_plus_update_us": kernel_us[0] + kernel_us[1], "step_us": 1e3 * ms_per_step,
              "ok": bool(kernel_us[0] + kernel_us[1] <= 1.05 * 1e3 * max(ms_per_step, float(np.median(region_ms))))},
         "roofline": {"bound": "hbm",
-                     "kernel": kernel_name + (" (rollout + next iteration's noise)" if kernel_name in ("k_rollout_pipe", "k_rollout_spec", "k_rollout_deep") else
+                     "kernel": kernel_name + (" (rollout + next iteration's noise)" if kernel_name in ("k_rollout_pipe",) else
                                               " (noise + rollout + per-tile update sums)" if fused else ""),
                      "fused": fused,
                      "fused_note": ("the launch samples the noise, rolls out and reduces the update per tile; the noise never "

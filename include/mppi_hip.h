@@ -291,13 +291,13 @@ int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity)
  * float32 tolerance only -- and so does whatever else decides which kernel runs there: N, the map
  * (a failed traction vote re-runs a tile sequentially; a map that keeps failing switches the
  * speculative kernels off until it changes). */
-#define MPPI_DEBUG_NO_SPEC_KERNEL 1  /* latency regime: k_rollout_pipe instead of k_rollout_spec */
+#define MPPI_DEBUG_NO_SPEC_KERNEL 1  /* retired (round 6: k_rollout_spec removed, profiles/r06_families.md); accepted, no effect */
 #define MPPI_DEBUG_NO_SPECULATION 2  /* the speculative kernels on their exact schedule from the first step */
-#define MPPI_DEBUG_NO_DEEP_KERNEL 4  /* one tile per CU: k_rollout_spec instead of k_rollout_deep */
+#define MPPI_DEBUG_NO_DEEP_KERNEL 4  /* retired (round 6: k_rollout_deep removed); accepted, no effect */
 #define MPPI_DEBUG_CC_GLOBAL 8       /* control-cost products in the global scratch array even when LDS has room */
 #define MPPI_DEBUG_KEEP_SPECULATING 16 /* keep the speculative kernels on a map where their tiles keep falling back */
 /* MPPI_MATH_FAST, the time-parallel rollout (k_rollout_scan): */
-#define MPPI_DEBUG_NO_SCAN_KERNEL 32     /* the float32 five-stage pipeline (k_rollout_deep<f32>) instead */
+#define MPPI_DEBUG_NO_SCAN_KERNEL 32     /* not the time-parallel kernels: k_rollout_pipe / k_rollout_fused / k_rollout_map instead */
 #define MPPI_DEBUG_SCAN_READ_NOISE 64    /* the iteration loop stores its noise and the kernel reads it (as the stage-level calls do) */
 #define MPPI_DEBUG_SCAN_FULL_TILES 128   /* workgroups of 64 rollouts (one lane per rollout) instead of 32 (two) */
 #define MPPI_DEBUG_NO_FOLDED_APPLY 256   /* sharded handle: every iteration's update by its own k_apply launch, never by the next rollout launch */

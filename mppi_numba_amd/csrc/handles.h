@@ -215,7 +215,7 @@ struct mppi_planner {
   float last_elapsed_ms = 0.f;
   bool elapsed_pending = false;
   int last_iterations = 0;
-  // Speculative rollout kernels (k_rollout_deep / k_rollout_spec) on a map where the traction
+  // Speculative rollout kernels (the time-parallel k_rollout_scan*) on a map where the traction
   // changes from cell to cell: every tile fails its vote and re-runs on the exact schedule, slower
   // than launching k_rollout_pipe in the first place (N = 8192, T = 200 over a CVaR-bin map: 85 vs
   // 49 us).  The kernels count failed tiles in a host-mapped word; whenever the host has

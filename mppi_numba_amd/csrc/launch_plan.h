@@ -286,8 +286,7 @@ static bool plan_lds_window(mppi_planner* p, DevParams& d, size_t* lds_bytes) {
     c1 = std::min((long)p->pitch16, (std::min((long)d.cols, xi0 + reach + 1) + 7) / 8 * 8);
     if (r1 > r0 && c1 > c0) bytes = (size_t)(r1 - r0) * (size_t)(c1 - c0) * cell_bytes;
   }
-  // (either way the rollouts spread at most step_cells per step: k_rollout_spec copies the window in
-  //  bands of rows as they go)
+  // (either way the rollouts spread at most step_cells per step)
   d.win_step_cells = std::isfinite(reach_m) ? (float)((double)a.dt * vmax * trmax / (double)a.res) : 0.0f;
   d.win_progressive = std::isfinite(reach_m) ? 1 : 0;
   if (bytes < whole) {  // the reach window is smaller: less to copy, more LDS left
@@ -468,13 +467,13 @@ static bool scan_plan_compute(const mppi_planner* p, ScanPlan* out) {
   plan.direct = direct;
   plan.exact = p->cfg.math == MPPI_MATH_EXACT;
   plan.chunk_waves = ceil_div(T, 8);
-  if (plan.exact && plan.chunk_waves > ScanExactLds::kMaxChunkWaves) return false;  // (T <= 104; beyond, k_rollout_deep)
+  if (plan.exact && plan.chunk_waves > ScanExactLds::kMaxChunkWaves) return false;  // (T <= 104; beyond, k_rollout_pipe)
   plan.waves = plan.exact ? ScanExactLds::waves(plan.chunk_waves) : plan.chunk_waves;
   if (plan.waves > 16) return false;
   plan.tile = (!plan.exact && (p->debug_flags & MPPI_DEBUG_SCAN_FULL_TILES)) ? 64 : 32;
   // one round of workgroups over the CUs: beyond that the kernels with one wave per tile win (a
   // 32-rollout workgroup lasts ~10 us whatever N is: N = 16384 would be two rounds against 18 us
-  // of k_rollout_deep, N = 65536 eight against 78 us of k_rollout_fused)
+  // of k_rollout_pipe, N = 65536 eight against 78 us of k_rollout_fused)
   if (ceil_div(p->n_local, plan.tile) > p->num_cus) return false;
   plan.lds = plan.exact ? ScanExactLds::total(plan.chunk_waves)
                         : (plan.tile == 64 ? ScanLds<64>::total(plan.waves) : ScanLds<32>::total(plan.waves));
@@ -579,7 +578,7 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
     gen_job = make_noise_job(p, nullptr);  // (advances the Philox epoch: this iteration's block)
   } else {
     // a loop that stores its noise (debug switch; the stage-level calls): CUs without a workgroup
-    // produce the next iteration's, as in k_rollout_deep.  (Producing it in the launch's own tail, by
+    // produce the next iteration's, as in k_rollout_pipe.  (Producing it in the launch's own tail, by
     // the waves that idle while one wave accumulates the costs, was measured: the stage gained is lost
     // again to the slower accumulation and the noise reads -- profiles/r03_scan_notes.md.)
     static const bool no_fused_noise = getenv("MPPI_NO_FUSED_NOISE") != nullptr;  // developer switch
@@ -708,14 +707,14 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
 }
 
 // ---- deterministic-dynamics mode: which rollout kernel runs ------------------
-// Decided per launch from measurements (profiles/r01_ablation.md, r02_stamps.md, r03_scan_notes.md):
-//   MPPI_MATH_FAST, 16-bit cells, T <= 128      k_rollout_scan   (time-parallel; launch_scan above)
-//   every tile of 64 rollouts can have a CU     k_rollout_deep   (five-stage speculative pipeline)
-//   up to two tiles per CU                      k_rollout_spec   (four-wave speculative pipeline)
-//   up to three                                 k_rollout_pipe   (exact three-wave schedule)
+// Decided per launch from measurements (profiles/r06_families.md; history: r01_ablation.md, r02_stamps.md, r03_scan_notes.md):
+//   every tile of 32 rollouts a CU, T <= 104    k_rollout_scan_exact / k_rollout_scan (time-parallel; launch_scan above)
+//   one or two tiles of 64 per CU               k_rollout_pipe   (exact three-wave schedule)
 //   beyond (throughput regime)                  k_rollout_fused  (one wave per tile, 4..16 per CU)
 //   no LDS window / no incremental trig         k_rollout_map    (general)
-// Each try_launch_* plans its LDS, launches when its regime applies and says so.
+// (Rounds 2-5 had two speculative pipelines between the first two, k_rollout_deep and k_rollout_spec; re-measured at the
+//  end of round 6 against the exact pipeline and the throughput kernel on one box neither won by 5 % anywhere it was still
+//  selected -- k_rollout_spec lost by a factor of two at T = 200 -- and both were removed: profiles/r06_families.md.)
 struct DetRegime {
   bool have_window;       // the 16-bit cell window reachable within the horizon fits in LDS
   size_t lds_win;         // ... bytes of {staged controls, window}
@@ -723,195 +722,13 @@ struct DetRegime {
   bool pow2res;           // resolution is a power of two: four-instruction cell coordinates
   bool pow2res_unclamped; // ... and no rollout can leave the map: the exact schedule's address without a clamp (unclamped_lookup_ok)
   bool rot_ok_fast;       // ... the same bound under MPPI_MATH_FAST (k_rollout_fused<one pass>)
-  bool fast_deep_ok;      // MPPI_MATH_FAST: |theta| stays inside v_sin_f32's range
-  bool keep_speculating;  // the map has not (yet) proved the traction assumption a loss
 };
-
-template <bool EXACT>
-static int try_launch_deep(mppi_planner* p, DevParams& d, const DetRegime& r, bool* launched) {
-  *launched = false;
-  const int N = p->n_local, T = p->cfg.num_steps;
-  [[maybe_unused]] const bool have_window = r.have_window, rot_ok = r.rot_ok, pow2res = r.pow2res_unclamped,
-                              fast_deep_ok = r.fast_deep_ok, keep_speculating = r.keep_speculating;
-  [[maybe_unused]] const size_t lds_win = r.lds_win;
-  static const bool no_pipe = getenv("MPPI_NO_PIPE") != nullptr;  // developer switch (ablation)
-  static const bool no_deep = getenv("MPPI_NO_DEEP") != nullptr;  // developer switch (ablation)
-  if (have_window && (EXACT ? rot_ok : fast_deep_ok) && !no_pipe && !no_deep && keep_speculating &&
-      !(p->debug_flags & (MPPI_DEBUG_NO_SPEC_KERNEL | MPPI_DEBUG_NO_DEEP_KERNEL)) &&
-      ceil_div(N, 64) <= p->num_cus) {
-    // five-stage speculative pipeline, one tile per CU (rollout_deep_kernel.h)
-    const size_t map_bytes = lds_win - sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);
-    const size_t Tp = ((size_t)T + 7) & ~(size_t)7;
-    const size_t head = sizeof(double2) * (Tp + Tp / 2);
-    const size_t budget = (size_t)p->lds_per_cu - 1024;
-    const size_t cc_bytes = Tp * 64 * sizeof(double);
-    // the exact re-execution path (pipe_tile_body<8>) lives in the same allocation
-    const size_t exact_need = lds_win + (size_t)PipeRing<8>::kBytesPerPair;
-    int chunk = 0;
-    auto ring_size = [](int c) {
-      return c == 8 ? (size_t)DeepRing<8>::kBytes : c == 4 ? (size_t)DeepRing<4>::kBytes : (size_t)DeepRing<2>::kBytes;
-    };
-    static const int forced_chunk = getenv("MPPI_DEEP_CHUNK") ? atoi(getenv("MPPI_DEEP_CHUNK")) : 0;  // developer switch
-    for (int cnd : {8, 4, 2})
-      if (head + map_bytes + ring_size(cnd) <= budget && (!forced_chunk || cnd <= forced_chunk)) { chunk = cnd; break; }
-    // (chunks of 8 with the control-cost products in LDS, else of 4 with them in LDS, else as found)
-    if (chunk == 8 && head + map_bytes + ring_size(8) + cc_bytes > budget &&
-        head + map_bytes + ring_size(4) + cc_bytes <= budget)
-      chunk = 4;
-    if (chunk > 0 && exact_need <= budget) {
-      const size_t rings = ring_size(chunk);
-      const size_t spec_need = head + map_bytes + rings;
-      const bool cc_lds = spec_need + cc_bytes <= budget && exact_need + (size_t)T * 64 * sizeof(double) <= budget &&
-                          !(p->debug_flags & MPPI_DEBUG_CC_GLOBAL);
-      const size_t lds_total = std::max(spec_need + (cc_lds ? cc_bytes : 0),
-                                        exact_need + (cc_lds ? (size_t)T * 64 * sizeof(double) : 0));
-      const int grid = ceil_div(N, 64);
-      NoiseJob next_job;
-      memset(&next_job, 0, sizeof(next_job));
-      int extra = 0;
-      static const bool no_fused_noise = getenv("MPPI_NO_FUSED_NOISE") != nullptr;  // developer switch
-      if (p->next_noise_wanted && grid < p->num_cus && !no_fused_noise) {  // (no spare CU otherwise: in line)
-        extra = p->num_cus - grid;
-        next_job = make_noise_job(p, p->noise_buf[p->noise_cur ^ 1]);
-        p->next_noise_done = true;
-      }
-      if (!cc_lds && !p->cc_scratch) TRY(dev_alloc(&p->cc_scratch, (size_t)ceil_div(N, 64) * 64 * T));
-      const int speculate = (p->debug_flags & MPPI_DEBUG_NO_SPECULATION) ? 0 : 1;
-      if (speculate) p->spec_launches += 1;
-#define MPPI_LAUNCH_DEEP(CH, P2, CL)                                                                   \
-  do {                                                                                                \
-auto kern = k_rollout_deep<CH, P2, CL, !EXACT>;                                                   \
-if (lds_total > 64 * 1024)                                                                        \
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));       \
-MPPI_KLAUNCH(kern, dim3(grid + extra), dim3(64 * kDeepWaves), lds_total, p->stream, d,      \
-                   p->cells16, p->noise, p->u, p->costs, p->w_rel, p->tile_beta, p->cc_scratch,   \
-                   (int)map_bytes, grid, speculate, next_job);                                     \
-  } while (0)
-#define MPPI_LAUNCH_DEEP_C(P2, CL)            \
-  do {                                        \
-if (chunk == 8) MPPI_LAUNCH_DEEP(8, P2, CL);      \
-else if (chunk == 4) MPPI_LAUNCH_DEEP(4, P2, CL); \
-else MPPI_LAUNCH_DEEP(2, P2, CL);                 \
-  } while (0)
-      if (pow2res && cc_lds) MPPI_LAUNCH_DEEP_C(true, true);
-      else if (pow2res) MPPI_LAUNCH_DEEP_C(true, false);
-      else if (cc_lds) MPPI_LAUNCH_DEEP_C(false, true);
-      else MPPI_LAUNCH_DEEP_C(false, false);
-#undef MPPI_LAUNCH_DEEP_C
-#undef MPPI_LAUNCH_DEEP
-      char buf[320];
-      snprintf(buf, sizeof(buf),
-               "k_rollout_deep%s chunk=%d pow2res=%d cc_lds=%d speculate=%d window=%dx%d@(%d,%d) lds=%zu "
-               "noise_blocks=%d problems=%d",
-               EXACT ? "" : "<f32>", chunk, (int)pow2res, (int)cc_lds, speculate, d.win_rows, d.win_cols, d.win_r0, d.win_c0, lds_total,
-               extra, p->inst_set ? p->B : 0);
-      p->last_rollout = buf;
-      p->tile_packets_fresh = true;
-      *launched = true;
-      return MPPI_OK;
-    }
-  }
-  return MPPI_OK;
-}
-
-template <bool EXACT>
-static int try_launch_spec(mppi_planner* p, DevParams& d, const DetRegime& r, bool* launched) {
-  *launched = false;
-  const int N = p->n_local, T = p->cfg.num_steps;
-  [[maybe_unused]] const bool have_window = r.have_window, rot_ok = r.rot_ok, pow2res = r.pow2res_unclamped,
-                              fast_deep_ok = r.fast_deep_ok, keep_speculating = r.keep_speculating;
-  [[maybe_unused]] const size_t lds_win = r.lds_win;
-  static const bool no_pipe = getenv("MPPI_NO_PIPE") != nullptr;  // developer switch (ablation)
-  static const bool no_spec = getenv("MPPI_NO_SPEC") != nullptr;  // developer switch (ablation)
-  if (have_window && rot_ok && !no_pipe && !no_spec && keep_speculating &&
-      !(p->debug_flags & MPPI_DEBUG_NO_SPEC_KERNEL)) {
-    // speculative 4-wave pipeline (rollout_spec_kernel.h): same regime as the pipelined kernel below
-    const size_t map_bytes = lds_win - sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);
-    // (this kernel pads the staged controls to a multiple of 8 steps)
-    const size_t Tp = ((size_t)T + 7) & ~(size_t)7;
-    const size_t lds_win = map_bytes + sizeof(double2) * (Tp + Tp / 2);
-    int tiles_wg = ceil_div(ceil_div(N, 64), p->num_cus);
-    if (tiles_wg < 1) tiles_wg = 1;
-    if (tiles_wg > 3) tiles_wg = 3;  // (three tiles per CU: the pipelined kernel below)
-    if (p->inst_set) while (p->inst_tiles % tiles_wg != 0) --tiles_wg;
-    const size_t budget = (size_t)p->lds_per_cu - 1024;
-    auto ring_bytes = [&](int chunk) {
-      const size_t per_tile = chunk == 8 ? SpecRing<8>::kBytesPerTile : chunk == 4 ? SpecRing<4>::kBytesPerTile
-                                                                                  : SpecRing<2>::kBytesPerTile;
-      return (size_t)tiles_wg * per_tile + 16;
-    };
-    int chunk = 0;
-    for (;;) {
-      for (int cnd : {8, 4, 2})
-        if (lds_win + ring_bytes(cnd) <= budget) { chunk = cnd; break; }
-      if (chunk > 0 || tiles_wg == 1) break;
-      --tiles_wg;
-      if (p->inst_set) while (p->inst_tiles % tiles_wg != 0) --tiles_wg;
-    }
-    const bool latency_regime = tiles_wg <= 2 && ceil_div(ceil_div(N, 64), tiles_wg) <= p->num_cus;
-    if (chunk > 0 && latency_regime) {
-      // (rows padded to whole chunks: the cost wave reads them at immediate offsets)
-      const size_t cc_bytes = (size_t)tiles_wg * ceil_div(T, chunk) * chunk * 64 * sizeof(double);
-      const bool cc_lds = lds_win + ring_bytes(chunk) + cc_bytes <= budget && !(p->debug_flags & MPPI_DEBUG_CC_GLOBAL);
-      const size_t lds_total = lds_win + ring_bytes(chunk) + (cc_lds ? cc_bytes : 0);
-      const int block = 256 * tiles_wg;
-      const int grid = ceil_div(N, 64 * tiles_wg);
-      NoiseJob next_job;
-      memset(&next_job, 0, sizeof(next_job));
-      int extra = 0;
-      static const bool no_fused_noise = getenv("MPPI_NO_FUSED_NOISE") != nullptr;  // developer switch
-      if (p->next_noise_wanted && grid < p->num_cus && !no_fused_noise) {  // (no spare CU otherwise: in line)
-        extra = p->num_cus - grid;
-        next_job = make_noise_job(p, p->noise_buf[p->noise_cur ^ 1]);
-        p->next_noise_done = true;
-      }
-      if (!cc_lds && !p->cc_scratch) TRY(dev_alloc(&p->cc_scratch, (size_t)ceil_div(N, 64) * 64 * T));
-      const int speculate = (p->debug_flags & MPPI_DEBUG_NO_SPECULATION) ? 0 : 1;
-      if (speculate) p->spec_launches += 1;
-#define MPPI_LAUNCH_SPEC(CH, P2, CL)                                                                   \
-  do {                                                                                                \
-auto kern = tiles_wg == 1 ? k_rollout_spec<CH, P2, CL, 1> : k_rollout_spec<CH, P2, CL, 2>;        \
-if (lds_total > 64 * 1024)                                                                        \
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));       \
-MPPI_KLAUNCH(kern, dim3(grid + extra), dim3(block), lds_total, p->stream, d, p->cells16,    \
-                   p->noise, p->u, p->costs, p->w_rel, p->tile_beta, p->cc_scratch,                \
-                   (int)map_bytes, grid, speculate, next_job);                                     \
-  } while (0)
-#define MPPI_LAUNCH_SPEC_C(P2, CL)            \
-  do {                                        \
-if (chunk == 8) MPPI_LAUNCH_SPEC(8, P2, CL);      \
-else if (chunk == 4) MPPI_LAUNCH_SPEC(4, P2, CL); \
-else MPPI_LAUNCH_SPEC(2, P2, CL);                 \
-  } while (0)
-      if (pow2res && cc_lds) MPPI_LAUNCH_SPEC_C(true, true);
-      else if (pow2res) MPPI_LAUNCH_SPEC_C(true, false);
-      else if (cc_lds) MPPI_LAUNCH_SPEC_C(false, true);
-      else MPPI_LAUNCH_SPEC_C(false, false);
-#undef MPPI_LAUNCH_SPEC_C
-#undef MPPI_LAUNCH_SPEC
-      char buf[320];
-      snprintf(buf, sizeof(buf),
-               "k_rollout_spec chunk=%d pow2res=%d cc_lds=%d tiles_per_wg=%d speculate=%d window=%dx%d@(%d,%d) "
-               "progressive=%d lds=%zu noise_blocks=%d problems=%d",
-               chunk, (int)pow2res, (int)cc_lds, tiles_wg, speculate, d.win_rows, d.win_cols, d.win_r0, d.win_c0,
-               d.win_progressive, lds_total, extra, p->inst_set ? p->B : 0);
-      p->last_rollout = buf;
-      p->tile_packets_fresh = true;
-      *launched = true;
-      return MPPI_OK;
-    }
-  }
-  return MPPI_OK;
-}
 
 template <bool EXACT>
 static int try_launch_pipe(mppi_planner* p, DevParams& d, const DetRegime& r, bool* launched) {
   *launched = false;
   const int N = p->n_local, T = p->cfg.num_steps;
-  [[maybe_unused]] const bool have_window = r.have_window, rot_ok = r.rot_ok, pow2res = r.pow2res_unclamped,
-                              fast_deep_ok = r.fast_deep_ok, keep_speculating = r.keep_speculating;
+  [[maybe_unused]] const bool have_window = r.have_window, rot_ok = r.rot_ok, pow2res = r.pow2res_unclamped;
   [[maybe_unused]] const size_t lds_win = r.lds_win;
   static const bool no_pipe = getenv("MPPI_NO_PIPE") != nullptr;  // developer switch (ablation)
   if (have_window && rot_ok && !no_pipe) {
@@ -936,16 +753,17 @@ static int try_launch_pipe(mppi_planner* p, DevParams& d, const DetRegime& r, bo
       --pairs;
       if (p->inst_set) while (p->inst_tiles % pairs != 0) --pairs;
     }
-    // The pipelined kernel is the low-latency choice: it wins while one workgroup per CU covers
-    // the problem with at most three triples (measured, profiles/r01_ablation.md: 1 triple
-    // 53 vs 79 us, 2 triples 76 vs 83 us, 4 triples a tie, two rounds 162 vs 88 us at T=200).
-    // Beyond that the fused kernel below, 4..16 waves per CU, has the better throughput.
-    static const int max_triples = getenv("MPPI_PIPE_MAX_TRIPLES") ? atoi(getenv("MPPI_PIPE_MAX_TRIPLES")) : 3;  // developer switch (experiments)
-    const bool latency_regime = pairs <= max_triples && ceil_div(ceil_div(N, 64), pairs) <= p->num_cus;
+    // The pipelined kernel is the low-latency choice: it wins while one workgroup per CU covers the problem with one
+    // wave triple, and with two when chunks of four steps at least fit beside the window (measured at the end of round 6,
+    // N x T, us per iteration pipe | fused: 8192 x 200 44 | 79; 16384 x 100 39 | 53; 16384 x 200 63 | 85;
+    // 32768 x 100 55 | 60; 32768 x 200 (chunks of two) 102 | 77; 49152 x 100 (three triples) 74 | 48:
+    // profiles/r06_families.md).  Beyond that the fused kernel, 4..16 waves per CU, has the better throughput.
+    static const int max_triples = getenv("MPPI_PIPE_MAX_TRIPLES") ? atoi(getenv("MPPI_PIPE_MAX_TRIPLES")) : 2;  // developer switch (experiments)
+    const bool latency_regime = pairs <= max_triples && (pairs == 1 || chunk >= 4) && ceil_div(ceil_div(N, 64), pairs) <= p->num_cus;
     if (chunk > 0 && latency_regime) {
       // control-cost products in LDS when there is room, else in a global scratch array
       const size_t cc_bytes = (size_t)pairs * T * 64 * sizeof(double);
-      const bool cc_lds = lds_win + ring_bytes(chunk) + cc_bytes <= budget;
+      const bool cc_lds = lds_win + ring_bytes(chunk) + cc_bytes <= budget && !(p->debug_flags & MPPI_DEBUG_CC_GLOBAL);
       const size_t lds_total = lds_win + ring_bytes(chunk) + (cc_lds ? cc_bytes : 0);
       const int block = 192 * pairs;
       const int grid = ceil_div(N, 64 * pairs);
@@ -1003,8 +821,7 @@ else MPPI_LAUNCH_PIPE(2, P2, CL);                 \
 template <bool EXACT, bool BOUNDED>
 static int launch_windowed_or_general(mppi_planner* p, DevParams& d, const DetRegime& r) {
   const int N = p->n_local, T = p->cfg.num_steps;
-  [[maybe_unused]] const bool have_window = r.have_window, rot_ok = r.rot_ok, pow2res = r.pow2res,
-                              fast_deep_ok = r.fast_deep_ok, keep_speculating = r.keep_speculating;
+  [[maybe_unused]] const bool have_window = r.have_window, rot_ok = r.rot_ok, pow2res = r.pow2res;
   [[maybe_unused]] const size_t lds_win = r.lds_win;
   const size_t lds_map = sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);  // + staged u[t]
   static const bool no_window = getenv("MPPI_NO_WINDOW") != nullptr;  // developer switch (ablation)
@@ -1075,27 +892,11 @@ static int launch_rollout_det(mppi_planner* p, DevParams d) {
     int res_exp = 0;
     pow2res = std::frexp((double)a.res, &res_exp) == 0.5;  // res == 2^k exactly
   }
-  // MPPI_MATH_FAST: the same five-stage pipeline in float32 (hardware sin / cos: |theta| must stay
-  // inside v_sin_f32's +-256 revolutions)
-  bool fast_deep_ok = false;
-  if (!EXACT) {
-    const mppi_params& a = p->params;
-    double wmax = std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
-    double trmax = std::fmax(std::fabs(d.ang_lo), std::fabs(d.ang_lo + (double)d.ang_max_byte * d.ang_ratio));
-    double th0_max = std::fabs((double)a.x0[2]);
-    if (p->inst_set) for (const BatchInst& I : p->inst_host) th0_max = std::fmax(th0_max, std::fabs((double)I.th0));
-    const double bound = th0_max + (double)T * (double)a.dt * wmax * trmax;
-    fast_deep_ok = std::isfinite(bound) && bound < 1500.0 && T <= 2000;
-  }
-  const bool keep_speculating = !p->speculation_off || (p->debug_flags & MPPI_DEBUG_KEEP_SPECULATING);
   DetRegime r;
   r.have_window = have_window; r.lds_win = lds_win; r.rot_ok = rot_ok; r.rot_ok_fast = rot_ok_fast; r.pow2res = pow2res;
   r.pow2res_unclamped = pow2res && unclamped_lookup_ok(p, d);
-  r.fast_deep_ok = fast_deep_ok; r.keep_speculating = keep_speculating;
   bool launched = false;
-  TRY(try_launch_deep<EXACT>(p, d, r, &launched));
-  if (!launched) TRY(try_launch_spec<EXACT>(p, d, r, &launched));
-  if (!launched) TRY(try_launch_pipe<EXACT>(p, d, r, &launched));
+  TRY(try_launch_pipe<EXACT>(p, d, r, &launched));
   if (!launched) TRY((launch_windowed_or_general<EXACT, BOUNDED>(p, d, r)));
   HIP_TRY(hipGetLastError());
   return MPPI_OK;
@@ -1631,11 +1432,11 @@ static void review_speculation(mppi_planner* p) {
   const uint64_t failed = *p->spec_fail_host;
   // A launch lasts as long as its slowest tile, and a tile whose vote fails is rolled out twice: ONE failing tile
   // makes its launch slower than the exact schedule would have been.  Every speculative kernel runs ONE round of
-  // workgroups (k_rollout_scan*: a tile per CU; k_rollout_deep: a tile per CU; k_rollout_spec: up to three tiles in
+  // workgroups (k_rollout_scan*: a tile per CU; the speculative pipelines of rounds 2-5 likewise: up to three tiles in
   // one workgroup per CU), so the criterion is per launch for all of them.  C2 shape, round 5: 15.2 us when every
   // vote holds, 21.6 us on the exact schedule (direct), ~40 us with a failing tile -- speculation pays while
   // P(fail) * (40 - 21.6) < (1 - P) * (21.6 - 15.2), i.e. fewer than one launch in four fails (the longer horizons'
-  // k_rollout_deep against k_rollout_pipe: 36 / 48 / 85 us, the same quarter).  The kernels count failed tiles: at
+  // speculative against exact pipeline then: 36 / 48 / 85 us, the same quarter).  The kernels count failed tiles: at
   // least one per four launches -> stop.
   if (4 * failed >= p->spec_launches) {
     p->speculation_off = true;

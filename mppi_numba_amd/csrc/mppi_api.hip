@@ -21,8 +21,6 @@
 
 #include "rng_kernels.h"
 #include "rollout_kernels.h"
-#include "rollout_spec_kernel.h"
-#include "rollout_deep_kernel.h"
 #include "rollout_scan_kernel.h"
 #include "rollout_scan_exact_kernel.h"
 #include "map_kernels.h"
@@ -580,7 +578,7 @@ static int planner_alloc(mppi_planner* p) {
   HIP_TRY(hipEventCreate(&p->ev_end));
   for (auto& e : p->ev_stage) HIP_TRY(hipEventCreate(&e));
   const size_t n_tiled = (size_t)ceil_div((long)N, 64) * 64;  // tile-major arrays cover whole tiles
-  // (+ 8 chunks of 8 rows: k_rollout_spec prefetches rows past the horizon of the last tile unclamped)
+  // (+ 8 chunks of 8 rows of slack behind the last tile: batch loads clamp rows, not tiles)
   const size_t noise_pad = 8 * 16 * 64;
   for (int b = 0; b < 2; ++b) {
     TRY(dev_alloc(&p->noise_buf[b], n_tiled * T + noise_pad));

@@ -59,7 +59,7 @@ struct DevParams {
   int win_rows, win_cols;  // window size; win_cols is a multiple of 8
   int pitch16;             // row pitch of the global 16-bit cell array (multiple of 8)
   int lin_max_byte, ang_max_byte;  // host-side bounds only (largest traction byte in the grids)
-  // k_rollout_spec copies the window in bands of rows as the rollouts spread: cells a rollout can
+  // (host-side window planning; rounds 2-5: a kernel that copied the window in bands of rows) cells a rollout can
   // cover per step (dt * max|v| * max traction / res); win_progressive = 0: everything up front
   float win_step_cells;
   int win_progressive;
@@ -792,7 +792,8 @@ __device__ __forceinline__ void pipe_state_tail(const DevParams& P, const PipeWi
 // ((n / 64) * T + t) * 64 + n % 64, i.e. the T x 64 block of one wave is contiguous.
 // The three cooperating roles of one workgroup of the pipelined rollout (threads [0, 192*W)): the
 // whole kernel below after its noise-generating workgroups have branched off, and the exact
-// re-execution path of k_rollout_deep (rollout_deep_kernel.h) after a failed speculation.
+// exact re-execution path of a tile of the time-parallel kernel whose vote failed follows the same schedule
+// (rollout_scan_exact_kernel.h: scan_exact_reexecute).
 template <int C, bool POW2RES, bool CC_LDS>
 __device__ __forceinline__ void pipe_tile_body(DevParams P, const uint16_t* __restrict__ cells16,
                                                const float2* __restrict__ noise, const float2* __restrict__ u,
@@ -1460,5 +1461,16 @@ __global__ void k_state_rollout(DevParams P, const uint32_t* __restrict__ cells,
     o[3 * (t + 1)] = x; o[3 * (t + 1) + 1] = y; o[3 * (t + 1) + 2] = th;
   }
 }
+
+// ---- small helpers of the flag-synchronised kernels (rollout_scan*_kernel.h) ----------------------------------------
+// interval barrier: this wave's LDS operations complete, its global loads stay in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// keeps the compiler from moving memory operations (LDS phases, early loads) across this point
+__device__ __forceinline__ void pin_memory_order() { asm volatile("" ::: "memory"); }
+// a compile-time index as a function argument (register sets used in turn)
+template <int I>
+struct PhaseTag {
+  static constexpr int value = I;
+};
 
 }  // namespace mppi

@@ -8,7 +8,7 @@
 //
 // Why.  The reference's rollout is a chain of T dependent steps per control sample; with one tile
 // of 64 rollouts per CU (N = 8192: the north-star shard) every design that walks that chain is
-// bound by the issue rate of a handful of waves (k_rollout_deep: 226 cycles per step, 18 us per
+// bound by the issue rate of a handful of waves (the five-stage pipeline of rounds 2-5: 226 cycles per step, 18 us per
 // launch, 11 % of the HBM roofline).  The chain exists because heading and position feed on the
 // traction of the visited cell.  Under the assumption the speculative kernels already make --
 // every visited cell carries the traction (vtr0, wtr0) of the start cell -- it is not a chain:
@@ -49,7 +49,7 @@
 // maps where most tiles fail (review_speculation).
 #pragma once
 #include <type_traits>
-#include "rollout_spec_kernel.h"
+#include "rollout_kernels.h"
 
 namespace mppi {
 
@@ -143,7 +143,7 @@ __device__ __forceinline__ float frozen_block(float acc, double k, float pen, in
 
 // GEN: `gen` describes the Philox counters of THIS iteration's noise (out is ignored);
 // !GEN: `noise` holds it (tile-major) and the spare workgroups (blockIdx >= n_rollout_blocks)
-//       write the next iteration's (`next_noise`), as in k_rollout_deep.
+//       write the next iteration's (`next_noise`), as in k_rollout_pipe.
 template <int R, bool POW2RES, bool GEN>
 __global__ __launch_bounds__(1024) void k_rollout_scan(DevParams P, const uint16_t* __restrict__ cells16,
                                                        const float2* __restrict__ noise, NoiseJob gen,

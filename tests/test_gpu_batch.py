@@ -57,7 +57,7 @@ def single_problem(cfg, lin, ang, params, x0, goal):
 @pytest.mark.parametrize("workload,n,t_steps,m,count,token", [
     ("c2", 1024, 60, 1, 5, "k_rollout_scan_exact"),     # deterministic traction: 160 tiles of 32, one round
     ("c2s", 1024, 60, 1, 5, "k_rollout_scan_exact"),    # semantic map: after solve() the exact schedule inside that kernel (direct), one window origin per problem
-    ("c2", 2048, 60, 1, 6, "k_rollout_deep"),           # 192 tiles of 64: one tile per CU, LDS reach windows
+    ("c2", 2048, 60, 1, 6, "k_rollout_pipe"),           # 192 tiles of 64: one tile per CU, LDS reach windows
     ("c2", 256, 250, 1, 3, "k_rollout_"),               # long horizon: whole map or global cells
     ("c2", 4096, 30, 1, 12, "k_rollout_fused"),  # throughput regime: fused kernel, LDS windows
     ("c3", 128, 40, 64, 3, "k_rollout_tdm"),            # CVaR over M sampled maps
@@ -75,7 +75,7 @@ def test_batch_matches_single_problem_handles_and_oracle(workload, n, t_steps, m
             useqs = batch.solve()
     assert useqs.shape == (count, t_steps, 2) and np.isfinite(useqs).all()
     assert token in batch.last_rollout_kernel()
-    if token in ("k_rollout_deep", "k_rollout_scan_exact"):
+    if token in ("k_rollout_pipe", "k_rollout_scan_exact"):
         assert "problems=%d" % count in batch.last_rollout_kernel()
     # a different warm start per problem, then injected noise
     u_in = (useqs + rng.normal(0, 0.05, useqs.shape)).astype(np.float32)
@@ -104,7 +104,7 @@ def test_batch_matches_single_problem_handles_and_oracle(workload, n, t_steps, m
         single.set_u(u_in[b])
         single.set_noise(noise[b])
         single.rollout()
-        if token in ("k_rollout_deep", "k_rollout_scan_exact"):
+        if token in ("k_rollout_pipe", "k_rollout_scan_exact"):
             assert token in single.last_rollout_kernel(), single.last_rollout_kernel()
         want = single.costs_d.copy_to_host()
         assert np.array_equal(costs[b], want), "problem %d: costs differ from the single-problem handle" % b

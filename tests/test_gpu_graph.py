@@ -19,7 +19,7 @@ def pair(workload, n, rng="philox"):
 
 @pytest.mark.parametrize("workload,n,token", [
     ("c2", 2048, "k_rollout_scan_exact"),  # noise computed in the rollout launch
-    ("c2", 12288, "k_rollout_deep"),     # in-launch generation of the next noise by spare workgroups
+    ("c2", 12288, "k_rollout_pipe"),     # in-launch generation of the next noise by spare workgroups
     ("c4", 65536, "k_rollout_fused"),    # generation on the second stream, fork / join inside the graph
     ("c3", 192, "k_rollout_tdm_fast"),   # generator in line: captured as part of the iteration
 ])

@@ -99,11 +99,10 @@ def test_fast_math_close_to_exact():
     assert np.quantile(rel, 0.99) < 1e-5
 
 
-def test_fast_math_runs_the_float32_pipeline_within_the_north_star_tolerance():
-    """math="fast" at the latency-regime sizes is k_rollout_deep<f32>: the five-stage pipeline
-    without float64 intermediates.  Held to north_star's own bar against the oracle (the exact
-    path is bit-identical; this one is an opt-in whose cost in accuracy and gain in time
-    DESIGN.md section 4 reports: ~1.5 % faster, i.e. the float64 roundings are NOT what bounds C2)."""
+def test_fast_math_beyond_the_time_parallel_kernel_within_the_north_star_tolerance():
+    """math="fast" where the tolerance mode's time-parallel kernel does not apply (here: switched off) is
+    k_rollout_fused<one pass> (rounds 2-5: a float32 five-stage pipeline, removed in round 6).  Held to north_star's own
+    bar against the oracle (the exact path is bit-identical; this one is an opt-in)."""
     from mppi_numba_amd import _lib
     w, cfg, lin, ang, planner, params = build("c2", 8192, math="fast")
     planner.set_debug_flags(_lib.DEBUG_NO_SCAN_KERNEL)  # (the default fast-math kernel: tests/test_gpu_scan.py)
@@ -112,7 +111,7 @@ def test_fast_math_runs_the_float32_pipeline_within_the_north_star_tolerance():
     noise = planner.noise_samples_d.copy_to_host()
     u_in = planner.u_cur_d.copy_to_host()
     planner.rollout()
-    assert planner.last_rollout_kernel().startswith("k_rollout_deep<f32>"), planner.last_rollout_kernel()
+    assert planner.last_rollout_kernel().startswith("k_rollout_fused<one pass>"), planner.last_rollout_kernel()
     got = planner.costs_d.copy_to_host()
     planner.update()
     u_out = planner.u_cur_d.copy_to_host()
@@ -340,44 +339,26 @@ def custom_world(rows, cols, res, seed):
 
 
 # (label, rows, cols, res, N, T, x0, padding speed, debug flags, tokens expected in the kernel description)
-NO_SPEC_KERNEL, NO_SPECULATION, NO_DEEP, CC_GLOBAL = 1, 2, 4, 8
+# (round 6: the two speculative pipelines of rounds 2-5 -- k_rollout_deep, k_rollout_spec -- lost to these kernels wherever
+#  they were still selected and were removed: profiles/r06_families.md)
+CC_GLOBAL = 8
 @pytest.mark.parametrize("label,rows,cols,res,n,t_steps,x0,pad_speed,flags,expect", [
-    # one tile per CU: the 11-wave speculative pipeline (random PMF worlds: the vote fails at once and the
-    # tile is re-executed on the exact schedule -- the speculation itself is exercised by
-    # test_speculation_holds_then_fails_same_bits)
-    ("deep: non power-of-two resolution", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0, 0,
-     ["k_rollout_deep", "pow2res=0", "cc_lds=1"]),
-    ("deep: resolution 0.1, 86 KiB window: chunks of 4", 200, 200, 0.1, 2048, 80, (7.33, 8.21, -2.0), 3.0, 0,
-     ["k_rollout_deep", "pow2res=0", "chunk=4", "cc_lds=1"]),
-    ("deep: products in global scratch", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0, CC_GLOBAL,
-     ["k_rollout_deep", "cc_lds=0"]),
-    ("spec: products in global scratch", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0, CC_GLOBAL | NO_DEEP,
-     ["k_rollout_spec", "cc_lds=0"]),
-    ("deep: exact schedule from the first step", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0, NO_SPECULATION,
-     ["k_rollout_deep", "speculate=0"]),
-    ("whole-map window too large for the deep kernel's rings: 4-wave speculative kernel", 270, 250, 0.25, 2048, 200,
-     (30.0, 33.0, 0.0), 5.0, 0, ["k_rollout_spec", "cc_lds=0", "window=274x"]),
-    # the 4-wave speculative kernel (two tiles per CU, or forced)
-    ("spec: non power-of-two resolution", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0, NO_DEEP,
-     ["k_rollout_spec", "pow2res=0", "tiles_per_wg=1"]),
-    ("spec: resolution 0.1: cell borders every few float32 ulps", 200, 200, 0.1, 2048, 80, (7.33, 8.21, -2.0), 3.0, NO_DEEP,
-     ["k_rollout_spec", "pow2res=0", "cc_lds=0"]),
-    ("spec: two tiles per workgroup", 256, 256, 0.25, 32768, 40, (20.0, 30.0, 0.3), 5.0, 0,
-     ["k_rollout_spec", "tiles_per_wg=2"]),
-    ("spec: exact schedule, non power-of-two resolution", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0,
-     NO_DEEP | NO_SPECULATION, ["k_rollout_spec", "pow2res=0", "speculate=0"]),
-    ("spec: exact schedule, two tiles per workgroup, ragged last tile", 256, 256, 0.25, 32768 - 37, 40,
-     (20.0, 30.0, 0.3), 5.0, NO_SPECULATION, ["k_rollout_spec", "tiles_per_wg=2", "speculate=0"]),
-    # the 3-wave pipelined kernel (three tiles per CU, or forced)
-    ("pipe: three tiles per CU, ragged last tile", 256, 256, 0.25, 49152 - 37, 40, (20.0, 30.0, 0.3), 5.0, 0,
-     ["k_rollout_pipe", "triples_per_wg=3"]),
-    ("pipe: non power-of-two resolution", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0, NO_SPEC_KERNEL,
+    # the exact three-wave pipeline: one or two tiles of 64 rollouts per CU
+    ("pipe: non power-of-two resolution", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0, 0,
+     ["k_rollout_pipe", "pow2res=0", "cc_lds=1"]),
+    ("pipe: resolution 0.1: cell borders every few float32 ulps, 86 KiB window", 200, 200, 0.1, 2048, 80, (7.33, 8.21, -2.0), 3.0, 0,
      ["k_rollout_pipe", "pow2res=0"]),
-    ("pipe: two wave triples per workgroup", 256, 256, 0.25, 32768, 40, (20.0, 30.0, 0.3), 5.0, NO_SPEC_KERNEL,
+    ("pipe: products in global scratch", 120, 140, 0.3, 4096, 60, (12.1, 9.7, 0.9), 4.0, CC_GLOBAL,
+     ["k_rollout_pipe", "cc_lds=0"]),
+    ("pipe: two wave triples per workgroup", 256, 256, 0.25, 32768, 40, (20.0, 30.0, 0.3), 5.0, 0,
+     ["k_rollout_pipe", "triples_per_wg=2"]),
+    ("pipe: two wave triples per workgroup, ragged last tile", 256, 256, 0.25, 32768 - 37, 40, (20.0, 30.0, 0.3), 5.0, 0,
      ["k_rollout_pipe", "triples_per_wg=2"]),
     ("pipe: whole-map window, control-cost products in global scratch", 270, 250, 0.25, 2048, 200,
-     (30.0, 33.0, 0.0), 5.0, NO_SPEC_KERNEL, ["k_rollout_pipe", "cc_lds=0", "window=274x"]),
+     (30.0, 33.0, 0.0), 5.0, 0, ["k_rollout_pipe", "cc_lds=0", "window=274x"]),
     # throughput regime and general fallbacks
+    ("throughput regime from three tiles per CU on, ragged last tile", 256, 256, 0.25, 49152 - 37, 40, (20.0, 30.0, 0.3), 5.0, 0,
+     ["k_rollout_fused", "waves_per_wg=4"]),
     ("throughput regime: fused kernel on the LDS window, 4 waves per CU", 256, 256, 0.25, 65536, 40,
      (20.0, 30.0, 0.3), 5.0, 0, ["k_rollout_fused", "waves_per_wg=4"]),
     ("throughput regime, long horizon: whole-map window, 8 waves per CU", 256, 256, 0.25, 131072, 120,
@@ -401,9 +382,8 @@ def test_det_rollout_variants_vs_oracle(label, rows, cols, res, n, t_steps, x0, 
     lin.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)
     ang.set_TDM_from_PMF_grid(pmf[:, ::-1].copy(), td, obstacle, unknown)
     planner = MPPI_Numba(cfg)
-    # (16: keep the speculative kernels where the planner would switch to k_rollout_pipe; 32: the kernels
-    #  this test pins are what runs beyond one round of the time-parallel kernel -- N > 8192, T > 120)
-    planner.set_debug_flags(flags | 16 | 32)
+    # (32: the kernels this test pins are what runs beyond one round of the time-parallel kernel -- N > 8192, T > 104)
+    planner.set_debug_flags(flags | 32)
     params = bench.make_params("c2")
     params.update(x0=np.array(x0), xgoal=np.array([x0[0] + 3.0, x0[1] + 2.0]), lambda_weight=5.0)
     planner.setup(params, lin, ang)
@@ -457,15 +437,15 @@ def patch_world(rows, cols, res, kind, seed):
     return pmf, ang_pmf, obstacle, unknown, td
 
 
-@pytest.mark.parametrize("flags", [0, 4, 2, 6, 1, 8, 12])
+@pytest.mark.parametrize("flags", [0, 8])
 @pytest.mark.parametrize("kind,t_steps,n", [("uniform", 100, 8192), ("far", 100, 8192), ("near", 100, 4096),
                                             ("stripes", 60, 8192), ("far", 37, 2048 + 5), ("far", 200, 16384 - 64),
                                             ("far", 50, 32768 - 64), ("ring", 100, 8192), ("ring", 26, 1024)])
-def test_speculation_holds_then_fails_same_bits(kind, t_steps, n, flags):
-    """k_rollout_spec assumes the start cell's traction bytes everywhere and falls back, per tile
-    and from the start of the offending chunk, when a lookup says otherwise: costs must be those
-    of the oracle (and of the kernel on its exact schedule, flags=2, and of k_rollout_pipe,
-    flags=1) wherever and whenever the assumption breaks."""
+def test_patchwise_constant_traction_on_the_exact_pipeline(kind, t_steps, n, flags):
+    """Maps whose traction is constant over patches (written for the speculative pipelines of rounds 2-5, which assumed the
+    start cell's traction everywhere and fell back per tile): the exact pipeline and, from three tiles per CU on, the
+    throughput kernel -- the oracle's costs wherever the traction changes along the paths, frozen rollouts in the padding
+    ring included.  (The time-parallel kernels on these maps: tests/test_gpu_scan.py, tests/test_gpu_fuzz.py.)"""
     from mppi_numba_amd.config import Config
     from mppi_numba_amd.mppi import MPPI_Numba
     from mppi_numba_amd.terrain import TDM_Numba
@@ -479,7 +459,7 @@ def test_speculation_holds_then_fails_same_bits(kind, t_steps, n, flags):
     lin.set_TDM_from_PMF_grid(pmf, td, obstacle, unknown)
     ang.set_TDM_from_PMF_grid(ang_pmf, td, obstacle, unknown)
     planner = MPPI_Numba(cfg)
-    planner.set_debug_flags(flags | 16 | 32)  # (16: keep speculating where the planner would have given up, see below; 32: not the time-parallel kernel)
+    planner.set_debug_flags(flags | 32)  # (32: not the time-parallel kernel)
     params = bench.make_params("c2")
     params.update(x0=np.array([25.1, 24.9, 0.7]), xgoal=np.array([40.0, 38.0]), lambda_weight=5.0)
     if kind == "ring":
@@ -493,11 +473,7 @@ def test_speculation_holds_then_fails_same_bits(kind, t_steps, n, flags):
     planner.rollout()
     kernel = planner.last_rollout_kernel()
     tiles = -(-n // 64)
-    want_kernel = ("k_rollout_pipe" if flags & 1 else
-                   "k_rollout_deep" if tiles <= 256 and not flags & 4 else "k_rollout_spec")
-    assert kernel.startswith(want_kernel), kernel
-    if not flags & 1:
-        assert "speculate=%d" % (0 if flags & 2 else 1) in kernel, kernel
+    assert kernel.startswith("k_rollout_pipe" if tiles <= 512 else "k_rollout_fused"), kernel
     got = planner.costs_d.copy_to_host()
     want = oracle_costs(dict(m=1), params, lin, ang, noise, u_in)
     ulps = ulp_diff_f32(got, want)

@@ -2,7 +2,7 @@
 groups of 8 steps to each other through LDS flags, without workgroup barriers, relying on the LDS executing a
 wave's instructions in order -- an ordering slip would show up rarely and as wrong costs, not as a crash.
 20 000 iterations of BASELINE configs[1] (C2: N = 8192, T = 100) in the ordinary loop (noise computed in the
-launch, updates applied by the next launch); every 100th iteration is re-computed by k_rollout_deep (barriers
+launch, updates applied by the next launch); every 100th iteration is re-computed by k_rollout_pipe (barriers
 between its stages) from the same Philox counters and the same controls and compared bit for bit, and the whole
 run is repeated with an update launch per iteration: the control sequences must come out identical.
 (mppi.py:916-1009.)"""
@@ -40,7 +40,7 @@ def test_twenty_thousand_iterations_against_the_barrier_synchronised_kernel():
         check.set_noise(noise)
         check.set_u(u_in)
         check.rollout()
-        assert check.last_rollout_kernel().startswith("k_rollout_deep"), check.last_rollout_kernel()
+        assert check.last_rollout_kernel().startswith("k_rollout_pipe"), check.last_rollout_kernel()
         want = check.costs_d.copy_to_host()
         differing = int((costs != want).sum())
         worst = max(worst, differing)
@@ -50,7 +50,7 @@ def test_twenty_thousand_iterations_against_the_barrier_synchronised_kernel():
     plain.synchronize()
     assert np.array_equal(loop.u_cur_d.copy_to_host(), plain.u_cur_d.copy_to_host())
     assert np.array_equal(loop.costs_d.copy_to_host(), plain.costs_d.copy_to_host())
-    print("\n%d iterations, %d checked bit for bit against k_rollout_deep: 0 costs differ" % (ROUNDS * PER_ROUND, ROUNDS))
+    print("\n%d iterations, %d checked bit for bit against k_rollout_pipe: 0 costs differ" % (ROUNDS * PER_ROUND, ROUNDS))
 
 
 def test_ten_thousand_iterations_of_the_tolerance_kernel_with_and_without_the_fold():
