@@ -469,7 +469,13 @@ def main():
     from mppi_numba_amd import launch
     if args.gpus > 1 and not args.single_process and not launch.launched_by_a_launcher():
         # plain `python bench.py --gpus N`: start the N ranks (one per GPU) ourselves
-        sys.exit(launch.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+        def crashed(per_rank):
+            print(json.dumps({"metric": "rollouts/sec (MPPI iteration = noise + rollout + update)", "value": None, "unit": "rollouts/s",
+                              "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "error": "rank(s) %s ended abnormally before the run completed" % ", ".join(sorted(per_rank)),
+                              "errors_per_rank": per_rank, "config": {"workload": WORKLOADS[args.workload]["label"]}}), flush=True)
+        sys.exit(launch.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], on_failure=crashed))
 
     # ONE line on stdout: everything else that writes to file descriptor 1 in this process -- librccl prints a version
     # banner when a communicator is created, the mirror classes print like the reference does -- goes to stderr
@@ -486,7 +492,25 @@ def main():
         rank, local_rank, world = 0, 0, 1
     elif world != args.gpus:
         args.gpus = world  # the launcher's word counts
-    hub = launch.Hub(rank, world)
+
+    def give_up(message, per_rank=None):
+        """A run that cannot start says so in the ONE line the driver parses (value null, an `error`), from rank 0 -- or
+        from whichever rank is left to say it when rank 0 never came up -- and exits 2: never a hang, never nothing."""
+        if rank == 0 or per_rank is None:
+            line = {"metric": "rollouts/sec (MPPI iteration = noise + rollout + update)", "value": None, "unit": "rollouts/s",
+                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                    "scaling": "weak", "vs_baseline": None, "error": message, "rank": rank,
+                    "errors_per_rank": per_rank, "config": {"workload": WORKLOADS[args.workload]["label"]}}
+            os.write(result_fd, (json.dumps(line) + "\n").encode())
+        print("bench.py rank %d: %s" % (rank, message), file=sys.stderr)
+        sys.exit(2)
+
+    if os.environ.get("MPPI_BENCH_DIE_RANK") == str(rank):  # (fault injection, tests/test_launch_hub.py: a rank that never reports)
+        os._exit(3)
+    try:
+        hub = launch.Hub(rank, world, timeout=float(os.environ.get("MPPI_HUB_TIMEOUT", "120")))
+    except Exception as e:  # noqa: BLE001 -- whatever kept the ranks from meeting is the run's result
+        give_up("rendezvous of %d ranks failed: %s: %s" % (world, type(e).__name__, e))
 
     from mppi_numba_amd import _lib
     from mppi_numba_amd.config import Config
@@ -505,60 +529,76 @@ def main():
     m_global = m * world if by_samples else m  # weak scaling in M: every rank keeps its 128 maps
     if by_samples:
         n_global = n_local  # every rank rolls all N control samples
-    device = local_rank % max(1, _lib.device_count())
     group_size = args.gpus if args.single_process else 1
     if group_size > 1:
         assert not problems and not args.graph, "--single-process: sharded workloads, direct launches"
-        assert _lib.device_count() >= group_size, "%d devices for --gpus %d" % (_lib.device_count(), group_size)
         n_global = n_local * group_size
 
     import contextlib
     import io
     quiet = contextlib.redirect_stdout(io.StringIO())  # the mirror prints like the reference does
-    with quiet:
-        cfg = Config(T=t_steps * 0.1, dt=0.1, num_grid_samples=m_global, num_control_rollouts=n_global,
-                     max_speed_padding=5.0, num_vis_state_rollouts=1, max_map_dim=(260, 260),
-                     seed=1 + (rank if problems else 0),
-                     enforce_recommended_limits=False, math=args.math, device=device, **w["mode"])
-        assert cfg.num_steps == t_steps, cfg.num_steps
-        world_rng = np.random.default_rng(0)
-        pmf, obstacle, unknown, tdm_dict = synthetic_world(args.workload, world_rng)
-        shard = (rank, world) if by_samples else None
-        lin, ang = TDM_Numba(cfg, sample_shard=shard), TDM_Numba(cfg, sample_shard=shard)
-        lin.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
-        ang.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
-        params = make_params(args.workload)
-        if problems:
-            from mppi_numba_amd.batch import MPPI_Batch
-            planner = MPPI_Batch(cfg, problems)
-            planner.setup(params, lin, ang, *batch_problems(problems, np.random.default_rng(100 + rank)))
-        elif group_size > 1:
-            import copy
-            from mppi_numba_amd.mppi import MPPI_Group
-            cfgs, lins, angs = [cfg], [lin], [ang]
-            for g in range(1, group_size):
-                c = copy.deepcopy(cfg)
-                c.device = g
-                lg, ag = TDM_Numba(c), TDM_Numba(c)
-                lg.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
-                ag.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
-                cfgs.append(c); lins.append(lg); angs.append(ag)
-            group = MPPI_Group(cfgs)
-            group.setup(params, lins, angs)
-            planner = group.planners[0]
-            if args.exchange in ("auto", "p2p"):
-                try:  # the peer exchange between the devices of this process (peer access)
-                    group.connect_peers()
-                    args.exchange = "p2p"
-                except Exception as e:
-                    print("bench.py: peer exchange unavailable in the device group (%s): RCCL" % e, file=sys.stderr)
-                    args.exchange = "rccl"
-        elif by_samples:
-            planner = MPPI_Numba(cfg, sample_shard=shard)
-            planner.setup(params, lin, ang)
-        else:
-            planner = MPPI_Numba(cfg, rank=rank, world_size=world)
-            planner.setup(params, lin, ang)
+    setup_error = None
+    try:
+      with quiet:
+          if os.environ.get("MPPI_BENCH_FAIL_RANK") == str(rank):  # (fault injection: a rank that cannot open its device)
+              raise RuntimeError("injected start-up failure (MPPI_BENCH_FAIL_RANK)")
+          device = local_rank % max(1, _lib.device_count())
+          if group_size > 1:
+              assert _lib.device_count() >= group_size, "%d devices for --gpus %d" % (_lib.device_count(), group_size)
+          cfg = Config(T=t_steps * 0.1, dt=0.1, num_grid_samples=m_global, num_control_rollouts=n_global,
+                       max_speed_padding=5.0, num_vis_state_rollouts=1, max_map_dim=(260, 260),
+                       seed=1 + (rank if problems else 0),
+                       enforce_recommended_limits=False, math=args.math, device=device, **w["mode"])
+          assert cfg.num_steps == t_steps, cfg.num_steps
+          world_rng = np.random.default_rng(0)
+          pmf, obstacle, unknown, tdm_dict = synthetic_world(args.workload, world_rng)
+          shard = (rank, world) if by_samples else None
+          lin, ang = TDM_Numba(cfg, sample_shard=shard), TDM_Numba(cfg, sample_shard=shard)
+          lin.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
+          ang.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
+          params = make_params(args.workload)
+          if problems:
+              from mppi_numba_amd.batch import MPPI_Batch
+              planner = MPPI_Batch(cfg, problems)
+              planner.setup(params, lin, ang, *batch_problems(problems, np.random.default_rng(100 + rank)))
+          elif group_size > 1:
+              import copy
+              from mppi_numba_amd.mppi import MPPI_Group
+              cfgs, lins, angs = [cfg], [lin], [ang]
+              for g in range(1, group_size):
+                  c = copy.deepcopy(cfg)
+                  c.device = g
+                  lg, ag = TDM_Numba(c), TDM_Numba(c)
+                  lg.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
+                  ag.set_TDM_from_PMF_grid(pmf, tdm_dict, obstacle, unknown)
+                  cfgs.append(c); lins.append(lg); angs.append(ag)
+              group = MPPI_Group(cfgs)
+              group.setup(params, lins, angs)
+              planner = group.planners[0]
+              if args.exchange in ("auto", "p2p"):
+                  try:  # the peer exchange between the devices of this process (peer access)
+                      group.connect_peers()
+                      args.exchange = "p2p"
+                  except Exception as e:
+                      print("bench.py: peer exchange unavailable in the device group (%s): RCCL" % e, file=sys.stderr)
+                      args.exchange = "rccl"
+          elif by_samples:
+              planner = MPPI_Numba(cfg, sample_shard=shard)
+              planner.setup(params, lin, ang)
+          else:
+              planner = MPPI_Numba(cfg, rank=rank, world_size=world)
+              planner.setup(params, lin, ang)
+    except Exception as e:  # noqa: BLE001 -- reported below, by every rank together
+        setup_error = "%s: %s" % (type(e).__name__, str(e)[:300])
+    # every rank says whether it is up BEFORE anything waits for a peer on the device: a rank that could not open its
+    # GPU (or build its planner) makes the run a reported error on all of them, not a hang in the first collective
+    try:
+        setup_errors = hub.all_gather(setup_error)
+    except Exception as e:  # noqa: BLE001 -- a rank that went away after the rendezvous
+        give_up("a rank went away during start-up (%s: %s)%s" % (type(e).__name__, e, "; this rank: " + setup_error if setup_error else ""))
+    if any(setup_errors):
+        bad = {str(r): e for r, e in enumerate(setup_errors) if e}
+        give_up("%d of %d ranks failed to start: %s" % (len(bad), world, "; ".join("rank %s: %s" % kv for kv in bad.items())), bad)
     rp, cp = lin.pmf_grid_d.shape[1:]
 
     exchange_note = None
@@ -819,6 +859,12 @@ def main():
                                 "RCCL all-gather on the planner's stream" if args.exchange == "rccl" else
                                 (exchange_note or "host-staged through the rendezvous hub (--exchange host)")),
                    "exchange_us_per_step": exchange_us or None,
+                   # one entry per transport that connected (a trial region each; the line's own region ran on `exchange`):
+                   # the first 8-GPU run reports both legs whichever wins
+                   "per_exchange": {mode: {"us_per_step": us, "rollouts_per_s": rollouts_per_step / (us * 1e-6),
+                                           **({"n_ranks_seen_by_rccl": rccl_ranks} if mode == "rccl" else
+                                              {"inbox_memory": planner.p2p_stats()["inbox"] if hasattr(planner, "p2p_stats") else None})}
+                                    for mode, us in exchange_us.items()} or None,
                    "pre_warm_iterations": args.pre_warm,
                    "n_ranks_seen_by_rccl": rccl_ranks,
                    "launcher": ("one process, %d devices (mppi_group_*)" % group_size) if group_size > 1 else

@@ -46,7 +46,7 @@ def rendezvous_path():
     return os.path.join(tempfile.gettempdir(), "mppi_rdzv_%d_%s.json" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
 
 
-def spawn_ranks(world, argv, extra_env=None, timeout=None):
+def spawn_ranks(world, argv, extra_env=None, timeout=None, on_failure=None):
     """Start `world` copies of `argv` (a full command line), one per rank; returns rank 0's
     exit code after all have ended.  Rank 0 inherits stdout; every rank inherits stderr."""
     # a directory of our own (mode 0700): the file rank 0 creates in it cannot be anticipated by anyone
@@ -76,6 +76,11 @@ def spawn_ranks(world, argv, extra_env=None, timeout=None):
                     codes[r] = p.wait()
                 if failed:
                     print("rank(s) %s failed with exit code(s) %s" % (failed, [codes[r] for r in failed]), file=sys.stderr)
+                    # ranks that give up in an orderly way (exit code 2) have said why on rank 0's stdout already; a rank
+                    # that crashed has not, and rank 0 was killed waiting for it: the launcher says it, in the same
+                    # one-line form, so that whoever parses the run's stdout finds an error instead of nothing
+                    if on_failure is not None and any(codes[r] != 2 for r in failed):
+                        on_failure({str(r): "exit code %s" % codes[r] for r in failed})
                 return codes[failed[0]] if failed else 124
             time.sleep(0.05)
     finally:

@@ -194,3 +194,54 @@ def test_hub_turns_away_a_peer_without_the_token(tmp_path):
     intruder.close()
     big.close()
     assert got == ["zero", "one"] and result["gathered"] == ["zero", "one"]
+
+
+# ---- bench.py: a run that cannot start is ONE parsed JSON line with an `error`, never a hang ----
+def _bench(args, env=None, timeout=120):
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                         env=dict(os.environ, MPPI_HUB_TIMEOUT="20", **(env or {})), cwd=root)
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip()]
+    return run.returncode, [json.loads(ln) for ln in lines], run.stderr
+
+
+def _no_gpu():
+    from mppi_numba_amd import _lib
+    try:
+        return _lib.device_count() == 0
+    except Exception:
+        return True
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="start-up failure of every rank: a box without a GPU")
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_ranks_that_cannot_open_a_device_report_one_json_error(gpus):
+    code, lines, err = _bench(["--gpus", str(gpus), "--steps", "2", "--warmup", "1"])
+    assert code == 2, (code, err[-500:])
+    assert len(lines) == 1 and lines[0]["value"] is None and lines[0]["n_gpus"] == gpus
+    assert "failed to start" in lines[0]["error"] and set(lines[0]["errors_per_rank"]) == {str(r) for r in range(gpus)}
+
+
+def test_a_rank_that_dies_before_the_rendezvous_is_reported_by_the_launcher():
+    code, lines, err = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1"], env={"MPPI_BENCH_DIE_RANK": "1"})
+    assert code != 0
+    assert len(lines) == 1 and lines[0]["value"] is None and "ended abnormally" in lines[0]["error"], (lines, err[-500:])
+    assert lines[0]["errors_per_rank"] == {"1": "exit code 3"}
+
+
+def test_a_rank_missing_under_an_external_launcher_times_out_into_a_json_error():
+    """Launched like the driver does (RANK / WORLD_SIZE from the environment), one rank never shows up: rank 0 gives the
+    rendezvous up after MPPI_HUB_TIMEOUT and says so in the line."""
+    import json
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MPPI_RDZV_FILE=os.path.join(d, "r.json"), MPPI_HUB_TIMEOUT="3")
+        run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                             capture_output=True, text=True, timeout=60, env=env, cwd=root)
+    assert run.returncode == 2
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["value"] is None and "rendezvous of 2 ranks failed" in line["error"]
