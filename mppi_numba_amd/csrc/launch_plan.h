@@ -1026,9 +1026,19 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
     case MPPI_MODE_BAREBONE: {
       const int N = p->n_local;
       p->tile_packets_fresh = false;
-      MPPI_KLAUNCH((k_rollout_barebone<EXACT>), dim3(ceil_div(N, 64)), dim3(64), sizeof(double2) * (size_t)p->cfg.num_steps,
-                   p->stream, d, p->obs_pos, p->obs_r, p->noise, p->u, p->costs);
-      p->last_rollout = "k_rollout_barebone exact=" + std::to_string((int)EXACT);
+      // (cos, sin) by rotation where the host can bound the heading increment: |dt * w| <= 0.36 rad, T <= 2000
+      const mppi_params& a = p->params;
+      const double dmax = (double)a.dt * std::fmax(std::fabs((double)a.wrange[0]), std::fabs((double)a.wrange[1]));
+      const bool rot = EXACT && std::isfinite(dmax) && dmax <= 0.36 && p->cfg.num_steps <= 2000;
+      const size_t lds_bb = sizeof(double2) * (size_t)p->cfg.num_steps + sizeof(float4) * (size_t)std::max(1, p->n_obstacles);
+      REQUIRE(lds_bb <= 64 * 1024, MPPI_ERR_INVALID, "%d disc obstacles and %d steps: more than 64 KiB of LDS", p->n_obstacles, p->cfg.num_steps);
+      if (rot)
+        MPPI_KLAUNCH((k_rollout_barebone<EXACT, true>), dim3(ceil_div(N, 64)), dim3(64), lds_bb,
+                     p->stream, d, p->obs_pos, p->obs_r, p->noise, p->u, p->costs);
+      else
+        MPPI_KLAUNCH((k_rollout_barebone<EXACT, false>), dim3(ceil_div(N, 64)), dim3(64), lds_bb,
+                     p->stream, d, p->obs_pos, p->obs_r, p->noise, p->u, p->costs);
+      p->last_rollout = "k_rollout_barebone exact=" + std::to_string((int)EXACT) + " rotation=" + std::to_string((int)rot);
       break;
     }
     default:

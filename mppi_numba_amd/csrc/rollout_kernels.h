@@ -1350,7 +1350,12 @@ __global__ void k_cvar_reduce(const float* __restrict__ slabs, int count, int n_
 // barebone notebook rollout: nominal unicycle, quadratic distance cost, disc
 // obstacles tested at the post-step position.
 // -------------------------------------------------------------------------
-template <bool EXACT>
+// ROT (round 6; exact math, host-proved |dt * w| <= 0.36 rad, T <= 2000): (cos, sin) of the heading by rotation with the
+// exact increment of the float32-rounded heading instead of a full float64 sincos per step (the reference's only
+// published timing is this kernel's configuration: N = 1000, T = 50 -- 16 waves walking 50 dependent steps), the noise
+// in batches of eight loads, and the state keeps integrating past the goal (only the cost is frozen), as in
+// k_rollout_fused.  Same operations on the same operands for everything that reaches the cost.
+template <bool EXACT, bool ROT = false>
 __global__ __launch_bounds__(64) void k_rollout_barebone(DevParams P, const float2* __restrict__ obs_pos,
                                                          const float* __restrict__ obs_r,
                                                          const float2* __restrict__ noise,
@@ -1358,7 +1363,14 @@ __global__ __launch_bounds__(64) void k_rollout_barebone(DevParams P, const floa
                                                          float* __restrict__ costs) {
   extern __shared__ double2 uos[];
   ktime_begin(P);
-  stage_control_ratios(P, u, uos);
+  // LDS: [T] double2 control ratios | [K] {float x, y, r, -} discs (a step looked each of them up in memory before:
+  // two dependent scalar loads per disc and step on a wave that has nothing else to run)
+  float4* discs = reinterpret_cast<float4*>(uos + P.n_steps);
+  for (int k = threadIdx.x; k < P.n_obstacles; k += 64) {
+    const float2 op = obs_pos[k];
+    discs[k] = make_float4(op.x, op.y, obs_r[k], 0.0f);
+  }
+  stage_control_ratios(P, u, uos);  // (ends with a barrier)
   const int n = blockIdx.x * 64 + threadIdx.x;
   const bool live = n < P.n_local;
   const int nn = live ? n : P.n_local - 1;
@@ -1367,48 +1379,89 @@ __global__ __launch_bounds__(64) void k_rollout_barebone(DevParams P, const floa
   float cost = 0.0f;
   double d2 = 1e9;
   bool done = false, reached = false;
-  for (int t = 0; t < T; ++t) {
-    float2 e = noise[tile_index(t, nn, T)];
-    float2 ut = u[t];
+  [[maybe_unused]] double rs = 0.0, rc = 1.0;
+  if (ROT) sincos_f64<false>((double)th, rs, rc);
+  const float2* col = noise + tile_index(0, nn, T);  // this lane's column; rows are 64 apart
+  auto step = [&](float2 ut, float2 e) {
     float v = clip_f32(ut.x + e.x, P.v_lo, P.v_hi);
     float w = clip_f32(ut.y + e.y, P.w_lo, P.w_hi);
     float nx, ny, nth;
     double nd2;
     float dtv = P.dt * v;  // float32 * float32 first (cell 3: dt_d*v_noisy*math.cos(...))
     if (EXACT) {
-      double s, c;
-      sincos_f64<false>((double)th, s, c);
-      nx = (float)fma((double)dtv, c, (double)x);
-      ny = (float)fma((double)dtv, s, (double)y);
+      double sn, cs;
+      if (ROT) { sn = rs; cs = rc; }
+      else sincos_f64<false>((double)th, sn, cs);
+      nx = (float)fma((double)dtv, cs, (double)x);
+      ny = (float)fma((double)dtv, sn, (double)y);
     } else {
-      float s, c;
-      sincosf(th, &s, &c);
-      nx = fmaf(dtv, c, x);
-      ny = fmaf(dtv, s, y);
+      float sn, cs;
+      sincosf(th, &sn, &cs);
+      nx = fmaf(dtv, cs, x);
+      ny = fmaf(dtv, sn, y);
     }
     nth = th + P.dt * w;
     double dx = (double)(P.xg - nx), dy = (double)(P.yg - ny);
     nd2 = fma(dx, dx, dy * dy);
     float c1 = (float)((double)cost + P.dist_weight * nd2);
     for (int k = 0; k < P.n_obstacles; ++k) {
-      float2 op = obs_pos[k];
+      const float4 op = discs[k];
       double ex = (double)(nx - op.x), ey = (double)(ny - op.y);
-      double rr = (double)obs_r[k] * (double)obs_r[k];
+      double rr = (double)op.z * (double)op.z;
       double diff = fma(ex, ex, ey * ey) - rr;
       double hit = (diff > 0.0) ? 0.0 : 1.0;
       c1 = (float)((double)c1 + hit * (double)P.obs_cost);
     }
-    if (!done) {
+    if (ROT) {
+      // (past the goal the state goes on -- nobody looks at it: cost, distance and the goal flag are frozen)
+      rotate_sincos_f64((double)nth - (double)th, rs, rc);  // exact increment of the ROUNDED heading
+      x = nx; y = ny; th = nth;
+      const bool hit_goal = nd2 <= (double)P.gt2, act = !done;
+      cost = act ? c1 : cost;
+      d2 = act ? nd2 : d2;
+      reached = reached || (act && hit_goal);
+      done = done || hit_goal;
+    } else if (!done) {
       x = nx; y = ny; th = nth; d2 = nd2; cost = c1;
       if (nd2 <= (double)P.gt2) { reached = true; done = true; }
     }
-    if (__all(done)) break;
+  };
+  if (ROT) {
+    float2 e_cur[kNoiseBatch], e_nxt[kNoiseBatch];
+#pragma unroll
+    for (int j = 0; j < kNoiseBatch; ++j) e_cur[j] = col[(size_t)min(j, T - 1) * 64];
+    int t0 = 0;
+    for (; t0 + kNoiseBatch <= T; t0 += kNoiseBatch) {
+#pragma unroll
+      for (int j = 0; j < kNoiseBatch; ++j) e_nxt[j] = col[(size_t)min(t0 + kNoiseBatch + j, T - 1) * 64];
+#pragma unroll
+      for (int j = 0; j < kNoiseBatch; ++j) step(u[t0 + j], e_cur[j]);
+#pragma unroll
+      for (int j = 0; j < kNoiseBatch; ++j) e_cur[j] = e_nxt[j];
+      if (__all(done)) break;
+    }
+    if (!__all(done))
+      for (int t = t0; t < T; ++t) {  // (batch registers shifted down, not indexed: see k_rollout_fused)
+        step(u[t], e_cur[0]);
+#pragma unroll
+        for (int j = 0; j + 1 < kNoiseBatch; ++j) e_cur[j] = e_cur[j + 1];
+      }
+  } else {
+    for (int t = 0; t < T; ++t) {
+      step(u[t], col[(size_t)t * 64]);
+      if (__all(done)) break;
+    }
   }
   cost = (float)((double)cost + (reached ? 0.0 : 1.0) * d2);
-  for (int t = 0; t < T; ++t) {
-    double cc = control_cost(P, uos[t], noise[tile_index(t, nn, T)]);
-    cost = (float)((double)cost + cc);
+  int t0 = 0;
+  for (; t0 + kNoiseBatch <= T; t0 += kNoiseBatch) {  // loads and products batched, the float32-rounded additions in order
+    double cc[kNoiseBatch];
+#pragma unroll
+    for (int j = 0; j < kNoiseBatch; ++j) cc[j] = control_cost(P, uos[t0 + j], col[(size_t)(t0 + j) * 64]);
+#pragma unroll
+    for (int j = 0; j < kNoiseBatch; ++j) cost = (float)((double)cost + cc[j]);
   }
+  for (int t = t0; t < T; ++t) cost = (float)((double)cost + control_cost(P, uos[t], col[(size_t)t * 64]));
   if (live) costs[n] = cost;
   ktime_end(P);
 }
