@@ -303,6 +303,7 @@ int mppi_planner_describe_last_rollout(mppi_planner* p, char* buf, int capacity)
 #define MPPI_DEBUG_NO_FOLDED_APPLY 256   /* sharded handle: every iteration's update by its own k_apply launch, never by the next rollout launch */
 #define MPPI_DEBUG_NO_REDUCE_FOLD 512    /* one GPU: every iteration's update by its own k_combine_tiles launch, never reduced and applied by the next rollout launch */
 #define MPPI_DEBUG_NO_SCAN_DIRECT 1024   /* a map the planner has stopped speculating on: k_rollout_pipe + k_update_rows (round 4) instead of k_rollout_scan_exact on its exact schedule (one launch per iteration) */
+#define MPPI_DEBUG_DROP_NOISE_FLAG 2048  /* test hook: the noise generator on the second stream does not announce itself -- the launch that waits for it gives up after ~60 ms, the next draining call returns MPPI_ERR_BUSY and the handle orders its streams with events from then on */
 int mppi_planner_set_debug_flags(mppi_planner* p, int flags);
 /* How long a workgroup of a rollout launch polls for the controls its sibling workgroups publish inside the launch
  * (update folded into the next rollout launch: rollout_scan*_kernel.h) before it gives the launch up: `polls` of

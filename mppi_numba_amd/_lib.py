@@ -25,6 +25,7 @@ DEBUG_NO_SCAN_KERNEL, DEBUG_SCAN_READ_NOISE, DEBUG_SCAN_FULL_TILES = 32, 64, 128
 DEBUG_NO_FOLDED_APPLY = 256
 DEBUG_NO_REDUCE_FOLD = 512
 DEBUG_NO_SCAN_DIRECT = 1024
+DEBUG_DROP_NOISE_FLAG = 2048
 ABI_VERSION = 1
 P2P_HANDLE_BYTES = 64
 

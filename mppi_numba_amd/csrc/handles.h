@@ -113,6 +113,9 @@ struct mppi_planner {
   unsigned long long progress_seq = 0;       // launches that signal, so far
   bool progress_signalled = false;           // the rollout launch of this iteration does
   bool progress_capable_last = false;        // ... the previous one did: no event is recorded in front of the next
+  unsigned int* flag_fault_host = nullptr;   // pinned, device-mapped: a bounded flag wait gave up (DevParams::flag_fault)
+  unsigned int* flag_fault_dev = nullptr;
+  bool stream_flags_off = false;             // ... after which this handle orders its two streams with events
   // hipGraph replay of the iteration loop (mppi_planner_set_graph_replay): two iterations
   // (one round of the noise double buffer) captured once, replayed while nothing a kernel
   // argument carries has changed.  See run_iterations.

@@ -375,14 +375,15 @@ static void settle_noise_wait(mppi_planner* p) {
   hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, p->kev_start, p->kev_stop, 0, __VA_ARGS__)
 static DevParams noise_flag_params(mppi_planner* p, DevParams d) {
   static const bool no_flag = getenv("MPPI_NO_NOISE_FLAG") != nullptr;  // developer switch (ablation): the event wait of rounds 1-5
-  if (p->noise_wait_pending && p->noise_flag_dev && !no_flag) {
+  d.flag_fault = p->flag_fault_dev;
+  if (p->noise_wait_pending && p->noise_flag_dev && !no_flag && !p->stream_flags_off) {
     d.noise_flag = p->noise_flag_dev;
     d.noise_flag_expect = p->noise_flag_expect;
     p->noise_wait_pending = false;
   } else {
     settle_noise_wait(p);
   }
-  if (p->progress_dev && !no_flag && !p->graph_on) {  // (a captured launch would signal a stale number)
+  if (p->progress_dev && !no_flag && !p->graph_on && !p->stream_flags_off) {  // (a captured launch would signal a stale number)
     d.progress = p->progress_dev;
     d.progress_value = ++p->progress_seq;
     p->progress_signalled = true;
@@ -1351,7 +1352,7 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
     if (buf_free_recorded) {
       HIP_TRY(hipStreamWaitEvent(p->noise_stream, p->ev_buf_free, 0));
     } else if (p->progress_signalled) {
-      hipLaunchKernelGGL(k_wait_progress, dim3(1), dim3(64), 0, p->noise_stream, p->progress_dev, p->progress_seq);
+      hipLaunchKernelGGL(k_wait_progress, dim3(1), dim3(64), 0, p->noise_stream, p->progress_dev, p->progress_seq, p->flag_fault_dev);
       HIP_TRY(hipGetLastError());
     } else {  // (neither: ordered behind the rollout launch itself)
       HIP_TRY(hipEventRecord(p->ev_buf_free, p->stream));
@@ -1362,8 +1363,10 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
     p->used_side_stream = true;
     if (p->noise_flag_dev && !p->graph_on) {
       p->noise_flag_expect = ++p->noise_flag_seq;
-      hipLaunchKernelGGL(k_set_noise_flag, dim3(1), dim3(1), 0, p->noise_stream, p->noise_flag_dev, p->noise_flag_expect);
-      HIP_TRY(hipGetLastError());
+      if (!(p->debug_flags & MPPI_DEBUG_DROP_NOISE_FLAG)) {  // (test hook: a generator the consumer never hears of)
+        hipLaunchKernelGGL(k_set_noise_flag, dim3(1), dim3(1), 0, p->noise_stream, p->noise_flag_dev, p->noise_flag_expect);
+        HIP_TRY(hipGetLastError());
+      }
     }
     HIP_TRY(hipEventRecord(p->ev_noise_ready, p->noise_stream));
     have_noise = p->noise_on_side_stream = true;

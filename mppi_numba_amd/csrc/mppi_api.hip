@@ -534,6 +534,7 @@ extern "C" int mppi_planner_destroy(mppi_planner* p) {
   dev_free(p->ktime_dev);
   dev_free(p->noise_flag_dev);
   dev_free(p->progress_dev);
+  if (p->flag_fault_host) (void)hipHostFree(p->flag_fault_host);
   if (p->spec_fail_host) (void)hipHostFree(p->spec_fail_host);
   dev_free(p->loop_state);
   dev_free(p->loop_xhist);
@@ -574,6 +575,9 @@ static int planner_alloc(mppi_planner* p) {
   HIP_TRY(hipMemset(p->noise_flag_dev, 0, sizeof(unsigned long long)));
   TRY(dev_alloc(&p->progress_dev, (size_t)1));
   HIP_TRY(hipMemset(p->progress_dev, 0, sizeof(unsigned long long)));
+  HIP_TRY(hipHostMalloc((void**)&p->flag_fault_host, sizeof(unsigned int), hipHostMallocMapped));
+  HIP_TRY(hipHostGetDevicePointer((void**)&p->flag_fault_dev, p->flag_fault_host, 0));
+  *p->flag_fault_host = 0u;
   HIP_TRY(hipEventCreate(&p->ev_begin));
   HIP_TRY(hipEventCreate(&p->ev_end));
   for (auto& e : p->ev_stage) HIP_TRY(hipEventCreate(&e));
@@ -897,9 +901,29 @@ static int check_fold_fault(mppi_planner* p) {
   return MPPI_OK;
 }
 
+// after the stream has drained: did a launch give up waiting for the noise generator on the second stream, or the
+// generator's gate for the launch it follows (rollout_kernels.h: DevParams::noise_flag / progress)?  Then the two
+// could not run side by side -- a tool that executes one kernel at a time (rocprofv3 --pmc), a device shared in an odd
+// way -- and this handle orders its streams with events from now on.
+static int check_flag_fault(mppi_planner* p) {
+  if (p->flag_fault_host && *p->flag_fault_host != 0u) {
+    *p->flag_fault_host = 0u;
+    p->stream_flags_off = true;
+    p->progress_capable_last = false;
+    drop_graphs(p);
+    return fail(MPPI_ERR_BUSY, "a launch waited in vain for the noise generator on the planner's second stream (or the generator "
+                               "for the launch it follows): the two cannot run side by side here (a tool that executes one "
+                               "kernel at a time, such as rocprofv3 --pmc?).  The control sequence of this call is not valid -- "
+                               "set it again; from now on this handle orders its streams with events (MPPI_NO_NOISE_FLAG=1 does "
+                               "so from the start)");
+  }
+  return MPPI_OK;
+}
+
 // what follows every wait for the stream (the wait itself: wait_for_stream on the control path, else drain_stream)
 static int after_drain(mppi_planner* p, bool review = true) {
   if (review) review_speculation(p);  // (the control loop's waits: is speculating on this map paying?)
+  TRY(check_flag_fault(p));
   TRY(check_peer_fault(p));
   TRY(check_fold_fault(p));
   return MPPI_OK;

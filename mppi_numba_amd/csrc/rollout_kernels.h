@@ -97,6 +97,11 @@ struct DevParams {
   // launch -- a marker that held the launch back by ~6 us (profiles/r06_ns_notes.md: timeline).
   unsigned long long* progress;
   unsigned long long progress_value;
+  // Both waits are bounded and fail soft: a wave that has polled for ~60 ms (the rollout's) / ~4 s (the gate's) raises this
+  // host-mapped word and the launch ends without its results; the call that waits for the stream next returns
+  // MPPI_ERR_BUSY and the handle orders its streams with events from then on.  (What it takes: a tool that runs one kernel
+  // at a time -- rocprofv3 --pmc does -- so that the generator cannot run beside the launch that waits for it.)
+  unsigned int* flag_fault;
 };
 
 // What differs between the problems of a batched handle (mppi_planner_set_instances).
@@ -109,25 +114,31 @@ struct BatchInst {
 
 // every wave of a workgroup, before its first load of the noise (see DevParams::noise_flag).  Every wave looks once; when
 // the generator has not finished yet ONE wave per workgroup polls -- thousands of waves on one word would be a hot spot of
-// their own -- and the others wait at the barrier.
-__device__ __forceinline__ void wait_for_noise(const DevParams& P) {
-  if (P.noise_flag == nullptr) return;  // (uniform over the launch)
+// their own -- and the others wait at the barrier.  false: the generator did not finish within the bound (flag_fault raised):
+// the caller leaves the kernel.
+__device__ __forceinline__ bool wait_for_noise(const DevParams& P) {
+  if (P.noise_flag == nullptr) return true;  // (uniform over the launch)
+  __shared__ int gave_up;
   const bool ready = __builtin_amdgcn_readfirstlane(
       (int)(__hip_atomic_load(P.noise_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.noise_flag_expect)) != 0;
-  if (!ready && threadIdx.x < 64) {
-    for (unsigned int polls = 0;; ++polls) {
+  if (threadIdx.x < 64) {
+    bool there = ready;
+    for (unsigned int polls = 0; !there && polls < (1u << 16); ++polls) {
       __builtin_amdgcn_s_sleep(32);
-      if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(P.noise_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.noise_flag_expect)))
-        break;
-      // (the generator was enqueued before this launch and needs no resource this launch holds: seconds of waiting mean
-      //  a broken device, not a slow one)
-      if (polls > (1u << 25)) __builtin_trap();
+      there = __builtin_amdgcn_readfirstlane(
+                  (int)(__hip_atomic_load(P.noise_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= P.noise_flag_expect)) != 0;
+    }
+    if (threadIdx.x == 0) {
+      gave_up = there ? 0 : 1;
+      if (!there && P.flag_fault) __hip_atomic_store(P.flag_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   __syncthreads();
+  if (gave_up) return false;
   // the generator finished while this kernel was running: nothing of its output may be served from this kernel's caches
   // (a wave that saw the flag at its first look needs nothing: the kernel's own start made those stores visible)
   if (!ready) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return true;
 }
 
 __global__ void k_set_noise_flag(unsigned long long* flag, unsigned long long value) {
@@ -143,11 +154,13 @@ __device__ __forceinline__ void signal_progress(const DevParams& P) {
 // One wave on the second stream, in front of the generator: returns when the main stream's launch number `value` has
 // started.  Bounded (a main stream that never gets there is an error the host reports elsewhere; the generator then
 // simply runs).
-__global__ __launch_bounds__(64) void k_wait_progress(const unsigned long long* progress, unsigned long long value) {
+__global__ __launch_bounds__(64) void k_wait_progress(const unsigned long long* progress, unsigned long long value,
+                                                      unsigned int* flag_fault) {
   for (unsigned int polls = 0; polls < (1u << 24); ++polls) {
     if (__builtin_amdgcn_readfirstlane((int)(__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= value))) return;
     __builtin_amdgcn_s_sleep(8);
   }
+  if (threadIdx.x == 0 && flag_fault) __hip_atomic_store(flag_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // (one slot per wave, plain stores: atomics of a few thousand waves on one address took longer than the kernel)
@@ -496,7 +509,10 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
   const bool live = n < N;
   const int nn = live ? n : N - 1;
   const float2* col = noise + tile_index(0, nn, T);  // this lane's column; rows are 64 apart
-  wait_for_noise(P);
+  if (!wait_for_noise(P)) {  // (workgroup-uniform; reported by the host: DevParams::flag_fault)
+    ktime_end(P);
+    return;
+  }
 
   float x = P.x0, y = P.y0, th = P.th0, cost = 0.0f;
   [[maybe_unused]] float cc32 = 0.0f;
