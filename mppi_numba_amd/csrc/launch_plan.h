@@ -737,7 +737,7 @@ static int try_launch_pipe(mppi_planner* p, DevParams& d, const DetRegime& r, bo
     const size_t map_bytes = lds_win - sizeof(double2) * ((size_t)T + (size_t)(T + 1) / 2);
     int pairs = ceil_div(ceil_div(N, 64), p->num_cus);  // wave triples per workgroup
     if (pairs < 1) pairs = 1;
-    if (pairs > 5) pairs = 5;                            // 15 waves = 960 threads
+    if (pairs > kPipeMaxTriples) pairs = kPipeMaxTriples + 1;  // (beyond the kernel's launch bounds: the throughput kernel's)
     // batched handle: the triples of a workgroup share one problem's window and controls
     if (p->inst_set) while (p->inst_tiles % pairs != 0) --pairs;
     const size_t budget = (size_t)p->lds_per_cu - 1024;
@@ -759,8 +759,7 @@ static int try_launch_pipe(mppi_planner* p, DevParams& d, const DetRegime& r, bo
     // N x T, us per iteration pipe | fused: 8192 x 200 44 | 79; 16384 x 100 39 | 53; 16384 x 200 63 | 85;
     // 32768 x 100 55 | 60; 32768 x 200 (chunks of two) 102 | 77; 49152 x 100 (three triples) 74 | 48:
     // profiles/r06_families.md).  Beyond that the fused kernel, 4..16 waves per CU, has the better throughput.
-    static const int max_triples = getenv("MPPI_PIPE_MAX_TRIPLES") ? atoi(getenv("MPPI_PIPE_MAX_TRIPLES")) : 2;  // developer switch (experiments)
-    const bool latency_regime = pairs <= max_triples && (pairs == 1 || chunk >= 4) && ceil_div(ceil_div(N, 64), pairs) <= p->num_cus;
+    const bool latency_regime = pairs <= kPipeMaxTriples && (pairs == 1 || chunk >= 4) && ceil_div(ceil_div(N, 64), pairs) <= p->num_cus;
     if (chunk > 0 && latency_regime) {
       // control-cost products in LDS when there is room, else in a global scratch array
       const size_t cc_bytes = (size_t)pairs * T * 64 * sizeof(double);

@@ -1036,8 +1036,11 @@ __device__ __forceinline__ void pipe_tile_body(DevParams P, const uint16_t* __re
   }
 }
 
+// (at most two wave triples per workgroup -- launch_plan.h: try_launch_pipe --: six waves, so that the three roles' one
+//  register allocation may use 256 registers per lane instead of the 128 a workgroup of 1024 threads would leave)
+constexpr int kPipeMaxTriples = 2;
 template <int C, bool POW2RES, bool CC_LDS>
-__global__ void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16,
+__global__ __launch_bounds__(192 * kPipeMaxTriples) void k_rollout_pipe(DevParams P, const uint16_t* __restrict__ cells16,
                                const float2* __restrict__ noise, const float2* __restrict__ u,
                                float* __restrict__ costs, float* __restrict__ w_rel,
                                float* __restrict__ tile_beta, double* __restrict__ cc_scratch, int map_bytes,
