@@ -1018,8 +1018,9 @@ __device__ __forceinline__ void pipe_tile_body(DevParams P, const uint16_t* __re
       }
     };
     // (three register sets, two batches ahead -- enough to cover the L2 latency of the global scratch at T = 200,
-    //  where this walk runs at 57 cycles per addition -- made the LAUNCH 21 us slower: the kernel's register allocation
-    //  is one for all roles, and 144 batch registers moved the state role's; measured, round 5)
+    //  where this walk runs at 57 cycles per addition -- made the LAUNCH 21 us slower in round 5: the kernel's register
+    //  allocation is one for all roles and was capped at 128, and 144 batch registers moved the state role's; with round
+    //  6's launch bound of two triples -- 256 registers -- it fits and changes nothing: 36.4 vs 36.5 us at the T = 200 shard)
     tail_load(ca, 0);
     for (int t0 = 0; t0 < T; t0 += 2 * kTailBatch) {
       tail_load(cb, t0 + kTailBatch);
