@@ -57,3 +57,27 @@ def test_a_generator_that_never_announces_itself_fails_soft_and_the_handle_falls
     got = planner.costs_d.copy_to_host()
     want = oracle_costs(w, params, lin, ang, noise, u_in)
     assert (ulp_diff_f32(got, want) == 0).mean() >= 0.999
+
+
+def test_event_ordered_loop_behind_the_developer_switch_gives_the_same_controls():
+    """MPPI_NO_NOISE_FLAG=1 (read once per process: a process of its own): the two streams ordered by events as in rounds
+    1-5 -- what a handle falls back to after a flag fault, and what tools/r06_profiles.sh uses for the counter passes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, bench\n"
+            "w, cfg, lin, ang, p, params = bench.build_planner('ns')\n"
+            "p.solve(); p.iterate_async(5); p.synchronize()\n"
+            "assert p.last_rollout_kernel().startswith('k_rollout_fused')\n"
+            "np.save(sys.argv[1], p.u_cur_d.copy_to_host())\n") % root
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        outs = []
+        for tag, env in (("flags", {}), ("events", {"MPPI_NO_NOISE_FLAG": "1"})):
+            path = os.path.join(d, tag + ".npy")
+            run = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True,
+                                 timeout=180, cwd=root)
+            assert run.returncode == 0, run.stderr[-800:]
+            outs.append(np.load(path))
+    assert np.isfinite(outs[0]).all() and np.array_equal(outs[0], outs[1])
