@@ -82,6 +82,7 @@ class MPPI_Numba(object):
         self.rng_states_d = None
         self.state_rollout_batch_d = None
         self.device_var_initialized = False
+        self._discs_key = None  # what the device's disc arrays hold (None: nothing handed over yet)
         self.reset()
 
     def __del__(self):
@@ -147,32 +148,42 @@ class MPPI_Numba(object):
         return True
 
     def move_mppi_task_vars_to_device(self):
+        """Pack the task description as notebook cell 3 casts it (np.float32 everywhere except dist_weight) and hand it to
+        the library.  (Assigning a Python / numpy scalar to a c_float field rounds float64 -> float32 to nearest, which is
+        what the np.float32(...) casts do: no numpy temporaries on the control path -- the notebook times solve() as a
+        whole, `bench.py --workload bb` likewise.)"""
         p = self.params
         c = _lib.Params()
         for name, count in (("x0", 3), ("xgoal", 2), ("vrange", 2), ("wrange", 2), ("u_std", 2)):
-            arr = _f32(p[name])
+            src, dst = p[name], getattr(c, name)
             for i in range(count):
-                getattr(c, name)[i] = arr[i]
-        c.dt = np.float32(p['dt'])
-        c.goal_tolerance = np.float32(p['goal_tolerance'])
+                dst[i] = float(src[i])
+        c.dt = float(p['dt'])
+        c.goal_tolerance = float(p['goal_tolerance'])
         c.v_post_rollout = 0.0
-        c.lambda_weight = np.float32(p['lambda_weight'])
+        c.lambda_weight = float(p['lambda_weight'])
         c.cvar_alpha = 1.0
-        c.obs_cost = np.float32(DEFAULT_OBS_COST if 'obs_penalty' not in p else p['obs_penalty'])
+        c.obs_cost = float(DEFAULT_OBS_COST if 'obs_penalty' not in p else p['obs_penalty'])
         c.unknown_cost = 0.0
         c.res, c.xlo, c.ylo = 1.0, 0.0, 0.0
         c.dist_weight = float(DEFAULT_DIST_WEIGHT if 'dist_weight' not in p else p['dist_weight'])
         c.alpha_dyn = 1.0
         c.num_opt = int(p['num_opt'])
         _lib.call("mppi_planner_set_params", self._handle, C.byref(c))
+        # the discs: handed over when they have changed (the notebook uploads them with every solve)
         if "obstacle_positions" in p and "obstacle_radius" in p:
-            pos = np.ascontiguousarray(_f32(p['obstacle_positions']).reshape(-1, 2))
-            rad = np.ascontiguousarray(_f32(p['obstacle_radius']).reshape(-1))
-            assert len(pos) == len(rad)
-            _lib.call("mppi_planner_set_disc_obstacles", self._handle, _lib.ptr(pos, C.c_float),
-                      _lib.ptr(rad, C.c_float), len(rad))
-        else:
+            op, orad = np.asarray(p['obstacle_positions']), np.asarray(p['obstacle_radius'])
+            key = (op.dtype.str, op.shape, op.tobytes(), orad.dtype.str, orad.shape, orad.tobytes())
+            if key != self._discs_key:
+                pos = np.ascontiguousarray(_f32(op).reshape(-1, 2))
+                rad = np.ascontiguousarray(_f32(orad).reshape(-1))
+                assert len(pos) == len(rad)
+                _lib.call("mppi_planner_set_disc_obstacles", self._handle, _lib.ptr(pos, C.c_float),
+                          _lib.ptr(rad, C.c_float), len(rad))
+                self._discs_key = key
+        elif self._discs_key != ():
             _lib.call("mppi_planner_set_disc_obstacles", self._handle, None, None, 0)
+            self._discs_key = ()
 
     def solve(self):
         if not self.check_solve_conditions():
