@@ -113,6 +113,8 @@ struct mppi_planner {
   unsigned long long progress_seq = 0;       // launches that signal, so far
   bool progress_signalled = false;           // the rollout launch of this iteration does
   bool progress_capable_last = false;        // ... the previous one did: no event is recorded in front of the next
+  bool update_signals = false;               // the coming k_update_rows launch is to signal its start (generator beside the update)
+  bool update_signalled = false;             // ... and it did (that kernel ran)
   unsigned int* flag_fault_host = nullptr;   // pinned, device-mapped: a bounded flag wait gave up (DevParams::flag_fault)
   unsigned int* flag_fault_dev = nullptr;
   bool stream_flags_off = false;             // ... after which this handle orders its two streams with events

@@ -1164,17 +1164,29 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
   // rows per workgroup: see k_update_rows
   const bool many_rows = (long)T * p->B >= 2048;
   const dim3 grid(many_rows ? ceil_div(T, 4) : T, p->B);
+// (slim: 256 threads with four times the loads in flight each and at most two workgroups per CU -- 60 KB of LDS each --,
+//  for the launches beside which the next iteration's noise is generated: k_update_rows, THREADS)
 #define MPPI_LAUNCH_ROWS(APPLY, TC, FC)                                                                         \
-  MPPI_KLAUNCH((k_update_rows<APPLY, TC, FC>), grid, dim3(kRowThreads), lds, p->stream,                   \
-                     FC ? p->costs : p->w_rel, p->tile_beta, p->n_inst, p->inst_tiles, p->noise, T,             \
-                     a.lambda_weight, my_packet, p->u, p->u_prev, (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0], a.vrange[1],      \
-                     a.wrange[0], a.wrange[1], p->stats, p->graph_on ? p->gen_dev : (unsigned long long*)nullptr,              \
-                     p->ktime_update_slot, p->ktime_waves)
+  do {                                                                                                          \
+    if (slim)                                                                                                   \
+      MPPI_KLAUNCH((k_update_rows<APPLY, TC, FC, 256>), grid, dim3(256), std::max(lds, (size_t)60 * 1024), p->stream, \
+                   FC ? p->costs : p->w_rel, p->tile_beta, p->n_inst, p->inst_tiles, p->noise, T,               \
+                   a.lambda_weight, my_packet, p->u, p->u_prev, (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0], a.vrange[1], \
+                   a.wrange[0], a.wrange[1], p->stats, p->graph_on ? p->gen_dev : (unsigned long long*)nullptr, \
+                   p->ktime_update_slot, p->ktime_waves, p->progress_dev, p->progress_seq);                     \
+    else                                                                                                        \
+      MPPI_KLAUNCH((k_update_rows<APPLY, TC, FC>), grid, dim3(kRowThreads), lds, p->stream,                     \
+                   FC ? p->costs : p->w_rel, p->tile_beta, p->n_inst, p->inst_tiles, p->noise, T,               \
+                   a.lambda_weight, my_packet, p->u, p->u_prev, (p->mirror_now ? p->u_host_dev : (float2*)nullptr), a.vrange[0], a.vrange[1], \
+                   a.wrange[0], a.wrange[1], p->stats, p->graph_on ? p->gen_dev : (unsigned long long*)nullptr, \
+                   p->ktime_update_slot, p->ktime_waves, (unsigned long long*)nullptr, 0ull);                   \
+  } while (0)
 #define MPPI_LAUNCH_ROWS_TC(APPLY, FC)        \
   do {                                        \
     if (many_rows) MPPI_LAUNCH_ROWS(APPLY, 4, FC); \
     else MPPI_LAUNCH_ROWS(APPLY, 1, FC);           \
   } while (0)
+  const bool slim = p->update_signals;
   if (apply_here && from_costs) MPPI_LAUNCH_ROWS_TC(true, true);
   else if (apply_here) MPPI_LAUNCH_ROWS_TC(true, false);
   else if (from_costs) MPPI_LAUNCH_ROWS_TC(false, true);
@@ -1183,6 +1195,7 @@ static int launch_update_local(mppi_planner* p, bool apply_here) {
 #undef MPPI_LAUNCH_ROWS
   if (p->graph_on) ++p->bumps_launched;
   HIP_TRY(hipGetLastError());
+  p->update_signalled = p->update_signals;
   return MPPI_OK;
 }
 
@@ -1377,6 +1390,20 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
     }
   }
   p->progress_capable_last = p->progress_signalled;
+  // Where the rollout fills the SIMDs by itself (more than 8 of its waves per CU: the batched handles, C5) a generator
+  // beside it only takes its issue slots; but the update behind it is bound by memory: there the next iteration's noise is
+  // generated beside the UPDATE launch -- which runs slim (k_update_rows<.., 256>: a quarter of the waves, the same bytes
+  // in flight) and signals its start to the generator's gate kernel.
+  static const bool no_beside_update = getenv("MPPI_NO_NOISE_BESIDE_UPDATE") != nullptr ||  // developer switch (ablation)
+                                       getenv("MPPI_NO_NOISE_FLAG") != nullptr;             // (no flags: no second stream here)
+  const bool beside_update = want_next && !have_noise && !side_stream_pays && !no_side_stream && !no_beside_update && !p->graph_on &&
+                             !prof && !defer_exchange && p->noise_flag_dev && p->progress_dev && !p->stream_flags_off &&
+                             p->cfg.rng == MPPI_RNG_PHILOX && (long)p->n_local * p->cfg.num_steps >= 4L * 1000 * 1000 &&
+                             !p->scan_packets_fresh && p->cfg.world_size == 1 && !p->comm && p->m_count == 1 &&
+                             2 * sizeof(float) * (size_t)p->inst_tiles <= 60 * 1024;
+  p->update_signals = beside_update;
+  p->update_signalled = false;
+  if (beside_update) ++p->progress_seq;
   p->next_noise_wanted = false;
   p->scan_gen_now = false;
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[2], p->stream));
@@ -1395,7 +1422,21 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
     const int rc = launch_update(p, prof, defer_exchange, may_leave_apply);
     p->kev_start = p->kev_stop = nullptr;
     p->ktime_update_slot = nullptr;
+    p->update_signals = false;
     TRY(rc);
+    if (p->update_signalled) {  // the generator, gated on this update launch's start
+      p->update_signalled = false;
+      hipLaunchKernelGGL(k_wait_progress, dim3(1), dim3(64), 0, p->noise_stream, p->progress_dev, p->progress_seq, p->flag_fault_dev);
+      HIP_TRY(hipGetLastError());
+      TraceRange tr("mppi:noise_beside_update");
+      TRY(launch_noise(p, p->noise_buf[p->noise_cur ^ 1], p->noise_stream));
+      p->used_side_stream = true;
+      p->noise_flag_expect = ++p->noise_flag_seq;
+      hipLaunchKernelGGL(k_set_noise_flag, dim3(1), dim3(1), 0, p->noise_stream, p->noise_flag_dev, p->noise_flag_expect);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(p->ev_noise_ready, p->noise_stream));
+      have_noise = p->noise_on_side_stream = true;
+    }
     // (an update left to the next rollout launch has no launch of its own to time)
     if (ktime_slot >= 0 && (size_t)ktime_slot < p->ktime_update_ran.size()) p->ktime_update_ran[(size_t)ktime_slot] = !p->reduce_pending;
   }

@@ -425,8 +425,14 @@ constexpr int kRowThreads = 1024;
 // formed here with the very expressions of emit_tile_weights (same bits), which saves the
 // k_tile_weights launch after the rollout kernels that have no such epilogue (CVaR, speed-map
 // fallback, barebone).
-template <bool APPLY, int TC, bool FROM_COSTS = false>
-__global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __restrict__ w_rel,
+// THREADS (round 6): 1024, or 256 with four times the loads in flight per thread -- the same bytes on their way with a
+// quarter of the waves, for the launches beside which the next iteration's noise generator runs (the batched handles:
+// launch_plan.h, beside_update): the generator is bound by instruction issue and needs the wave slots this kernel, bound
+// by memory, can do without.  Each thread still sums its strided subset in increasing i; the strides differ, so `u`
+// differs in its last bits between the two (held to 1e-5 of the range against the oracle either way).
+// progress: "this launch has started" for the gate kernel in front of that generator (rollout_kernels.h: k_wait_progress).
+template <bool APPLY, int TC, bool FROM_COSTS = false, int THREADS = kRowThreads>
+__global__ __launch_bounds__(THREADS) void k_update_rows(const float* __restrict__ w_rel,
                                                              const float* __restrict__ tile_beta, int n, int n_tiles,
                                                              const float2* __restrict__ noise, int n_steps,
                                                              float lambda, double* __restrict__ rank_packet,
@@ -434,17 +440,21 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
                                                              float2* __restrict__ u_mirror, float v_lo, float v_hi,
                                                              float w_lo, float w_hi, double* __restrict__ stats,
                                                              unsigned long long* __restrict__ gen_counter,
-                                                             unsigned long long* __restrict__ ktime, int ktime_waves) {
+                                                             unsigned long long* __restrict__ ktime, int ktime_waves,
+                                                             unsigned long long* __restrict__ progress,
+                                                             unsigned long long progress_value) {
   extern __shared__ float scale_sh[];  // [n_tiles]
+  if (progress && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    __hip_atomic_store(progress, progress_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // mppi_planner_time_kernels (else nullptr): when every wave of this launch entered / left (as DevParams::ktime)
-  const int ktime_slot = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * (kRowThreads / 64) + (int)(threadIdx.x >> 6);
+  const int ktime_slot = ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * (THREADS / 64) + (int)(threadIdx.x >> 6);
   if (ktime && (threadIdx.x & 63) == 0) ktime[ktime_slot] = (unsigned long long)wall_clock64();
   // graph replay: one more generation of noise has been consumed (rng_kernels.h NoiseJob); no
   // generator runs while an update does
   if (gen_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *gen_counter += 1ull;
   constexpr int kCols = 1 + 2 * TC;    // den, then (x, y) per row
-  __shared__ double red[kRowThreads / 64][kCols];
-  __shared__ float redf[kRowThreads / 64];
+  __shared__ double red[THREADS / 64][kCols];
+  __shared__ float redf[THREADS / 64];
   const int t0 = blockIdx.x * TC, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   {
     const int inst = blockIdx.y;
@@ -464,7 +474,7 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
   size_t row_off[TC];
 #pragma unroll
   for (int j = 0; j < TC; ++j) row_off[j] = (size_t)min(t0 + j, n_steps - 1) * 64;
-  constexpr int UN = TC == 1 ? 8 : 2;  // independent loads in flight per thread: UN * (TC + 1)
+  constexpr int UN = (TC == 1 ? 8 : 2) * (kRowThreads / THREADS);  // independent loads in flight per thread: UN * (TC + 1)
   // The first batch of this thread's weights and noise is requested before the minimum / scale
   // prologue below, which needs ~2k cycles of its own: the stream's first round trip hides behind it.
   // (loads return in order: the tile minima the prologue waits for go first)
@@ -472,11 +482,11 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
   if (!FROM_COSTS && (int)threadIdx.x < n_tiles) tb0 = tile_beta[threadIdx.x];
   float wr0[UN];
   float2 e0[UN][TC];
-  const bool have0 = (int)threadIdx.x + (UN - 1) * kRowThreads < n;
+  const bool have0 = (int)threadIdx.x + (UN - 1) * THREADS < n;
   if (have0) {
 #pragma unroll
     for (int k = 0; k < UN; ++k) {
-      const int idx = threadIdx.x + k * kRowThreads;
+      const int idx = threadIdx.x + k * THREADS;
       wr0[k] = w_rel[idx];
       const float2* tile = noise + (size_t)(idx >> 6) * n_steps * 64 + (idx & 63);
 #pragma unroll
@@ -485,7 +495,7 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
   }
   float* tb_sh = scale_sh + n_tiles;  // FROM_COSTS: [n_tiles] tile minima
   if (FROM_COSTS) {
-    for (int g = wave; g < n_tiles; g += kRowThreads / 64) {
+    for (int g = wave; g < n_tiles; g += THREADS / 64) {
       const int i = g * 64 + lane;
       const float m = wave_min_f32(i < n ? w_rel[i] : __builtin_inff());
       if (lane == 0) tb_sh[g] = m;
@@ -494,26 +504,26 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
     tile_beta = tb_sh;
   }
   float b = tb0;
-  for (int g = threadIdx.x + (FROM_COSTS ? 0 : kRowThreads); g < n_tiles; g += kRowThreads) b = fminf(b, tile_beta[g]);
+  for (int g = threadIdx.x + (FROM_COSTS ? 0 : THREADS); g < n_tiles; g += THREADS) b = fminf(b, tile_beta[g]);
   b = wave_min_f32(b);
   if (lane == 0) redf[wave] = b;
   __syncthreads();
   MPPI_STAMP(stamp_wg, 513);
   float beta = redf[0];
-  for (int k = 1; k < kRowThreads / 64; ++k) beta = fminf(beta, redf[k]);
+  for (int k = 1; k < THREADS / 64; ++k) beta = fminf(beta, redf[k]);
   if (!FROM_COSTS && (int)threadIdx.x < n_tiles) scale_sh[threadIdx.x] = (float)exp(neg_inv_lambda * (double)(tb0 - beta));
-  for (int g = threadIdx.x + (FROM_COSTS ? 0 : kRowThreads); g < n_tiles; g += kRowThreads)
+  for (int g = threadIdx.x + (FROM_COSTS ? 0 : THREADS); g < n_tiles; g += THREADS)
     scale_sh[g] = (float)exp(neg_inv_lambda * (double)(tile_beta[g] - beta));
   __syncthreads();
   MPPI_STAMP(stamp_wg, 514);
   double den = 0.0, nx[TC], ny[TC];
 #pragma unroll
   for (int j = 0; j < TC; ++j) nx[j] = ny[j] = 0.0;
-  int i = threadIdx.x;                 // kRowThreads is a multiple of 64: i>>6 is the tile, i&63 the lane
+  int i = threadIdx.x;                 // THREADS is a multiple of 64: i>>6 is the tile, i&63 the lane
   auto consume = [&](int at, float (&wr)[UN], float2 (&e)[UN][TC]) {
 #pragma unroll
     for (int k = 0; k < UN; ++k) {
-      const int tile = (at + k * kRowThreads) >> 6;
+      const int tile = (at + k * THREADS) >> 6;
       if (FROM_COSTS) wr[k] = (float)exp(neg_inv_lambda * (double)(wr[k] - tb_sh[tile]));  // emit_tile_weights
       double w = (double)scale_sh[tile] * (double)wr[k];
       den += w;
@@ -526,14 +536,14 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
   };
   if (have0) {
     consume(i, wr0, e0);
-    i += UN * kRowThreads;
+    i += UN * THREADS;
   }
-  for (; i + (UN - 1) * kRowThreads < n; i += UN * kRowThreads) {
+  for (; i + (UN - 1) * THREADS < n; i += UN * THREADS) {
     float wr[UN];
     float2 e[UN][TC];
 #pragma unroll
     for (int k = 0; k < UN; ++k) {
-      const int idx = i + k * kRowThreads;
+      const int idx = i + k * THREADS;
       wr[k] = w_rel[idx];
       const float2* tile = noise + (size_t)(idx >> 6) * n_steps * 64 + (idx & 63);
 #pragma unroll
@@ -541,7 +551,7 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
     }
     consume(i, wr, e);
   }
-  for (; i < n; i += kRowThreads) {
+  for (; i < n; i += THREADS) {
     float wr1 = w_rel[i];
     if (FROM_COSTS) wr1 = (float)exp(neg_inv_lambda * (double)(wr1 - tb_sh[i >> 6]));
     double w = (double)scale_sh[i >> 6] * (double)wr1;
@@ -572,7 +582,7 @@ __global__ __launch_bounds__(kRowThreads) void k_update_rows(const float* __rest
   __syncthreads();
   if (threadIdx.x < kCols) {  // fixed wave order: ((w0 + w1) + w2) + ...
     double acc = red[0][threadIdx.x];
-    for (int k = 1; k < kRowThreads / 64; ++k) acc += red[k][threadIdx.x];
+    for (int k = 1; k < THREADS / 64; ++k) acc += red[k][threadIdx.x];
     red[0][threadIdx.x] = acc;
   }
   __syncthreads();
