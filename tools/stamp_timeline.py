@@ -47,50 +47,7 @@ def main():
     t0 = st[0]
     rel = lambda v: int(v - t0) if v else None
     out = {"rollout": {}, "update": {}, "noise_wg": {}}
-    if "k_rollout_deep" in planner.last_rollout_kernel():
-        names = ["P", "H", "S", "C", "V"]
-        print("k_rollout_deep, workgroup 5: per wave [before first barrier, after it, arrival at the barrier of "
-              "intervals 0.., (C) tail begin, tail end]; cycles from the workgroup's first stamp")
-        arr = {}
-        for w, name in enumerate(names):
-            row = st[64 + 32 * w: 64 + 32 * w + 32]
-            vals = [rel(v) for v in row]
-            out["rollout"][name] = vals
-            arr[name] = [v for v in vals[2:26] if v is not None]
-            print("  %-2s" % name, vals)
-        n_iv = min(len(a) for a in arr.values())
-        release = [max(arr[nm][i] for nm in names) for i in range(n_iv)]
-        print("  barrier releases:", release)
-        print("  interval lengths:", [b - a for a, b in zip(release[:-1], release[1:])])
-        for nm in names:
-            print("  work of %-2s per interval (arrival - previous release):" % nm,
-                  [arr[nm][i] - release[i - 1] for i in range(1, n_iv)])
-        u = st[512:520]
-        out["update"] = [int(v - u[0]) if v else None for v in u]
-        print("update kernel (middle WG) phases, cycles from its entry:", out["update"])
-        life = st[2048:2048 + 1024].reshape(512, 2)
-        ok = (life[:, 0] > 0) & (life[:, 1] > life[:, 0])
-        dur = (life[:, 1] - life[:, 0])[ok]
-        ids = np.flatnonzero(ok)
-        roll = dur[ids < 128] if ok[:128].any() else dur
-        rest = dur[ids >= 128]
-        print("workgroup lifetimes (entry -> exit, cycles): rollout tiles n=%d min %d median %d max %d | "
-              "noise workgroups n=%d min %d median %d max %d"
-              % (len(roll), roll.min(), np.median(roll), roll.max(), len(rest), rest.min() if len(rest) else 0,
-                 np.median(rest) if len(rest) else 0, rest.max() if len(rest) else 0))
-        # entry skew inside one XCD (clocks of different XCDs are not comparable): workgroups 0, 8, 16, ...
-        x0 = life[0:128:8, 0]
-        print("entry times of tiles 0, 8, 16, ... (one XCD), relative to the first:", [int(v - x0.min()) for v in x0])
-        e0 = life[0:128:8, 1]
-        print("exit times of the same, relative to the first entry:", [int(v - x0.min()) for v in e0])
-        sub = st[1100:1108]
-        if sub[0]:
-            print("P inside interval 5 (top, noise waited for, computed, next loads issued, LDS stores issued), "
-                  "cycles from the top:", [int(v - sub[0]) if v else None for v in sub[:5]])
-        if args.json:
-            with open(args.json, "w") as fh:
-                json.dump(out, fh)
-        return
+    # (the branch that read the five-stage speculative pipeline's stamps went with that kernel: round 6)
     names = sorted({int(i) // 64 for i in np.flatnonzero(st[64:512]) + 64})
     for r in names:
         base = 64 * r
