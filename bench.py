@@ -924,7 +924,8 @@ def main():
                                "frac": bytes_iter / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "algorithmic_bytes_per_step": bytes_iter},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world * group_size == 1:
+        # (the CPU legs are timed at N = 1 only: with several ranks the others would sit at the closing barrier for it)
         with quiet:
             out["cpu_baseline"] = cpu_baseline(w, params, lin, ang, planner)
         out["cpu_baseline_reference"] = reference_cpu_path()
