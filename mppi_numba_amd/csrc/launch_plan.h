@@ -642,6 +642,12 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
     const size_t lds = scan_fallback_place(p, d, plan.chunk_waves, plan.lds, &fallback.offset, &fallback.map_bytes);
     if (lds) plan.lds = lds;
   }
+  // Developer experiment (profiles/r06_overlap_notes.md; TIMING ONLY -- the launches race on the tile packets): every
+  // other launch goes to the second stream with nothing ordering it behind its predecessor, i.e. the upper bound of what
+  // "launch k+1 before launch k ends"  could hide.
+  static const bool alt_streams = getenv("MPPI_EXPERIMENT_ALT_STREAMS") != nullptr;
+  static unsigned alt_toggle = 0;
+  hipStream_t scan_stream = (alt_streams && (alt_toggle++ & 1)) ? p->noise_stream : p->stream;
 #define MPPI_LAUNCH_SCAN_EXACT(P2, GEN)                                                                    \
   do {                                                                                                    \
     auto kern = speed ? k_rollout_scan_exact<P2, GEN, false, true>                                        \
@@ -649,7 +655,7 @@ static int launch_scan(mppi_planner* p, const DevParams& d, const ScanPlan& plan
     if (plan.lds > 64 * 1024)                                                                             \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds));            \
-    MPPI_KLAUNCH(kern, dim3(tiles), dim3(64 * plan.waves), plan.lds, p->stream, d, p->cells16, p->cells,  \
+    MPPI_KLAUNCH(kern, dim3(tiles), dim3(64 * plan.waves), plan.lds, scan_stream, d, p->cells16, p->cells, \
                  p->noise, gen_job, p->u, p->costs, p->w_rel, pk, pend, fallback,                          \
                  (const int8_t*)(speed ? p->risk_ref : nullptr));                                          \
   } while (0)
@@ -1606,6 +1612,11 @@ static int run_iterations(mppi_planner* p, mppi_tdm* lin, mppi_tdm* ang, int ite
     }
     for (; k < iterations; ++k) TRY(launch_iteration(p, d, have_noise, true, false, false, k + 1 < iterations));
     p->primed = have_noise;
+  }
+  static const bool alt_streams = getenv("MPPI_EXPERIMENT_ALT_STREAMS") != nullptr;
+  if (alt_streams) {  // (developer experiment, launch_scan: the second stream joins here)
+    HIP_TRY(hipEventRecord(p->ev_noise_ready, p->noise_stream));
+    HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_noise_ready, 0));
   }
   if (timed) {
     HIP_TRY(hipEventRecord(p->ev_end, p->stream));
