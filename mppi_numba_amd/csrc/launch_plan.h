@@ -1302,10 +1302,12 @@ static int launch_iteration(mppi_planner* p, const DevParams& d, bool& have_nois
                             bool defer_exchange = false, bool may_leave_apply = false) {
   // (below ~4M rollout-steps the generator takes less than the ~12 us a cross-stream dependency costs)
   static const bool no_side_stream = getenv("MPPI_NO_SIDE_STREAM") != nullptr;  // developer switch
-  // and above 8 rollout waves per CU the register file has no room for the generator's waves: it
-  // then runs in the rollout's tail and collides with the update (measured, profiles/r01_ablation.md)
+  // and above 8 rollout waves per CU the register file has room for one generator wave per SIMD only: the generator
+  // crawls beside the rollout, slows it, and still collides with the update (measured in round 1, profiles/r01_ablation.md,
+  // and again in round 6 with MPPI_SIDE_STREAM_MAX_WAVES=16: C5 187 us against 178, profiles/r06_ns_notes.md section 3)
+  static const int side_max_waves = getenv("MPPI_SIDE_STREAM_MAX_WAVES") ? atoi(getenv("MPPI_SIDE_STREAM_MAX_WAVES")) : 8;  // developer switch
   const bool side_stream_pays = (long)p->n_local * p->cfg.num_steps >= 4L * 1000 * 1000 &&
-                                ceil_div(ceil_div(p->n_local, 64), p->num_cus) <= 8 && !no_side_stream;
+                                ceil_div(ceil_div(p->n_local, 64), p->num_cus) <= side_max_waves && !no_side_stream;
   const bool ktime_stamps = p->ktime_index >= 0 && p->ktime_dev && p->ktime_use_stamps;  // (mppi_planner_time_kernels)
   if (prof) HIP_TRY(hipEventRecord(p->ev_stage[0], p->stream));
   // MPPI_MATH_FAST over a map the time-parallel kernel takes: the rollout launch computes its noise
