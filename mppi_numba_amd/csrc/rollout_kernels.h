@@ -527,7 +527,7 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
   const char* lds_bytes = reinterpret_cast<const char*>(lds_map);
 
   // the cell of (px, py) in the LDS window: the request only -- the value is looked at one step later
-  auto lookup = [&](float px, float py) -> uint32_t {
+  auto lookup = [&](float px, float py) {
     int xi, yi;
     if (POW2RES) {  // res is a power of two: see cell_coord_pow2
       xi = cell_coord_pow2(px, P.xlo, P.inv_res, win_c0f, win_last_col);
@@ -537,24 +537,40 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
       yi = clamp_index(floordiv_to_int(py - P.ylo, P.res, P.inv_res) - P.win_r0, P.win_rows);
     }
     // 32-bit cell (speed-map mode): the 16 bits below + the risk traction byte
-    if (SPEED) return *reinterpret_cast<const uint32_t*>(lds_bytes + (__mul24(yi, win_pitch_bytes) + (xi << 2)));
-    return *reinterpret_cast<const uint16_t*>(lds_bytes + (__mul24(yi, win_pitch_bytes) + (xi << 1)));
+    if constexpr (SPEED) {
+      return *reinterpret_cast<const uint32_t*>(lds_bytes + (__mul24(yi, win_pitch_bytes) + (xi << 2)));
+    } else {
+      // (handed on as a 16-bit FLOAT: a 16-bit integer is zero-extended next to the load -- v_and_b32 0xffff behind an
+      //  s_waitcnt, i.e. the wait for the gather right where it was issued, in front of the barrier below: the ISA of
+      //  round 6's first version -- while a half is just its bits in the low half of the register; pipe_cell_arrived.
+      //  Measured: nothing at ns / C4 / C5, where the generator's or the other rollout waves fill the slots either way)
+      return __builtin_bit_cast(_Float16, *reinterpret_cast<const uint16_t*>(lds_bytes + (__mul24(yi, win_pitch_bytes) + (xi << 1))));
+    }
   };
   // Round 6: the chain of a step is  cell -> traction -> x, y -> next cell, and its LDS gather (64 lanes, bank conflicts:
   // ~100+ cycles) was waited for a handful of instructions after it was issued -- with ONE wave per SIMD at N = 65536
   // nothing else covers it.  As in the pipelined kernels' state role the lookup of step t + 1 is requested the moment
   // x, y of step t exist, and the rotation and the whole cost side of step t run in its shadow.
-  uint32_t cell_now = lookup(x, y);
+  auto cell_now = lookup(x, y);
   auto step = [&](float2 ut, float2 e, [[maybe_unused]] int t) {
-    const uint32_t c16 = cell_now;  // the cell this step STARTS in
+    // the cell this step STARTS in: traction codes and penalty bits (the compiler's wait for the lookup lands here)
+    uint32_t lin_code, ang_code, pen_bits;
     double step_time = dt64;
-    if (SPEED) {
+    if constexpr (SPEED) {
+      const uint32_t c32 = cell_now;
+      lin_code = c32 & 127u;
+      ang_code = (c32 >> 7) & 127u;
+      pen_bits = c32 & 0xc000u;
       // time per step = dt over the risk-aware effective speed (mppi.py:1095-1096)
-      const double eff = fma(P.lin_ratio, (double)(int)(int8_t)(c16 >> 16), P.lin_lo);
+      const double eff = fma(P.lin_ratio, (double)(int)(int8_t)(c32 >> 16), P.lin_lo);
       step_time = dt64 / (eff + 1e-6);
+    } else {
+      asm volatile("v_and_b32 %0, 0x7f, %3\n\tv_bfe_u32 %1, %3, 7, 7\n\tv_and_b32 %2, 0xc000, %3"
+                   : "=&v"(lin_code), "=&v"(ang_code), "=v"(pen_bits)
+                   : "v"(cell_now));
     }
-    const double vtr = fma(P.lin_ratio, (double)(int)(c16 & 127u), P.lin_lo);
-    const double wtr = fma(P.ang_ratio, (double)(int)((c16 >> 7) & 127u), P.ang_lo);
+    const double vtr = fma(P.lin_ratio, (double)(int)lin_code, P.lin_lo);
+    const double wtr = fma(P.ang_ratio, (double)(int)ang_code, P.ang_lo);
     const double qv = dt64 * (double)clip_f32(ut.x + e.x, P.v_lo, P.v_hi);  // exact: float32 factors
     const double qw = dt64 * (double)clip_f32(ut.y + e.y, P.w_lo, P.w_hi);
     x = (float)fma(vtr, qv * c, x64);
@@ -575,8 +591,8 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
       const double dx = (double)(P.xg - x), dy = (double)(P.yg - y);
       const double nd2 = fma(dx, dx, dy * dy);
       float c1 = (float)((double)cost + fma(P.dist_weight, sqrt_newton_f64(nd2), step_time));
-      c1 = c1 + ((c16 & 0x4000u) ? P.obs_cost : 0.0f);  // cell the step STARTED in (mppi.py:971-998)
-      c1 = c1 + ((c16 & 0x8000u) ? P.unk_cost : 0.0f);
+      c1 = c1 + ((pen_bits & 0x4000u) ? P.obs_cost : 0.0f);  // cell the step STARTED in (mppi.py:971-998)
+      c1 = c1 + ((pen_bits & 0x8000u) ? P.unk_cost : 0.0f);
       const bool hit = nd2 <= gt2, act = !done;
       cost = act ? c1 : cost;
       d2 = act ? nd2 : d2;
