@@ -244,3 +244,13 @@ class MPPI_Numba(object):
         self.move_mppi_task_vars_to_device()
         _lib.call("mppi_planner_update", self._handle)
         self.u_prev_d = self._u_prev_view
+
+    def last_rollout_kernel(self):
+        """Which kernel variant the last rollout launch used (diagnostic string)."""
+        buf = C.create_string_buffer(512)
+        _lib.call("mppi_planner_describe_last_rollout", self._handle, buf, 512)
+        return buf.value.decode()
+
+    def set_debug_flags(self, flags):
+        """Developer switches (_lib.DEBUG_*): which rollout kernel variant runs; never the costs."""
+        _lib.call("mppi_planner_set_debug_flags", self._handle, int(flags))
