@@ -1038,7 +1038,14 @@ static int launch_rollout_t(mppi_planner* p, DevParams d) {
       const bool rot = EXACT && std::isfinite(dmax) && dmax <= 0.36 && p->cfg.num_steps <= 2000;
       const size_t lds_bb = sizeof(double2) * (size_t)p->cfg.num_steps + sizeof(float4) * (size_t)std::max(1, p->n_obstacles);
       REQUIRE(lds_bb <= 64 * 1024, MPPI_ERR_INVALID, "%d disc obstacles and %d steps: more than 64 KiB of LDS", p->n_obstacles, p->cfg.num_steps);
-      if (rot)
+      static const bool no_kd = getenv("MPPI_BAREBONE_NO_KD") != nullptr;  // developer switch (ablation)
+      if (rot && !no_kd && p->n_obstacles <= 2)
+        MPPI_KLAUNCH((k_rollout_barebone<EXACT, true, 2>), dim3(ceil_div(N, 64)), dim3(64), lds_bb + 2 * sizeof(float4),
+                     p->stream, d, p->obs_pos, p->obs_r, p->noise, p->u, p->costs);
+      else if (rot && !no_kd && p->n_obstacles <= 4)
+        MPPI_KLAUNCH((k_rollout_barebone<EXACT, true, 4>), dim3(ceil_div(N, 64)), dim3(64), lds_bb + 4 * sizeof(float4),
+                     p->stream, d, p->obs_pos, p->obs_r, p->noise, p->u, p->costs);
+      else if (rot)
         MPPI_KLAUNCH((k_rollout_barebone<EXACT, true>), dim3(ceil_div(N, 64)), dim3(64), lds_bb,
                      p->stream, d, p->obs_pos, p->obs_r, p->noise, p->u, p->costs);
       else

@@ -1391,7 +1391,10 @@ __global__ void k_cvar_reduce(const float* __restrict__ slabs, int count, int n_
 // published timing is this kernel's configuration: N = 1000, T = 50 -- 16 waves walking 50 dependent steps), the noise
 // in batches of eight loads, and the state keeps integrating past the goal (only the cost is frozen), as in
 // k_rollout_fused.  Same operations on the same operands for everything that reaches the cost.
-template <bool EXACT, bool ROT = false>
+// KD (round 6): the disc count as a compile-time bound -- >= 0: exactly the discs 0 .. KD-1 are tested, slots past
+// n_obstacles hold a disc nobody can touch (the same additions of +0.0) -- so that a batch of eight steps is ONE basic
+// block and the scheduler may run step t's cost beside step t+1's state; -1: the run-time loop.
+template <bool EXACT, bool ROT = false, int KD = -1>
 __global__ __launch_bounds__(64) void k_rollout_barebone(DevParams P, const float2* __restrict__ obs_pos,
                                                          const float* __restrict__ obs_r,
                                                          const float2* __restrict__ noise,
@@ -1406,6 +1409,8 @@ __global__ __launch_bounds__(64) void k_rollout_barebone(DevParams P, const floa
     const float2 op = obs_pos[k];
     discs[k] = make_float4(op.x, op.y, obs_r[k], 0.0f);
   }
+  if (KD > 0)  // (slots past the last disc: far away, radius 0 -- `diff > 0`, no hit, +0.0 added)
+    for (int k = P.n_obstacles + (int)threadIdx.x; k < KD; k += 64) discs[k] = make_float4(1e18f, 1e18f, 0.0f, 0.0f);
   stage_control_ratios(P, u, uos);  // (ends with a barrier)
   const int n = blockIdx.x * 64 + threadIdx.x;
   const bool live = n < P.n_local;
@@ -1440,7 +1445,8 @@ __global__ __launch_bounds__(64) void k_rollout_barebone(DevParams P, const floa
     double dx = (double)(P.xg - nx), dy = (double)(P.yg - ny);
     nd2 = fma(dx, dx, dy * dy);
     float c1 = (float)((double)cost + P.dist_weight * nd2);
-    for (int k = 0; k < P.n_obstacles; ++k) {
+#pragma unroll
+    for (int k = 0; k < (KD >= 0 ? KD : P.n_obstacles); ++k) {
       const float4 op = discs[k];
       double ex = (double)(nx - op.x), ey = (double)(ny - op.y);
       double rr = (double)op.z * (double)op.z;
@@ -1470,8 +1476,68 @@ __global__ __launch_bounds__(64) void k_rollout_barebone(DevParams P, const floa
     for (; t0 + kNoiseBatch <= T; t0 += kNoiseBatch) {
 #pragma unroll
       for (int j = 0; j < kNoiseBatch; ++j) e_nxt[j] = col[(size_t)min(t0 + kNoiseBatch + j, T - 1) * 64];
+      if constexpr (EXACT && KD >= 0) {
+        // Round 6: a lone wave issues a DEPENDENT instruction every ~9 cycles, an independent one every ~5
+        // (tools/microbench/icache_cold.hip, issue_cost.hip), and step by step this kernel is one long chain.  Per batch
+        // of eight steps: first everything that does not depend on the position -- clipped controls, the heading (one
+        // float32 addition per step) and the polynomials of the rotation's exact increments: eight independent streams --
+        // then the positions with the rotation (three short chains), then what each step adds to the cost (independent
+        // again), then the cost itself: the float32-rounded additions, 3 + 3 per disc dependent instructions per step
+        // and nothing else in the chain.  The same operations on the same operands as step() above.
+        double q64[kNoiseBatch], sd[kNoiseBatch], cd[kNoiseBatch];
 #pragma unroll
-      for (int j = 0; j < kNoiseBatch; ++j) step(u[t0 + j], e_cur[j]);
+        for (int j = 0; j < kNoiseBatch; ++j) {
+          const float2 ut = u[t0 + j];
+          const float v = clip_f32(ut.x + e_cur[j].x, P.v_lo, P.v_hi);
+          const float w = clip_f32(ut.y + e_cur[j].y, P.w_lo, P.w_hi);
+          q64[j] = (double)(P.dt * v);  // float32 * float32 first (cell 3: dt_d*v_noisy*math.cos(...))
+          const float nth = th + P.dt * w;
+          sincos_increment_f64((double)nth - (double)th, sd[j], cd[j]);  // exact increment of the ROUNDED heading
+          th = nth;
+        }
+        // the positions (and the rotation): three short chains
+        float nxa[kNoiseBatch], nya[kNoiseBatch];
+#pragma unroll
+        for (int j = 0; j < kNoiseBatch; ++j) {
+          nxa[j] = (float)fma(q64[j], rc, (double)x);
+          nya[j] = (float)fma(q64[j], rs, (double)y);
+          apply_rotation_f64(sd[j], cd[j], rs, rc);
+          x = nxa[j];
+          y = nya[j];
+        }
+        // what each step adds to the cost -- distance term, one term per disc --: independent of each other
+        double nd2a[kNoiseBatch], add0[kNoiseBatch], addk[kNoiseBatch][KD > 0 ? KD : 1];
+#pragma unroll
+        for (int j = 0; j < kNoiseBatch; ++j) {
+          const double dx = (double)(P.xg - nxa[j]), dy = (double)(P.yg - nya[j]);
+          nd2a[j] = fma(dx, dx, dy * dy);
+          add0[j] = P.dist_weight * nd2a[j];
+#pragma unroll
+          for (int k = 0; k < KD; ++k) {
+            const float4 op = discs[k];
+            const double ex = (double)(nxa[j] - op.x), ey = (double)(nya[j] - op.y);
+            const double rr = (double)op.z * (double)op.z;
+            const double diff = fma(ex, ex, ey * ey) - rr;
+            const double hit = (diff > 0.0) ? 0.0 : 1.0;
+            addk[j][k] = hit * (double)P.obs_cost;
+          }
+        }
+        // the cost: the float32-rounded additions in the reference's order -- the one long chain, nothing else in it
+#pragma unroll
+        for (int j = 0; j < kNoiseBatch; ++j) {
+          float c1 = (float)((double)cost + add0[j]);
+#pragma unroll
+          for (int k = 0; k < KD; ++k) c1 = (float)((double)c1 + addk[j][k]);
+          const bool hit_goal = nd2a[j] <= (double)P.gt2, act = !done;
+          cost = act ? c1 : cost;
+          d2 = act ? nd2a[j] : d2;
+          reached = reached || (act && hit_goal);
+          done = done || hit_goal;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < kNoiseBatch; ++j) step(u[t0 + j], e_cur[j]);
+      }
 #pragma unroll
       for (int j = 0; j < kNoiseBatch; ++j) e_cur[j] = e_nxt[j];
       if (__all(done)) break;
