@@ -488,6 +488,7 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
   extern __shared__ double2 uos[];
   signal_progress(P);
   ktime_begin(P);
+  MPPI_STAMP(blockIdx.x == 5 && threadIdx.x == 0, 710);  // (stamps build: tools/fused_stamps.py)
   // batched handle: the waves of a workgroup belong to one problem (host: blockDim/64 divides inst_tiles)
   u = select_instance(P, u, P.inst ? (int)(blockIdx.x * (blockDim.x >> 6)) / P.inst_tiles : 0);
   const int T = P.n_steps, N = P.n_local;
@@ -514,6 +515,7 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
     return;
   }
 
+  MPPI_STAMP(blockIdx.x == 5 && threadIdx.x == 0, 711);  // (stamps build: tools/fused_stamps.py)
   float x = P.x0, y = P.y0, th = P.th0, cost = 0.0f;
   [[maybe_unused]] float cc32 = 0.0f;
   double x64 = (double)x, y64 = (double)y, th64 = (double)th, d2 = 1e9;
@@ -624,6 +626,7 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
       for (int j = 0; j + 1 < kNoiseBatch; ++j) e_cur[j] = e_cur[j + 1];
     }
 
+  MPPI_STAMP(blockIdx.x == 5 && threadIdx.x == 0, 712);  // (stamps build: tools/fused_stamps.py)
   // terminal cost, then the control cost of all T steps (mppi.py:1005-1009): the float32-rounded
   // accumulation is sequential, loads and products are batched
   cost = (float)((double)cost + (reached ? 0.0 : 1.0) * sqrt(d2) / P.v_post_den);
@@ -642,6 +645,7 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
     for (int j = 0; j < kNoiseBatch; ++j) cost = (float)((double)cost + cc[j]);
   }
   for (int t = t0; t < T; ++t) cost = (float)((double)cost + control_cost(P, uos[t], col[(size_t)t * 64]));
+  MPPI_STAMP(blockIdx.x == 5 && threadIdx.x == 0, 713);  // (stamps build: tools/fused_stamps.py)
   if (live) costs[n] = cost;
   // first half of the control update (update_kernels.h): weights relative to the tile's minimum
   if ((n & ~63) < N) emit_tile_weights(cost, live, P.lambda, n, n >> 6, w_rel, tile_beta);
