@@ -840,16 +840,38 @@ static int launch_windowed_or_general(mppi_planner* p, DevParams& d, const DetRe
     static const bool no_fused = getenv("MPPI_NO_FUSED") != nullptr;  // developer switch (ablation)
     if ((rot_ok || r.rot_ok_fast) && !no_fused) {
       // (MPPI_MATH_FAST: one pass over the noise, the control cost added once)
-      auto fused = EXACT ? (pow2res ? k_rollout_fused<true> : k_rollout_fused<false>)
+      // (round 6: workgroups of at most four waves -- nobody hides a wave's trips to memory: k_rollout_fused, LONE)
+      static const bool no_lone = getenv("MPPI_NO_FUSED_LONE") != nullptr;  // developer switch (ablation)
+      const bool lone = EXACT && waves <= 4 && !no_lone;
+      auto fused = EXACT ? (lone ? (pow2res ? k_rollout_fused<true, false, false, true> : k_rollout_fused<false, false, false, true>)
+                                 : (pow2res ? k_rollout_fused<true> : k_rollout_fused<false>))
                          : (pow2res ? k_rollout_fused<true, false, true> : k_rollout_fused<false, false, true>);
-      if (lds_win > 64 * 1024)
+      // Round 6 (exact mode reads the noise twice): what the window leaves of the CU's LDS keeps the noise of the first
+      // steps for the second pass -- one workgroup per CU either way (DevParams::stash_steps; N = 65536, T = 100: 56 of
+      // the 100 steps of each of the four waves)
+      static const bool no_stash = getenv("MPPI_NO_NOISE_STASH") != nullptr;  // developer switch (ablation)
+      size_t lds_fused = lds_win;
+      d.stash_steps = d.stash_offset = 0;
+      if (EXACT && !no_stash) {
+        const size_t off = (lds_win + 15) & ~(size_t)15, limit = (size_t)p->lds_per_cu - 1024;
+        if (limit > off) {
+          const int fit = (int)((limit - off) / ((size_t)waves * 64 * sizeof(float2)));
+          const int steps = std::min(fit, T) & ~7;
+          if (steps >= 8) {
+            d.stash_steps = steps;
+            d.stash_offset = (int)off;
+            lds_fused = off + (size_t)waves * (size_t)steps * 64 * sizeof(float2);
+          }
+        }
+      }
+      if (lds_fused > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(fused),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_win));
-      MPPI_KLAUNCH_WAITS_ITSELF(fused, dim3(ceil_div(N, block)), dim3(block), lds_win, p->stream, noise_flag_params(p, d), p->cells16,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fused));
+      MPPI_KLAUNCH_WAITS_ITSELF(fused, dim3(ceil_div(N, block)), dim3(block), lds_fused, p->stream, noise_flag_params(p, d), p->cells16,
                                 p->noise, p->u, p->costs, p->w_rel, p->tile_beta);
       char buf[200];
-      snprintf(buf, sizeof(buf), "k_rollout_fused%s pow2res=%d waves_per_wg=%d window=%dx%d problems=%d",
-               EXACT ? "" : "<one pass>", (int)pow2res, waves, d.win_rows, d.win_cols, p->inst_set ? p->B : 0);
+      snprintf(buf, sizeof(buf), "k_rollout_fused%s pow2res=%d waves_per_wg=%d window=%dx%d problems=%d noise_kept=%d",
+               EXACT ? "" : "<one pass>", (int)pow2res, waves, d.win_rows, d.win_cols, p->inst_set ? p->B : 0, d.stash_steps);
       p->last_rollout = buf;
       p->tile_packets_fresh = true;
             return MPPI_OK;

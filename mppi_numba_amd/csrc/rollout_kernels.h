@@ -54,6 +54,10 @@ struct DevParams {
   int n_grids;        // M
   int rows, cols;     // padded map dims Rp, Cp
   int n_obstacles;    // barebone only
+  // k_rollout_fused, exact mode (round 6): the noise of the first `stash_steps` steps (a multiple of 8) is kept in the
+  // LDS the window leaves free, `stash_offset` bytes into the dynamic LDS, [wave][step][64] float2, for the control-cost
+  // pass -- which otherwise reads all of it from memory again, every wave at the same time (0: nothing is kept)
+  int stash_steps, stash_offset;
   // LDS-resident window of the 16-bit cell map (deterministic modes)
   int win_r0, win_c0;      // first row / column of the window (column multiple of 8)
   int win_rows, win_cols;  // window size; win_cols is a multiple of 8
@@ -480,8 +484,13 @@ __global__ void k_rollout_map(DevParams P, const uint32_t* __restrict__ cells,
 // the floor of ANY single-pass design, tests/test_cost_order_noise.py).
 // LDS (ONEPASS): [T] float2 control ratios in the double2 area.
 // -------------------------------------------------------------------------
-template <bool POW2RES, bool SPEED = false, bool ONEPASS = false>
-__global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells16,
+// LONE (round 6; exact det mode, workgroups of at most four waves: one or two waves per SIMD, N = 65536 on one GPU):
+// nobody hides this wave's trips to memory, and the control-cost pass made one per eight steps (2k cycles each) and one
+// per step of the horizon's last, shorter batch.  Here everything that pass still reads from memory is requested at
+// once, in front of the steps it reads from the noise kept in LDS (DevParams::stash_steps); 256 registers per lane
+// (launch bound of four waves) hold it.
+template <bool POW2RES, bool SPEED = false, bool ONEPASS = false, bool LONE = false>
+__global__ __launch_bounds__(LONE ? 256 : 1024) void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells16,
                                 const float2* __restrict__ noise, const float2* __restrict__ u,
                                 float* __restrict__ costs, float* __restrict__ w_rel,
                                 float* __restrict__ tile_beta) {
@@ -510,6 +519,10 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
   const bool live = n < N;
   const int nn = live ? n : N - 1;
   const float2* col = noise + tile_index(0, nn, T);  // this lane's column; rows are 64 apart
+  // (exact mode) this wave's rows of the noise stash: see DevParams::stash_steps
+  float2* stash = reinterpret_cast<float2*>(reinterpret_cast<char*>(uos) + P.stash_offset) +
+                  ((size_t)(threadIdx.x >> 6) * (size_t)P.stash_steps * 64 + (threadIdx.x & 63));
+  [[maybe_unused]] int stashed = 0;  // steps [0, stashed) of this wave's noise are in LDS
   if (!wait_for_noise(P)) {  // (workgroup-uniform; reported by the host: DevParams::flag_fault)
     ktime_end(P);
     return;
@@ -611,6 +624,11 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
   for (; t0 + kNoiseBatch <= T; t0 += kNoiseBatch) {
 #pragma unroll
     for (int j = 0; j < kNoiseBatch; ++j) e_nxt[j] = col[(size_t)min(t0 + kNoiseBatch + j, T - 1) * 64];
+    if (!ONEPASS && t0 < P.stash_steps) {  // (uniform; stash_steps is a multiple of the batch)
+#pragma unroll
+      for (int j = 0; j < kNoiseBatch; ++j) stash[(size_t)(t0 + j) * 64] = e_cur[j];
+      stashed = t0 + kNoiseBatch;
+    }
 #pragma unroll
     for (int j = 0; j < kNoiseBatch; ++j) step(us[t0 + j], e_cur[j], t0 + j);
 #pragma unroll
@@ -637,10 +655,59 @@ __global__ void k_rollout_fused(DevParams P, const uint16_t* __restrict__ cells1
     ktime_end(P);
     return;
   }
+  // (round 6: the steps whose noise this wave kept in LDS come from there -- all waves reach this pass together, and 52 MB
+  //  read again at once ran at the speed of the memory, 5.9 TB/s: profiles/r06_ns_notes.md, section 5)
+  if constexpr (LONE) {
+    static_assert(!LONE || (!SPEED && !ONEPASS), "LONE serves the exact deterministic mode");
+    // the batches behind the kept steps: up to kPre of them and the horizon's last, shorter batch, all in flight at once
+    constexpr int kPre = 6;
+    float2 g[kPre][kNoiseBatch], gt[kNoiseBatch - 1];
+    const int full = (T / kNoiseBatch) * kNoiseBatch;  // steps in whole batches
+#pragma unroll
+    for (int b = 0; b < kPre; ++b)
+#pragma unroll
+      for (int j = 0; j < kNoiseBatch; ++j) g[b][j] = col[(size_t)min(stashed + b * kNoiseBatch + j, T - 1) * 64];
+#pragma unroll
+    for (int j = 0; j < kNoiseBatch - 1; ++j) gt[j] = col[(size_t)min(full + j, T - 1) * 64];
+    for (t0 = 0; t0 < stashed; t0 += kNoiseBatch) {  // from LDS
+      double cc[kNoiseBatch];
+#pragma unroll
+      for (int j = 0; j < kNoiseBatch; ++j) cc[j] = control_cost(P, uos[t0 + j], stash[(size_t)(t0 + j) * 64]);
+#pragma unroll
+      for (int j = 0; j < kNoiseBatch; ++j) cost = (float)((double)cost + cc[j]);
+    }
+#pragma unroll
+    for (int b = 0; b < kPre; ++b) {  // requested above
+      if (t0 + kNoiseBatch <= T) {  // (uniform)
+        double cc[kNoiseBatch];
+#pragma unroll
+        for (int j = 0; j < kNoiseBatch; ++j) cc[j] = control_cost(P, uos[t0 + j], g[b][j]);
+#pragma unroll
+        for (int j = 0; j < kNoiseBatch; ++j) cost = (float)((double)cost + cc[j]);
+        t0 += kNoiseBatch;
+      }
+    }
+    for (; t0 + kNoiseBatch <= T; t0 += kNoiseBatch) {  // a longer horizon: one trip per batch, as before
+      double cc[kNoiseBatch];
+#pragma unroll
+      for (int j = 0; j < kNoiseBatch; ++j) cc[j] = control_cost(P, uos[t0 + j], col[(size_t)(t0 + j) * 64]);
+#pragma unroll
+      for (int j = 0; j < kNoiseBatch; ++j) cost = (float)((double)cost + cc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kNoiseBatch - 1; ++j)
+      if (full + j < T) cost = (float)((double)cost + control_cost(P, uos[full + j], gt[j]));
+    t0 = T;
+  } else
   for (t0 = 0; t0 + kNoiseBatch <= T; t0 += kNoiseBatch) {
     double cc[kNoiseBatch];
+    if (t0 + kNoiseBatch <= stashed) {
 #pragma unroll
-    for (int j = 0; j < kNoiseBatch; ++j) cc[j] = control_cost(P, uos[t0 + j], col[(size_t)(t0 + j) * 64]);
+      for (int j = 0; j < kNoiseBatch; ++j) cc[j] = control_cost(P, uos[t0 + j], stash[(size_t)(t0 + j) * 64]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kNoiseBatch; ++j) cc[j] = control_cost(P, uos[t0 + j], col[(size_t)(t0 + j) * 64]);
+    }
 #pragma unroll
     for (int j = 0; j < kNoiseBatch; ++j) cost = (float)((double)cost + cc[j]);
   }

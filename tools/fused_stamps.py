@@ -14,5 +14,7 @@ for rep in range(3):
     planner.iterate_async(1); planner.synchronize()
     _lib.call("mppi_debug_read_stamps", buf, 1024, 1)
     st = [buf[710 + i] for i in range(4)]
+    ex = [buf[714 + i] for i in range(3)]
+    if all(ex): print('   pass detail: terminal %d | batches 0-6 %d | batches 7-11 %d | tail steps %d' % (ex[0]-st[2], ex[1]-ex[0], ex[2]-ex[1], st[3]-ex[2]))
     print(planner.last_rollout_kernel()[:60], "| prologue %d  step loop %d  terminal + control-cost pass %d  total %d cycles" %
           (st[1] - st[0], st[2] - st[1], st[3] - st[2], st[3] - st[0]))
