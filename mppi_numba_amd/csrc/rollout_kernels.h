@@ -655,8 +655,8 @@ __global__ __launch_bounds__(LONE ? 256 : 1024) void k_rollout_fused(DevParams P
     ktime_end(P);
     return;
   }
-  // (round 6: the steps whose noise this wave kept in LDS come from there -- all waves reach this pass together, and 52 MB
-  //  read again at once ran at the speed of the memory, 5.9 TB/s: profiles/r06_ns_notes.md, section 5)
+  // (round 6: the steps whose noise this wave kept in LDS come from there -- with one or two waves per SIMD every batch
+  //  of this pass was a trip to memory nobody hid: profiles/r06_ns_notes.md, section 5)
   if constexpr (LONE) {
     static_assert(!LONE || (!SPEED && !ONEPASS), "LONE serves the exact deterministic mode");
     // the batches behind the kept steps: up to kPre of them and the horizon's last, shorter batch, all in flight at once
